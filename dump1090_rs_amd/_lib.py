@@ -1,0 +1,94 @@
+"""ctypes binding of libadsb_hip.so (include/adsb_hip.h).  No fallback: if the HIP
+library is missing this raises, it never routes anywhere else."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libadsb_hip.so"
+
+ADSB_OK = 0
+ADSB_ERR_INVALID = -1
+ADSB_ERR_NO_DEVICE = -2
+ADSB_ERR_HIP = -3
+ADSB_ERR_TOO_LONG = -4
+ADSB_ERR_CAPACITY = -5
+ADSB_ERR_NOMEM = -6
+
+
+class AdsbMsg(C.Structure):
+    """adsb_msg (include/adsb_hip.h) == ModeSMessage + provenance."""
+    _fields_ = [
+        ("msg", C.c_uint8 * 14),
+        ("len", C.c_uint8),
+        ("try_phase", C.c_uint8),
+        ("score", C.c_int32),
+        ("j", C.c_uint32),
+        ("chunk", C.c_uint64),
+        ("signal_level", C.c_double),
+    ]
+
+
+class AdsbStats(C.Structure):
+    _fields_ = [
+        ("n_samples", C.c_uint64),
+        ("n_chunks", C.c_uint64),
+        ("n_candidates", C.c_uint64),
+        ("n_ap_entries", C.c_uint64),
+        ("n_records", C.c_uint64),
+        ("n_messages", C.c_uint64),
+        ("ms_scan", C.c_float),
+        ("ms_match", C.c_float),
+        ("ms_records", C.c_float),
+        ("ms_total_device", C.c_float),
+        ("retries", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class AdsbError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{what}: {detail}" if detail else what)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libadsb_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m dump1090_rs_amd.build` "
+            "(there is no CPU fallback for the demod_2400 path)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, sz = C.c_void_p, C.c_size_t
+    L.adsb_create.argtypes = [C.POINTER(vp), C.c_int, sz]
+    L.adsb_destroy.argtypes = [vp]
+    L.adsb_destroy.restype = None
+    L.adsb_set_stream.argtypes = [vp, vp]
+    L.adsb_set_profiling.argtypes = [vp, C.c_int]
+    L.adsb_icao_flush.argtypes = [vp]
+    L.adsb_to_mag.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
+    L.adsb_demodulate2400.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_demod_iq.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_demod_iq_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_read_test_data.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
+    L.adsb_get_stats.argtypes = [vp, C.POINTER(AdsbStats)]
+    L.adsb_replay_records.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_selftest_mag_digest.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.adsb_strerror.argtypes = [C.c_int]
+    L.adsb_strerror.restype = C.c_char_p
+    L.adsb_last_error.argtypes = [vp]
+    L.adsb_last_error.restype = C.c_char_p
+    L.adsb_version.restype = C.c_char_p
+    for name in ("adsb_create", "adsb_set_stream", "adsb_set_profiling", "adsb_icao_flush",
+                 "adsb_to_mag", "adsb_demodulate2400", "adsb_demod_iq", "adsb_demod_iq_device",
+                 "adsb_read_test_data", "adsb_get_stats", "adsb_replay_records",
+                 "adsb_selftest_mag_digest"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,55 @@
+"""Build libadsb_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+    python -m dump1090_rs_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU
+box with the tree.  -ffp-contract=off is load-bearing: the magnitude pipeline
+(reference src/utils.rs:53-55) has one separately rounded multiply that must not
+be fused.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libadsb_hip.so"
+SOURCES = [CSRC / "adsb_kernels.hip", CSRC / "adsb_host.cpp"]
+HEADERS = [CSRC / "adsb_device.h", CSRC / "mode_s_host.hpp", PKG.parent / "include" / "adsb_hip.h"]
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    "-Wall", "-Wextra", "-x", "hip",
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libadsb_hip.so cannot be built")
+    return exe
+
+
+def stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS + [Path(__file__)])
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc(), *FLAGS, *map(str, SOURCES), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv, verbose=True)
+    print(LIB)

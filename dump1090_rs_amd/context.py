@@ -1,0 +1,185 @@
+"""Context: one GPU stream of the demod_2400 path (wraps adsb_ctx of include/adsb_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import AdsbError, AdsbMsg, AdsbStats
+
+# reference src/lib.rs:22-26
+MODES_MAG_BUF_SAMPLES = 131_072
+TRAILING_SAMPLES = 326
+MODES_LONG_MSG_BYTES = 14
+MODES_SHORT_MSG_BYTES = 7
+MAG_DATA_LEN = TRAILING_SAMPLES + MODES_MAG_BUF_SAMPLES
+
+
+@dataclass
+class MagnitudeBuffer:
+    """reference src/lib.rs:30-51: 326 zero lead-in samples, then `length` magnitudes."""
+    data: np.ndarray = field(default_factory=lambda: np.zeros(MAG_DATA_LEN, dtype=np.uint16))
+    length: int = 0
+    first_sample_timestamp_12mhz: int = 0
+
+    def push(self, x: int) -> None:  # src/lib.rs:47-50
+        if self.length >= MODES_MAG_BUF_SAMPLES:
+            raise IndexError("MagnitudeBuffer is full")  # the reference panics (index OOB)
+        self.data[TRAILING_SAMPLES + self.length] = x
+        self.length += 1
+
+
+@dataclass(frozen=True)
+class ModeSMessage:
+    """reference src/demod_2400.rs:92-112.  Only buffer() is public upstream; the
+    other fields are what its Debug output shows, plus (chunk, j, try_phase)."""
+    msg: bytes          # all 14 sliced bytes
+    msglen: int         # 7 (MsgLen::Short) | 14 (MsgLen::Long)
+    signal_level: float
+    score: int
+    j: int = 0
+    try_phase: int = 0
+    chunk: int = 0
+
+    def buffer(self) -> bytes:  # src/demod_2400.rs:106-111
+        return self.msg[: self.msglen]
+
+
+def _as_iq(iq) -> np.ndarray:
+    """Accept (N,2) int16 [re, im] rows, flat interleaved int16, or complex arrays of ints."""
+    a = np.asarray(iq)
+    if np.iscomplexobj(a):
+        a = np.stack([a.real, a.imag], axis=-1)
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    if a.ndim == 1:
+        if a.size % 2:
+            raise ValueError("interleaved IQ needs an even number of int16")
+        a = a.reshape(-1, 2)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError("IQ must be (N, 2) int16 rows of [re, im]")
+    return a
+
+
+class Context:
+    """One adsb_ctx: device buffers, stream and the ICAO filter of one stream of IQ."""
+
+    def __init__(self, device: int = 0, max_chunks: int = 1):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        st = self._L.adsb_create(C.byref(self._h), int(device), int(max_chunks))
+        if st != _lib.ADSB_OK:
+            self._h = C.c_void_p()
+            raise AdsbError(st, "adsb_create", self._L.adsb_strerror(st).decode())
+        self.device = device
+        self.max_chunks = max_chunks
+
+    # -- lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.adsb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st: int, what: str) -> None:
+        if st != _lib.ADSB_OK:
+            detail = self._L.adsb_last_error(self._h).decode() if st == _lib.ADSB_ERR_HIP else ""
+            raise AdsbError(st, f"{what}: {self._L.adsb_strerror(st).decode()}", detail)
+
+    # -- reference API
+    def icao_flush(self) -> None:
+        self._check(self._L.adsb_icao_flush(self._h), "adsb_icao_flush")
+
+    def to_mag(self, iq) -> MagnitudeBuffer:
+        a = _as_iq(iq)
+        out = MagnitudeBuffer()
+        n = C.c_size_t()
+        st = self._L.adsb_to_mag(self._h, a.ctypes.data, a.shape[0], out.data.ctypes.data, C.byref(n))
+        if st == _lib.ADSB_ERR_TOO_LONG:
+            raise IndexError("to_mag: more than 131072 samples (the reference panics here)")
+        self._check(st, "adsb_to_mag")
+        out.length = n.value
+        return out
+
+    def _collect(self, call, what: str, cap: int) -> List[ModeSMessage]:
+        while True:
+            buf = (AdsbMsg * cap)()
+            n = C.c_size_t()
+            st = call(buf, cap, C.byref(n))
+            if st == _lib.ADSB_ERR_CAPACITY:
+                raise AdsbError(st, f"{what}: output of {n.value} messages exceeds cap {cap}")
+            self._check(st, what)
+            return [
+                ModeSMessage(bytes(m.msg), int(m.len), float(m.signal_level), int(m.score),
+                             int(m.j), int(m.try_phase), int(m.chunk))
+                for m in buf[: n.value]
+            ]
+
+    def demodulate2400(self, mag: MagnitudeBuffer, cap: int = 4096) -> List[ModeSMessage]:
+        data = np.ascontiguousarray(mag.data, dtype=np.uint16)
+        if data.shape != (MAG_DATA_LEN,):
+            raise ValueError("MagnitudeBuffer.data must hold 131398 u16")
+        if mag.length > MODES_MAG_BUF_SAMPLES:
+            raise IndexError("MagnitudeBuffer.length > 131072")
+        return self._collect(
+            lambda out, c, n: self._L.adsb_demodulate2400(self._h, data.ctypes.data, mag.length, out, c, n),
+            "adsb_demodulate2400", cap)
+
+    # -- stream forms (to_mag + demodulate2400 per 131072-sample buffer)
+    def demod_iq(self, iq, cap: Optional[int] = None) -> List[ModeSMessage]:
+        a = _as_iq(iq)
+        cap = cap or max(4096, a.shape[0] // 256)
+        return self._collect(
+            lambda out, c, n: self._L.adsb_demod_iq(self._h, a.ctypes.data, a.shape[0], out, c, n),
+            "adsb_demod_iq", cap)
+
+    def demod_iq_device(self, device_ptr: int, n_samples: int, cap: Optional[int] = None
+                        ) -> List[ModeSMessage]:
+        cap = cap or max(4096, n_samples // 256)
+        return self._collect(
+            lambda out, c, n: self._L.adsb_demod_iq_device(self._h, C.c_void_p(device_ptr), n_samples, out, c, n),
+            "adsb_demod_iq_device", cap)
+
+    def demod_iq_device_raw(self, device_ptr: int, n_samples: int, out_buf, cap: int) -> int:
+        """No Python-side unpacking: for the bench loop.  Returns the message count."""
+        n = C.c_size_t()
+        st = self._L.adsb_demod_iq_device(self._h, C.c_void_p(device_ptr), n_samples, out_buf, cap, C.byref(n))
+        self._check(st, "adsb_demod_iq_device")
+        return n.value
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._L.adsb_set_stream(self._h, C.c_void_p(hip_stream)), "adsb_set_stream")
+
+    def set_profiling(self, enabled: bool) -> None:
+        self._check(self._L.adsb_set_profiling(self._h, int(enabled)), "adsb_set_profiling")
+
+    def stats(self) -> dict:
+        s = AdsbStats()
+        self._check(self._L.adsb_get_stats(self._h, C.byref(s)), "adsb_get_stats")
+        return {name: getattr(s, name) for name, _ in AdsbStats._fields_ if name != "reserved"}
+
+
+_default: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """The process-wide context that stands in for the reference's global filter
+    statics (src/icao_filter.rs:8-9).  Device = LOCAL_RANK if set, else 0."""
+    global _default
+    if _default is None:
+        _default = Context(device=int(os.environ.get("LOCAL_RANK", "0")), max_chunks=1)
+    return _default

@@ -1,0 +1,480 @@
+// adsb_host.cpp -- context, C ABI (include/adsb_hip.h) and the ordered host replay.
+//
+// The functions here mirror the reference's library API for the path
+// (src/utils.rs:43 to_mag, src/demod_2400.rs:115 demodulate2400,
+// src/icao_filter.rs:11 icao_flush); what each one replaces is listed in the header.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/adsb_hip.h"
+#include "adsb_device.h"
+#include "mode_s_host.hpp"
+
+using namespace adsb;
+
+struct adsb_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool profiling = true;
+    size_t max_chunks = 0;
+
+    void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
+    size_t stage_bytes = 0;
+    uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
+    uint32_t *d_bitmap = nullptr;
+    Counters *d_ctr = nullptr;
+    uint64_t *d_hits = nullptr, *d_ap = nullptr;
+    TrialRecord *d_rec = nullptr;
+    uint32_t hits_cap = 0, ap_cap = 0;
+
+    Counters *h_ctr = nullptr;     // pinned
+    TrialRecord *h_rec = nullptr;  // pinned, hits_cap entries
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    IcaoFilter filter;
+    Crc24 crc;
+    adsb_stats stats{};
+    std::string last_error;
+};
+
+namespace {
+
+constexpr size_t kBitmapBytes = (1u << 24) / 8;
+constexpr uint32_t kWorstPerChunk = 5u * kChunkSamples;  // every j sliced, 5 trials each
+
+int fail(adsb_ctx *c, hipError_t e, const char *what)
+{
+    if (c) {
+        c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return ADSB_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return fail((ctx), e_, #call); \
+    } while (0)
+
+int reset_bitmap(adsb_ctx *c)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_bitmap, 0, kBitmapBytes, c->stream));
+    // address 0 always tests true (src/icao_filter.rs:71-80: an empty slot equals 0)
+    const uint32_t one = 1;
+    HIP_TRY(c, hipMemcpyAsync(c->d_bitmap, &one, sizeof(one), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ADSB_OK;
+}
+
+// Ordered replay (src/demod_2400.rs:149-207 with mode_s scoring): records sorted by
+// (chunk, j, try_phase); per (chunk, j) the best trial by strictly-greater score
+// starting from -2 wins and is emitted when its score is >= 0.
+void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out)
+{
+    std::sort(rec, rec + n, [](const TrialRecord &a, const TrialRecord &b) {
+        if (a.chunk != b.chunk) return a.chunk < b.chunk;
+        const uint32_t ja = a.j_tp & 0xFFFFFFu, jb = b.j_tp & 0xFFFFFFu;
+        if (ja != jb) return ja < jb;
+        return (a.j_tp >> 24) < (b.j_tp >> 24);
+    });
+    size_t i = 0;
+    while (i < n) {
+        const uint32_t chunk = rec[i].chunk, j = rec[i].j_tp & 0xFFFFFFu;
+        adsb_msg best{};
+        best.score = -2;
+        best.len = ADSB_MODES_SHORT_MSG_BYTES;
+        for (; i < n && rec[i].chunk == chunk && (rec[i].j_tp & 0xFFFFFFu) == j; i++) {
+            const TrialRecord &r = rec[i];
+            const Score s = score_modes_message(filter, crc, r.msg);
+            if (!s.some || s.value <= best.score) continue;
+            std::memcpy(best.msg, r.msg, 14);
+            best.len = (uint8_t)s.len;
+            best.score = s.value;
+            best.try_phase = (uint8_t)(r.j_tp >> 24);
+            // demod_2400.rs:191-198: signal_len = 14*12/5 = 33
+            const double signal_power = (double)r.power / 65535.0 / 65535.0;
+            best.signal_level = signal_power / 33.0;
+        }
+        if (best.score < 0) continue;
+        best.j = j;
+        best.chunk = chunk_offset + chunk;
+        out.push_back(best);
+    }
+}
+
+// One device pass over n_chunks chunks starting at d_src.  Returns 1 when a device
+// list overflowed (caller retries in smaller pieces), 0 on success, <0 on error.
+int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, uint32_t n_chunks,
+              uint64_t chunk_offset, std::vector<adsb_msg> &out)
+{
+    ScanParams p{};
+    p.src = d_src;
+    p.n_samples = n_samples;
+    p.n_chunks = n_chunks;
+    p.bitmap = c->d_bitmap;
+    p.hits = c->d_hits;
+    p.hits_cap = c->hits_cap;
+    p.ap = c->d_ap;
+    p.ap_cap = c->ap_cap;
+    p.ctr = c->d_ctr;
+
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (int e = launch_records(p, from_mag, c->d_rec, c->stream))
+        return fail(c, (hipError_t)e, "launch_records");
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    if (c->h_ctr->overflow) return 1;
+    const size_t n = c->h_ctr->n_hits;
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_rec, c->d_rec, n * sizeof(TrialRecord),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->profiling) {
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->stats.ms_scan += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+        c->stats.ms_match += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        c->stats.ms_records += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3]));
+        c->stats.ms_total_device += ms;
+    }
+    c->stats.n_candidates += c->h_ctr->n_cand;
+    c->stats.n_ap_entries += c->h_ctr->n_ap;
+    c->stats.n_records += n;
+    replay(c->filter, c->crc, c->h_rec, n, chunk_offset, out);
+    return 0;
+}
+
+// IQ stream of any length resident on the device.
+int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<adsb_msg> &out)
+{
+    c->stats = adsb_stats{};
+    c->stats.n_samples = n_samples;
+    const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
+    c->stats.n_chunks = n_chunks;
+    if (n_chunks == 0) return ADSB_OK;
+    if (n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+
+    int rc = run_batch(c, d_iq, false, n_samples, (uint32_t)n_chunks, 0, out);
+    if (rc <= 0) return rc;
+    // A device list overflowed (far denser input than the lists were sized for):
+    // go chunk by chunk, where the worst case always fits.  The bitmap bits the
+    // aborted pass set are a harmless superset.  `out` is still empty here.
+    c->stats.retries++;
+    for (uint64_t ch = 0; ch < n_chunks; ch++) {
+        const uint64_t off = ch * kChunkSamples;
+        const uint64_t n = std::min<uint64_t>(kChunkSamples, n_samples - off);
+        rc = run_batch(c, (const uint32_t *)d_iq + off, false, n, 1, ch, out);
+        if (rc > 0) {
+            c->last_error = "device lists overflowed on a single chunk";
+            return ADSB_ERR_HIP;
+        }
+        if (rc < 0) return rc;
+    }
+    return ADSB_OK;
+}
+
+int deliver(adsb_ctx *c, const std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap,
+            size_t *n_out)
+{
+    c->stats.n_messages = msgs.size();
+    const size_t n = std::min(cap, msgs.size());
+    if (n && out) std::memcpy(out, msgs.data(), n * sizeof(adsb_msg));
+    if (n_out) *n_out = msgs.size();
+    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int ensure_stage(adsb_ctx *c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return ADSB_OK;
+    if (c->d_stage) HIP_TRY(c, hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return ADSB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
+{
+    if (!out) return ADSB_ERR_INVALID;
+    *out = nullptr;
+    if (device < 0) return ADSB_ERR_NO_DEVICE;  // no CPU backend by design
+    if (max_chunks == 0) max_chunks = 1;
+    if (max_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return ADSB_ERR_NO_DEVICE;
+
+    adsb_ctx *c = new (std::nothrow) adsb_ctx;
+    if (!c) return ADSB_ERR_NOMEM;
+    c->device = device;
+    c->max_chunks = max_chunks;
+    // lists sized for ~5x the rate pure noise produces (2.3 % of samples become
+    // address/parity entries); denser input falls back to per-chunk passes
+    const uint64_t ap = std::max<uint64_t>(kWorstPerChunk, max_chunks * (uint64_t)kChunkSamples / 8 + 65536);
+    c->ap_cap = (uint32_t)std::min<uint64_t>(ap, 0xFFFFFFF0u);
+    c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
+
+    int rc = ADSB_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(device));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, kBitmapBytes));
+        HIP_TRY(c, hipMalloc((void **)&c->d_ctr, sizeof(Counters)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_rec, (size_t)c->hits_cap * sizeof(TrialRecord)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
+                                 hipHostMallocDefault));
+        for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+        return reset_bitmap(c);
+    };
+    rc = body();
+    if (rc != ADSB_OK) {
+        std::fprintf(stderr, "adsb_create: %s\n", c->last_error.c_str());
+        adsb_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ADSB_OK;
+}
+
+void adsb_destroy(adsb_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_mag) (void)hipFree(c->d_mag);
+    if (c->d_bitmap) (void)hipFree(c->d_bitmap);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->d_hits) (void)hipFree(c->d_hits);
+    if (c->d_ap) (void)hipFree(c->d_ap);
+    if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int adsb_set_stream(adsb_ctx *c, void *hip_stream)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ADSB_OK;
+}
+
+int adsb_set_profiling(adsb_ctx *c, int enabled)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    c->profiling = enabled != 0;
+    return ADSB_OK;
+}
+
+int adsb_icao_flush(adsb_ctx *c)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->filter.flush();
+    return reset_bitmap(c);
+}
+
+int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, size_t *length_out)
+{
+    if (!c || (!iq && n) || !data_out) return ADSB_ERR_INVALID;
+    if (n > kChunkSamples) return ADSB_ERR_TOO_LONG;  // reference: index panic, lib.rs:48
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_stage(c, (size_t)kChunkSamples * 4);
+    if (rc) return rc;
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (int e = launch_to_mag(c->d_stage, (uint32_t)n, c->d_mag, c->stream))
+        return fail(c, (hipError_t)e, "launch_to_mag");
+    HIP_TRY(c, hipMemcpyAsync(data_out, c->d_mag, kMagDataLen * sizeof(uint16_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (length_out) *length_out = n;
+    return ADSB_OK;
+}
+
+int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_msg *out, size_t cap,
+                        size_t *n_out)
+{
+    if (!c || !data || (!out && cap)) return ADSB_ERR_INVALID;
+    if (length > kChunkSamples) return ADSB_ERR_TOO_LONG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->stats = adsb_stats{};
+    c->stats.n_samples = length;
+    c->stats.n_chunks = 1;
+    std::vector<adsb_msg> msgs;
+    if (length) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_mag, data, kMagDataLen * sizeof(uint16_t),
+                                  hipMemcpyHostToDevice, c->stream));
+        int rc = run_batch(c, c->d_mag, true, length, 1, 0, msgs);
+        if (rc > 0) {
+            c->last_error = "device lists overflowed on a single chunk";
+            return ADSB_ERR_HIP;
+        }
+        if (rc < 0) return rc;
+    }
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_demod_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples, adsb_msg *out, size_t cap,
+                         size_t *n_out)
+{
+    if (!c || (!d_iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
+    if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<adsb_msg> msgs;
+    int rc = demod_device(c, d_iq, n_samples, msgs);
+    if (rc) return rc;
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *out, size_t cap,
+                  size_t *n_out)
+{
+    if (!c || (!iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // stage through the device in pieces of at most max_chunks chunks
+    std::vector<adsb_msg> msgs;
+    adsb_stats total{};
+    const size_t piece = c->max_chunks * (size_t)kChunkSamples;
+    int rc = ensure_stage(c, std::min(piece, std::max<size_t>(n_samples, 1)) * 4);
+    if (rc) return rc;
+    for (size_t off = 0; off < n_samples; off += piece) {
+        const size_t n = std::min(piece, n_samples - off);
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq + 2 * off, n * 4, hipMemcpyHostToDevice, c->stream));
+        std::vector<adsb_msg> part;
+        rc = demod_device(c, c->d_stage, n, part);
+        if (rc) return rc;
+        const uint64_t chunk0 = off / kChunkSamples;
+        for (auto &m : part) {
+            m.chunk += chunk0;
+            msgs.push_back(m);
+        }
+        total.n_chunks += c->stats.n_chunks;
+        total.n_candidates += c->stats.n_candidates;
+        total.n_ap_entries += c->stats.n_ap_entries;
+        total.n_records += c->stats.n_records;
+        total.ms_scan += c->stats.ms_scan;
+        total.ms_match += c->stats.ms_match;
+        total.ms_records += c->stats.ms_records;
+        total.ms_total_device += c->stats.ms_total_device;
+        total.retries += c->stats.retries;
+    }
+    total.n_samples = n_samples;
+    c->stats = total;
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_read_test_data(const char *path, int16_t *iq, size_t max_samples, size_t *n_out)
+{
+    if (!path || !iq) return ADSB_ERR_INVALID;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return ADSB_ERR_INVALID;
+    size_t k = 0;
+    unsigned char b[4];
+    while (k < max_samples && std::fread(b, 1, 4, fp) == 4) {
+        // file: [im lo][im hi][re lo][re hi]  (src/utils.rs:29-31) -> memory {re, im}
+        iq[2 * k] = (int16_t)(b[2] | (b[3] << 8));
+        iq[2 * k + 1] = (int16_t)(b[0] | (b[1] << 8));
+        k++;
+    }
+    std::fclose(fp);
+    if (n_out) *n_out = k;
+    return ADSB_OK;
+}
+
+int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, uint64_t *sum_out,
+                             uint64_t *xor_out)
+{
+    if (!c || !sum_out || !xor_out) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the counters block doubles as the 16-byte result area
+    static_assert(sizeof(Counters) >= 16, "digest result fits the counters block");
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+    if (int e = launch_mag_digest(first_bits, count, (unsigned long long *)c->d_ctr, c->stream))
+        return fail(c, (hipError_t)e, "launch_mag_digest");
+    uint64_t res[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(res, c->d_ctr, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *sum_out = res[0];
+    *xor_out = res[1];
+    return ADSB_OK;
+}
+
+static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors TrialRecord");
+
+int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
+                        size_t cap, size_t *n_out)
+{
+    if (!filter_table || (!records && n) || (!out && cap)) return ADSB_ERR_INVALID;
+    static const Crc24 crc;
+    IcaoFilter filter;
+    filter.load(filter_table);
+    std::vector<adsb_msg> msgs;
+    replay(filter, crc, reinterpret_cast<TrialRecord *>(records), n, 0, msgs);
+    filter.store(filter_table);
+    const size_t k = std::min(cap, msgs.size());
+    if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
+    if (n_out) *n_out = msgs.size();
+    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
+{
+    if (!c || !out) return ADSB_ERR_INVALID;
+    *out = c->stats;
+    return ADSB_OK;
+}
+
+const char *adsb_strerror(int status)
+{
+    switch (status) {
+    case ADSB_OK: return "ok";
+    case ADSB_ERR_INVALID: return "invalid argument";
+    case ADSB_ERR_NO_DEVICE: return "no usable HIP device (libadsb_hip has no CPU fallback)";
+    case ADSB_ERR_HIP: return "HIP runtime error";
+    case ADSB_ERR_TOO_LONG: return "more than 131072 samples for a single MagnitudeBuffer";
+    case ADSB_ERR_CAPACITY: return "output array too small";
+    case ADSB_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+const char *adsb_version(void) { return "adsb_hip 0.1 gfx950 scan=v0"; }
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+/*
+ * include/adsb_hip.h -- C ABI of libadsb_hip.so, the MI355X (gfx950) drop-in for the
+ * demod_2400 hot path of rsadsb/dump1090_rs v0.8.1.
+ *
+ * The reference has no FFI or plugin interface of its own: the boundary it offers
+ * is its Rust library API.  Each entry point below replaces one of those items; a
+ * Rust host declares them in an `extern "C"` block and keeps its own
+ * to_mag / demodulate2400 / ModeSMessage wrappers (INTEGRATION.md shows the stub).
+ *
+ *   reference item (file:line)                              replaced by
+ *   ------------------------------------------------------  -------------------------
+ *   utils::to_mag                  src/utils.rs:43-58       adsb_to_mag
+ *   MagnitudeBuffer / push         src/lib.rs:30-51         the (data[131398], length) pair
+ *   demod_2400::demodulate2400     src/demod_2400.rs:115    adsb_demodulate2400
+ *   ModeSMessage / buffer()        src/demod_2400.rs:92-112 adsb_msg (msg, len)
+ *   icao_filter::icao_flush        src/icao_filter.rs:11    adsb_icao_flush
+ *   to_mag + demodulate2400 per buffer, as composed at
+ *     dump1090_rs/src/main.rs:166-167 and
+ *     benches/demod_benchmark.rs:10-11                      adsb_demod_iq / _device
+ *
+ * Conventions: every function returns ADSB_OK (0) or a negative adsb_status and
+ * never throws, aborts or panics across the ABI; the caller owns every host
+ * buffer; all pointers are plain host pointers except where the name says
+ * `device`.  One adsb_ctx per host thread / per GPU: the ICAO address filter
+ * (process-global statics in the reference, src/icao_filter.rs:8-9) lives in the
+ * context, so contexts are independent streams.  There is no CPU fallback:
+ * adsb_create fails with ADSB_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef ADSB_HIP_H
+#define ADSB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/lib.rs:22-26 */
+#define ADSB_MODES_MAG_BUF_SAMPLES 131072u
+#define ADSB_TRAILING_SAMPLES 326u
+#define ADSB_MODES_LONG_MSG_BYTES 14u
+#define ADSB_MODES_SHORT_MSG_BYTES 7u
+/* length of MagnitudeBuffer.data, src/lib.rs:31 */
+#define ADSB_MAG_DATA_LEN (ADSB_TRAILING_SAMPLES + ADSB_MODES_MAG_BUF_SAMPLES)
+
+typedef enum {
+    ADSB_OK = 0,
+    ADSB_ERR_INVALID = -1,   /* null pointer / bad argument */
+    ADSB_ERR_NO_DEVICE = -2, /* no usable HIP device (there is no CPU fallback) */
+    ADSB_ERR_HIP = -3,       /* a HIP runtime call failed; see adsb_last_error */
+    ADSB_ERR_TOO_LONG = -4,  /* more than 131072 samples handed to a one-buffer call:
+                                the reference panics here (src/lib.rs:48) */
+    ADSB_ERR_CAPACITY = -5,  /* `out` too small; *n_out holds the required count and the
+                                first `cap` messages were written */
+    ADSB_ERR_NOMEM = -6
+} adsb_status;
+
+typedef struct adsb_ctx adsb_ctx;
+
+/* Mirrors ModeSMessage (src/demod_2400.rs:92-102) plus provenance.
+ * buffer() == msg[0..len]. */
+typedef struct {
+    uint8_t msg[ADSB_MODES_LONG_MSG_BYTES];
+    uint8_t len;       /* 7 (MsgLen::Short) or 14 (MsgLen::Long) */
+    uint8_t try_phase; /* winning trial phase, 4..8 (demod_2400.rs:158) */
+    int32_t score;     /* src/mode_s/mod.rs score of the winning trial */
+    uint32_t j;        /* preamble index into MagnitudeBuffer.data */
+    uint64_t chunk;    /* index of the 131072-sample buffer inside this call */
+    double signal_level;
+} adsb_msg;
+
+/* Counters of the most recent demod call (diagnostics / bench). */
+typedef struct {
+    uint64_t n_samples;
+    uint64_t n_chunks;
+    uint64_t n_candidates;  /* j that passed preamble + SNR + quiet gates */
+    uint64_t n_ap_entries;  /* address/parity trials deferred to the filter match */
+    uint64_t n_records;     /* trial records replayed on the host */
+    uint64_t n_messages;
+    float ms_scan;          /* scan kernel (IQ -> candidates -> trials), HIP events */
+    float ms_match;         /* address/parity match kernel */
+    float ms_records;       /* record builder kernel */
+    float ms_total_device;  /* first launch -> last kernel end */
+    uint32_t retries;       /* device-list overflow fallbacks taken */
+    uint32_t reserved;
+} adsb_stats;
+
+/* Create a context on HIP device `device` (>= 0), sized to demodulate up to
+ * `max_chunks` 131072-sample buffers per call (host-pointer calls stage through
+ * a device buffer of that size; device-pointer calls only size the lists). */
+int adsb_create(adsb_ctx **out, int device, size_t max_chunks);
+void adsb_destroy(adsb_ctx *ctx);
+
+/* Launch on the caller's HIP stream (e.g. torch's current stream) instead of the
+ * context's own.  Pass NULL to go back to the private stream. */
+int adsb_set_stream(adsb_ctx *ctx, void *hip_stream);
+/* Record HIP events around each kernel so adsb_stats.ms_* are filled (default on). */
+int adsb_set_profiling(adsb_ctx *ctx, int enabled);
+
+/* == icao_filter::icao_flush() (src/icao_filter.rs:11-17) for this context. */
+int adsb_icao_flush(adsb_ctx *ctx);
+
+/* == utils::to_mag (src/utils.rs:43-58).  iq_re_im is the in-memory
+ * Complex<i16> order: first i16 = re, second = im.  data_out must hold
+ * ADSB_MAG_DATA_LEN u16: [0,326) zero, [326,326+n) magnitudes, rest zero.
+ * n > 131072 -> ADSB_ERR_TOO_LONG. */
+int adsb_to_mag(adsb_ctx *ctx, const int16_t *iq_re_im, size_t n, uint16_t *data_out,
+                size_t *length_out);
+
+/* == demod_2400::demodulate2400 (src/demod_2400.rs:115-212) on one
+ * MagnitudeBuffer given as (data[ADSB_MAG_DATA_LEN], length).  Messages come
+ * out in ascending j, exactly the reference's Vec order. */
+int adsb_demodulate2400(adsb_ctx *ctx, const uint16_t *data, size_t length, adsb_msg *out,
+                        size_t cap, size_t *n_out);
+
+/* to_mag + demodulate2400 over consecutive 131072-sample buffers of a host IQ
+ * stream of any length (the last buffer may be short), the filter persisting
+ * from buffer to buffer as in dump1090_rs/src/main.rs:154-167.  Output order:
+ * ascending (chunk, j). */
+int adsb_demod_iq(adsb_ctx *ctx, const int16_t *iq_re_im, size_t n_samples, adsb_msg *out,
+                  size_t cap, size_t *n_out);
+
+/* Same, the IQ already resident in device memory (16-byte aligned). */
+int adsb_demod_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples,
+                         adsb_msg *out, size_t cap, size_t *n_out);
+
+/* src/utils.rs:23-40 read_test_data: file pairs are [im][re] little-endian;
+ * writes in-memory {re, im}.  Returns samples read via *n_out. */
+int adsb_read_test_data(const char *path, int16_t *iq_re_im, size_t max_samples, size_t *n_out);
+
+/* One trial message as the device hands it to the host replay. */
+typedef struct {
+    uint64_t power;   /* sum of the 33 squared magnitudes from j+19 (demod_2400.rs:191-196) */
+    uint32_t chunk;
+    uint32_t j_tp;    /* j | try_phase << 24 */
+    uint8_t msg[ADSB_MODES_LONG_MSG_BYTES];
+    uint16_t pad;
+} adsb_trial;
+
+/* Host only, no device needed: the ordered replay every demod call ends with
+ * (score_modes_message src/mode_s/mod.rs:34-139 + best-of-5 selection
+ * src/demod_2400.rs:149-207 + icao_filter src/icao_filter.rs), exposed so the
+ * sequential logic can be exercised on its own.  `records` is sorted in place by
+ * (chunk, j, try_phase).  `filter_table` is table A of the filter (4096 u32,
+ * src/icao_filter.rs:8), read and updated. */
+int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
+                        size_t cap, size_t *n_out);
+
+/* Device self-test: digest of the magnitude tail (sqrt, *65535+0.5, saturating
+ * cast; src/utils.rs:54-55) over `count` consecutive f32 bit patterns of
+ * X = im^2 + rn(re^2) starting at `first_bits`.  sum = sum of the u16 outputs,
+ * xor = XOR of (out+1)*(2*bits+1).  A test sweeps all X in [0, 2^31] with it. */
+int adsb_selftest_mag_digest(adsb_ctx *ctx, uint32_t first_bits, uint32_t count,
+                             uint64_t *sum_out, uint64_t *xor_out);
+
+int adsb_get_stats(const adsb_ctx *ctx, adsb_stats *out);
+const char *adsb_strerror(int status);
+/* Text of the last HIP failure on this context ("" if none). */
+const char *adsb_last_error(const adsb_ctx *ctx);
+/* Library / kernel generation string, e.g. "adsb_hip 0.1 gfx950". */
+const char *adsb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,141 @@
+"""ctypes binding of oracle/liboracle.so (dump1090_oracle.h).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "liboracle.so"
+MAG_DATA_LEN = 326 + 131072
+
+
+class OrcMsg(C.Structure):
+    _fields_ = [("msg", C.c_uint8 * 14), ("len", C.c_uint8), ("try_phase", C.c_uint8),
+                ("score", C.c_int32), ("j", C.c_uint32), ("chunk", C.c_uint64),
+                ("signal_level", C.c_double)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("preamble_pass", "snr_pass", "quiet_pass", "trials", "frames")]
+
+
+class OrcMagBuf(C.Structure):
+    _fields_ = [("data", C.c_uint16 * MAG_DATA_LEN), ("length", C.c_size_t),
+                ("first_sample_timestamp_12mhz", C.c_size_t)]
+
+
+class OrcFilter(C.Structure):
+    _fields_ = [("a", C.c_uint32 * 4096), ("b", C.c_uint32 * 4096)]
+
+
+def build(force: bool = False) -> Path:
+    src = [HERE / "dump1090_oracle.c", HERE / "dump1090_oracle.h", HERE / "Makefile"]
+    if force or not LIB_PATH.exists() or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in src):
+        subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "liboracle.so"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        L = C.CDLL(str(LIB_PATH))
+        vp, sz = C.c_void_p, C.c_size_t
+        L.orc_icao_flush.argtypes = [vp]
+        L.orc_icao_hash.argtypes = [C.c_uint32]
+        L.orc_icao_hash.restype = C.c_uint32
+        L.orc_icao_filter_add.argtypes = [vp, C.c_uint32]
+        L.orc_icao_filter_test.argtypes = [vp, C.c_uint32]
+        L.orc_icao_filter_test.restype = C.c_int
+        L.orc_crc_table_entry.argtypes = [C.c_uint]
+        L.orc_crc_table_entry.restype = C.c_uint32
+        L.orc_modes_checksum.argtypes = [vp, sz]
+        L.orc_modes_checksum.restype = C.c_uint32
+        L.orc_getbits.argtypes = [vp, sz, sz]
+        L.orc_getbits.restype = sz
+        L.orc_score_modes_message.argtypes = [vp, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int32)]
+        L.orc_score_modes_message.restype = C.c_int
+        L.orc_to_mag.argtypes = [vp, sz, vp]
+        L.orc_to_mag.restype = C.c_int
+        L.orc_mag_sample.argtypes = [C.c_int16, C.c_int16]
+        L.orc_mag_sample.restype = C.c_uint16
+        L.orc_check_preamble.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_check_preamble.restype = C.c_int
+        L.orc_slice_phase.argtypes = [vp, sz, C.c_int, vp]
+        L.orc_slice_phase.restype = None
+        L.orc_demodulate2400.argtypes = [vp, vp, C.c_uint64, vp, sz, vp]
+        L.orc_demodulate2400.restype = sz
+        L.orc_demod_iq.argtypes = [vp, vp, sz, vp, sz, vp]
+        L.orc_demod_iq.restype = sz
+        L.orc_read_test_data.argtypes = [C.c_char_p, vp, sz]
+        L.orc_read_test_data.restype = C.c_long
+        L.orc_mag_x_digest.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.orc_mag_x_digest.restype = C.c_uint64
+        L.orc_all_trials.argtypes = [vp, C.c_uint64, vp, sz]
+        L.orc_all_trials.restype = sz
+        _lib = L
+    return _lib
+
+
+def as_iq(iq) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(iq), dtype=np.int16)
+    return a.reshape(-1, 2)
+
+
+class Oracle:
+    """One stream of the reference algorithm on the CPU (own ICAO filter)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.filter = OrcFilter()
+
+    def icao_flush(self) -> None:
+        self.L.orc_icao_flush(C.byref(self.filter))
+
+    def to_mag(self, iq) -> Tuple[np.ndarray, int]:
+        a = as_iq(iq)
+        mb = OrcMagBuf()
+        if self.L.orc_to_mag(a.ctypes.data, a.shape[0], C.byref(mb)) != 0:
+            raise IndexError("to_mag: more than 131072 samples")
+        return np.ctypeslib.as_array(mb.data).copy(), int(mb.length)
+
+    def demodulate2400(self, data: np.ndarray, length: int, cap: int = 65536):
+        mb = OrcMagBuf()
+        C.memmove(mb.data, np.ascontiguousarray(data, dtype=np.uint16).ctypes.data, MAG_DATA_LEN * 2)
+        mb.length = length
+        out = (OrcMsg * cap)()
+        st = OrcStats()
+        n = self.L.orc_demodulate2400(C.byref(self.filter), C.byref(mb), 0, out, cap, C.byref(st))
+        assert n <= cap
+        return [unpack(m) for m in out[:n]], st
+
+    def demod_iq(self, iq, cap: Optional[int] = None):
+        a = as_iq(iq)
+        cap = cap or max(4096, a.shape[0] // 64)
+        out = (OrcMsg * cap)()
+        st = OrcStats()
+        n = self.L.orc_demod_iq(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap, C.byref(st))
+        assert n <= cap, "oracle output overflowed its buffer"
+        return [unpack(m) for m in out[:n]], st
+
+
+def unpack(m: OrcMsg) -> dict:
+    return {"msg": bytes(m.msg), "len": int(m.len), "try_phase": int(m.try_phase), "score": int(m.score),
+            "j": int(m.j), "chunk": int(m.chunk), "signal_level": float(m.signal_level),
+            "buffer": bytes(m.msg[: m.len])}
+
+
+def read_test_data(path: str) -> np.ndarray:
+    buf = np.zeros((0x20000, 2), dtype=np.int16)
+    n = lib().orc_read_test_data(str(path).encode(), buf.ctypes.data, 0x20000)
+    if n < 0:
+        raise IOError(path)
+    return buf[:n]

@@ -1,0 +1,273 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference's golden vectors.  Needs a real MI355X: run with -m gpu on the GPU box.
+
+Bar: bit-exact -- frames, count, order, (chunk, j, try_phase, score), and
+signal_level as an f64 bit pattern.  The magnitude stage is the only floating-point
+stage and its u16 output is bit-exact too (tolerance 0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dump1090_rs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(hip_lib):
+    from dump1090_rs_amd import Context
+    c = Context(device=0, max_chunks=64)
+    yield c
+    c.close()
+
+
+def assert_same(msgs, want):
+    got = [(m.chunk, m.j, m.try_phase, m.score, m.msglen, m.msg.hex(), m.signal_level) for m in msgs]
+    exp = [(w["chunk"], w["j"], w["try_phase"], w["score"], w["len"], w["msg"].hex(), w["signal_level"])
+           for w in want]
+    assert got == exp
+
+
+# ----------------------------------------------------------------------------- golden
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_reference_fixture_frames_like_upstream_tests(idx, golden, fixture_iq, hip_lib):
+    """Reads like reference tests/test.rs: icao_flush, read_test_data, to_mag,
+    demodulate2400, compare buffer() -- but exact in count and order."""
+    from dump1090_rs_amd import demod_2400, icao_filter, utils
+    from tests.conftest import GOLDEN
+    fx = golden["fixtures"][idx]
+    icao_filter.icao_flush()
+    buf = utils.read_test_data(str(GOLDEN / fx["file"]))
+    assert np.array_equal(buf, fixture_iq[fx["file"]])
+    outbuf = utils.to_mag(buf)
+    data = demod_2400.demodulate2400(outbuf)
+    assert [a.buffer().hex() for a in data] == fx["frames"]
+    assert [a.j for a in data] == fx["j"]
+    assert [a.try_phase for a in data] == fx["try_phase"]
+    assert [a.score for a in data] == fx["score"]
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_to_mag_bit_exact_on_fixtures(idx, golden, fixture_iq, ctx, oracle_mod):
+    fx = golden["fixtures"][idx]
+    mb = ctx.to_mag(fixture_iq[fx["file"]])
+    want, n = oracle_mod.Oracle().to_mag(fixture_iq[fx["file"]])
+    assert mb.length == n == 131072
+    assert mb.data.dtype == np.uint16 and np.array_equal(mb.data, want)
+    assert not mb.data[:326].any()
+
+
+def test_fixture_stage_counters(golden, fixture_iq, ctx):
+    """candidates == quiet-gate passes, records bounded."""
+    for fx in golden["fixtures"]:
+        ctx.icao_flush()
+        msgs = ctx.demod_iq(fixture_iq[fx["file"]])
+        st = ctx.stats()
+        assert st["n_candidates"] == fx["stats"][2]
+        assert len(msgs) == len(fx["frames"]) == st["n_messages"]
+        assert st["n_records"] < 64 and st["retries"] == 0
+
+
+def test_three_fixtures_as_one_stream_filter_persists(golden, fixture_iq, ctx, oracle_mod):
+    files = [fx["file"] for fx in golden["fixtures"]]
+    stream = np.concatenate([fixture_iq[f] for f in files])
+    orc = oracle_mod.Oracle()
+    want, _ = orc.demod_iq(stream)
+    ctx.icao_flush()
+    assert_same(ctx.demod_iq(stream), want)
+    # not flushed: second pass scores against the warmed filter, on both sides
+    want2, _ = orc.demod_iq(stream)
+    assert_same(ctx.demod_iq(stream), want2)
+    assert [w["score"] for w in want] != [w["score"] for w in want2]
+
+
+# ----------------------------------------------------------------------------- magnitude, exhaustive
+def test_magnitude_tail_every_representable_x(ctx, oracle_mod, hip_lib):
+    """Every f32 X in {0} U [1, 2^31] (all values im^2 + rn(re^2) can take, and more)
+    through sqrt / *65535+0.5 / saturating cast: device digest == CPU digest."""
+    L = oracle_mod.lib()
+    lo, hi = 0x3F800000, 0x4F000000  # 1.0f .. 2^31
+    step = 1 << 24
+    for first in [0] + list(range(lo, hi + 1, step)):
+        count = 1 if first == 0 else min(step, hi + 1 - first)
+        s, x = C.c_uint64(), C.c_uint64()
+        assert hip_lib.adsb_selftest_mag_digest(ctx._h, first, count, C.byref(s), C.byref(x)) == 0
+        wx = C.c_uint64()
+        ws = L.orc_mag_x_digest(first, count, C.byref(wx))
+        assert (s.value, x.value) == (ws, wx.value), hex(first)
+
+
+def test_to_mag_random_and_extreme_pairs(ctx, oracle_mod):
+    rng = np.random.default_rng(11)
+    iq = rng.integers(-32768, 32768, (131072, 2)).astype(np.int16)
+    edge = np.array([-32768, -32767, -16384, -1, 0, 1, 255, 256, 16384, 32767], dtype=np.int16)
+    pairs = np.array([(a, b) for a in edge for b in edge], dtype=np.int16)
+    iq[: len(pairs)] = pairs
+    mb = ctx.to_mag(iq)
+    want, _ = oracle_mod.Oracle().to_mag(iq)
+    assert np.array_equal(mb.data, want)
+    assert mb.data.max() == 65535
+
+
+# ----------------------------------------------------------------------------- edge cases
+def test_empty_and_ragged_inputs(ctx, oracle_mod):
+    assert ctx.demod_iq(np.zeros((0, 2), np.int16)) == []
+    mb = ctx.to_mag(np.zeros((0, 2), np.int16))
+    assert mb.length == 0 and not mb.data.any()
+    assert ctx.demodulate2400(mb) == []
+    with pytest.raises(IndexError):
+        ctx.to_mag(np.zeros((131073, 2), np.int16))
+    base = synth.make_iq(2 * 131072 + 5000, n_bursts=24, seed=77)
+    for n in (1, 3, 18, 19, 326, 327, 4095, 4096, 4097, 4098, 100001, 131071, 131072, 131073,
+              131072 + 4099, 2 * 131072 + 4999):
+        iq = base[:n]
+        orc = oracle_mod.Oracle()
+        want, _ = orc.demod_iq(iq)
+        ctx.icao_flush()
+        assert_same(ctx.demod_iq(iq), want)
+
+
+def test_frame_straddling_chunk_edges_matches_reference_semantics(ctx, oracle_mod):
+    """No carry-over between buffers (src/utils.rs:44, lib.rs:36-44): a burst cut by a
+    chunk edge decodes (or not) exactly as on the CPU."""
+    n = 3 * 131072
+    iq = synth.noise_numpy(n, seed=9)
+    bursts = [synth.Burst(5 * (131072 * c + off), 20000, 3, synth.df17_frame(0xA1B2C3, 1000 + k))
+              for k, (c, off) in enumerate([(1, -400), (1, -300), (1, -200), (1, -100), (1, -20), (1, 0),
+                                            (2, -326), (2, -150), (0, 0), (0, 5)])]
+    synth.add_bursts(iq, bursts)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    ctx.icao_flush()
+    assert_same(ctx.demod_iq(iq), want)
+    assert len(want) >= 5
+
+
+def test_demodulate2400_honours_caller_magnitudes(ctx, oracle_mod, fixture_iq, golden):
+    """demodulate2400 takes any MagnitudeBuffer, not only to_mag output: non-zero
+    lead-in samples and a short `length`."""
+    from dump1090_rs_amd import MagnitudeBuffer
+    f = golden["fixtures"][2]["file"]
+    orc = oracle_mod.Oracle()
+    data, n = orc.to_mag(fixture_iq[f])
+    rng = np.random.default_rng(5)
+    data[:326] = rng.integers(0, 4000, 326)
+    for length in (131072, 40000, 34916, 34915, 1):
+        orc.icao_flush()
+        want, _ = orc.demodulate2400(data, length)
+        ctx.icao_flush()
+        got = ctx.demodulate2400(MagnitudeBuffer(data.copy(), length))
+        assert_same(got, want)
+
+
+def test_saturated_and_constant_inputs(ctx, oracle_mod):
+    for val in (0, 1, -32768, 32767):
+        iq = np.full((131072, 2), val, dtype=np.int16)
+        want, _ = oracle_mod.Oracle().demod_iq(iq)
+        ctx.icao_flush()
+        assert_same(ctx.demod_iq(iq), want)
+        assert want == []
+
+
+# ----------------------------------------------------------------------------- synthetic, multi-chunk
+def test_sparse_synthetic_64_chunks(ctx, oracle_mod):
+    n = 64 * 131072
+    iq = synth.make_iq(n, n_bursts=64)
+    want, st = oracle_mod.Oracle().demod_iq(iq)
+    ctx.icao_flush()
+    assert_same(ctx.demod_iq(iq), want)
+    s = ctx.stats()
+    assert s["n_candidates"] == st.quiet_pass and s["n_chunks"] == 64
+    assert len(want) >= 60
+
+
+def test_dense_synthetic_all_message_kinds(ctx, oracle_mod):
+    """~40 bursts per chunk from 7 addresses, every 3rd a DF11: 750/1000/1400/1600/1800
+    transitions and address/parity matches all occur."""
+    n = 16 * 131072
+    iq = synth.make_iq(n, n_bursts=640, n_icao=7, df11_every=3, seed=31337)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    ctx.icao_flush()
+    assert_same(ctx.demod_iq(iq), want)
+    assert {1400, 1600, 1800} <= {w["score"] for w in want}
+    assert ctx.stats()["n_records"] >= len(want)
+
+
+def test_address_parity_hit_from_later_learned_address_is_ordered(ctx, oracle_mod):
+    """A DF4 whose parity matches an address that is only learned LATER in the same call
+    must not score (bitmap is a superset in time; the host replay restores order)."""
+    n = 2 * 131072
+    iq = synth.noise_numpy(n, seed=4242)
+    icao = 0x4840D6
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    ap = (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    df4 = body + ap
+    bursts = [synth.Burst(5 * 20000, 22000, 1, df4),                       # before the address is known
+              synth.Burst(5 * 60000, 22000, 2, synth.df17_frame(icao, 77)),
+              synth.Burst(5 * 90000, 22000, 5, df4),                       # after: scores 1000
+              synth.Burst(5 * (131072 + 5000), 22000, 9, df4)]
+    synth.add_bursts(iq, bursts)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    ctx.icao_flush()
+    got = ctx.demod_iq(iq)
+    assert_same(got, want)
+    hits = [w for w in want if w["buffer"] == df4]
+    assert hits and all(w["chunk"] * 131072 + w["j"] > 60000 for w in hits)
+    assert ctx.stats()["n_records"] > len(want)  # the early DF4 was handed back and rejected
+
+
+def test_device_resident_entry_point_and_determinism(ctx, oracle_mod):
+    import torch
+    n = 32 * 131072
+    t = synth.make_iq_torch(n, n_bursts=100, seed=2024, device="cuda")
+    torch.cuda.synchronize()
+    want, _ = oracle_mod.Oracle().demod_iq(t.cpu().numpy())
+    for _ in range(3):
+        ctx.icao_flush()
+        assert_same(ctx.demod_iq_device(t.data_ptr(), n), want)
+
+
+def test_context_isolation(hip_lib, oracle_mod, fixture_iq, golden):
+    """Two contexts are two independent streams (their own filters)."""
+    from dump1090_rs_amd import Context
+    f = golden["fixtures"][0]["file"]
+    with Context(0, 1) as a, Context(0, 1) as b:
+        a.icao_flush(); b.icao_flush()
+        first = a.demod_iq(fixture_iq[f])
+        again = a.demod_iq(fixture_iq[f])
+        fresh = b.demod_iq(fixture_iq[f])
+        assert [m.score for m in first] == [m.score for m in fresh] == golden["fixtures"][0]["score"]
+        assert [m.score for m in again] != [m.score for m in first]
+
+
+# ----------------------------------------------------------------------------- full size (BASELINE configs 2 and 5)
+@pytest.mark.parametrize("n_bursts", [64, 5000])
+def test_full_256mib_buffer_bit_exact(hip_lib, oracle_mod, n_bursts):
+    """512 chunks = 256 MiB of IQ, device resident; the oracle needs a couple of seconds."""
+    import torch
+    from dump1090_rs_amd import Context
+    n = 512 * 131072
+    t = synth.make_iq_torch(n, n_bursts=n_bursts, device="cuda")
+    torch.cuda.synchronize()
+    host = t.cpu().numpy()
+    want, st = oracle_mod.Oracle().demod_iq(host, cap=1 << 20)
+    with Context(0, 512) as c:
+        c.icao_flush()
+        got = c.demod_iq_device(t.data_ptr(), n, cap=1 << 20)
+        s = c.stats()
+    assert_same(got, want)
+    assert s["n_candidates"] == st.quiet_pass and s["retries"] == 0
+    injected = {b.frame for b in synth.plan_bursts(n, n_bursts)}
+    assert len(injected & {w["buffer"] for w in want}) >= 0.95 * len(injected)
+
+
+def test_list_overflow_falls_back_and_stays_exact(hip_lib, oracle_mod):
+    """A context sized for 1 chunk given far denser input than its lists expect still
+    returns the exact answer (per-chunk fallback)."""
+    from dump1090_rs_amd import Context
+    n = 8 * 131072
+    iq = synth.make_iq(n, n_bursts=300, n_icao=3, seed=99)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    with Context(0, 1) as c:
+        c.icao_flush()
+        assert_same(c.demod_iq(iq), want)
