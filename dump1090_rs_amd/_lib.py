@@ -64,6 +64,14 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m dump1090_rs_amd.build` "
             "(there is no CPU fallback for the demod_2400 path)")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7.
+    # If this library pulled in /opt/rocm's copy first, a later `import torch` would find
+    # "No HIP GPUs".  Loading torch first (when it is installed) makes both share
+    # torch's runtime; without torch (a C/Rust host) the RUNPATH copy is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(LIB_PATH))
     vp, sz = C.c_void_p, C.c_size_t
     L.adsb_create.argtypes = [C.POINTER(vp), C.c_int, sz]

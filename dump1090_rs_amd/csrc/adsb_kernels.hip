@@ -22,11 +22,31 @@ namespace adsb {
 // Scaling by 2^-15 is exact and commutes with every rounding here (no value is
 // subnormal or overflows: X = rn(im^2 + rn(re^2)) is 0 or in [1, 2^31]), so the
 // two divisions fold into the last constant: 65535 * 2^-15 is a 16-bit value.
-// sqrt must be the correctly rounded one (IEEE), as Rust's f32::sqrt is.
+// sqrt must be the correctly rounded one (IEEE), as Rust's f32::sqrt is.  HIP's
+// __fsqrt_rn is the raw v_sqrt_f32 (1 ulp) -- not good enough: it flips the u16
+// result for about one sample in 10^5.  sqrt_rn below is v_sqrt_f32 plus the
+// neighbour test LLVM uses for IEEE sqrtf, without the subnormal scaling and
+// class checks x never needs (x is 0 or in [1, 2^31]): the correctly rounded root is
+// the candidate s, or its lower neighbour if s_dn*s >= x, or its upper one if
+// s_up*s < x (the products stand for the squared midpoints).  For x = 0 both
+// residuals are NaN / 0 and s = 0 stays.  tests/test_gpu_parity.py sweeps every
+// f32 x in the range against the CPU.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __fmaf_rn(-s_dn, s, x);
+    const float r_up = __fmaf_rn(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
+
 __device__ __forceinline__ uint32_t mag_from_x(float x)
 {
-    float m = __fsqrt_rn(x);
+    float m = sqrt_rn(x);
     float o = __fmaf_rn(m, 65535.0f / 32768.0f, 0.5f);
     o = fminf(o, 65535.0f);  // Rust `as u16` saturates; o >= 0.5 always
     return (uint32_t)o;      // truncates

@@ -131,11 +131,12 @@ def test_empty_and_ragged_inputs(ctx, oracle_mod):
 def test_frame_straddling_chunk_edges_matches_reference_semantics(ctx, oracle_mod):
     """No carry-over between buffers (src/utils.rs:44, lib.rs:36-44): a burst cut by a
     chunk edge decodes (or not) exactly as on the CPU."""
-    n = 3 * 131072
+    offsets = [-400, -330, -326, -300, -200, -100, -20, -1, 0, 5, 36, 326]
+    n = (len(offsets) + 1) * 131072
     iq = synth.noise_numpy(n, seed=9)
-    bursts = [synth.Burst(5 * (131072 * c + off), 20000, 3, synth.df17_frame(0xA1B2C3, 1000 + k))
-              for k, (c, off) in enumerate([(1, -400), (1, -300), (1, -200), (1, -100), (1, -20), (1, 0),
-                                            (2, -326), (2, -150), (0, 0), (0, 5)])]
+    # burst k sits at the start of chunk k+1, shifted by offsets[k] samples (one per edge)
+    bursts = [synth.Burst(5 * (131072 * (k + 1) + off) + k % 5, 20000, 3, synth.df17_frame(0xA1B2C3, 1000 + k))
+              for k, off in enumerate(offsets)]
     synth.add_bursts(iq, bursts)
     want, _ = oracle_mod.Oracle().demod_iq(iq)
     ctx.icao_flush()
