@@ -1,0 +1,204 @@
+// adsb_aux.hip -- the small kernels around the scan: to_mag alone, the address/parity
+// match, the record builder and the magnitude self-test digest.
+#include "adsb_dev_common.h"
+
+namespace adsb {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// to_mag alone (adsb_to_mag).  data[0..326) = 0, data[326+k] = mag(iq[k]), rest 0
+// (src/lib.rs:36-50, src/utils.rs:43-58).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_to_mag(const uint32_t *__restrict__ iq, uint32_t n,
+                                                uint16_t *__restrict__ data)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)kMagDataLen) return;
+    uint32_t v = 0;
+    if (i >= (uint32_t)kLead && i - kLead < n) v = mag_of_dword(iq[i - kLead]);
+    data[i] = (uint16_t)v;
+}
+
+// ---------------------------------------------------------------------------
+// match.  An address/parity trial can only score >= 0 if its CRC residual is in
+// the filter when it is scored (mode_s/mod.rs:71,115,130); the bitmap now holds
+// every address the filter can contain at any point of this call (plus 0, which
+// icao_filter_test always accepts, icao_filter.rs:71-80).  Entries from the fast
+// scan carry the syndrome H; the residual is x^51*H or x^107*H (adsb_tables.h).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gf_apply(const uint32_t *tab3, uint32_t h)
+{
+    return tab3[h & 255u] ^ tab3[256 + ((h >> 8) & 255u)] ^ tab3[512 + (h >> 16)];
+}
+
+__global__ __launch_bounds__(256) void k_match(ScanParams p)
+{
+    __shared__ uint32_t stab[6 * 256];  // X51 and X107
+    for (int i = threadIdx.x; i < 6 * 256; i += blockDim.x) stab[i] = p.tables[kTabX51 * 256 + i];
+    __syncthreads();
+    // block b works on AP segment b % kApSegments (the grid is a multiple of kApSegments)
+    const uint32_t seg = blockIdx.x % kApSegments;
+    const uint32_t seg_cap = p.ap_cap / kApSegments;
+    const uint32_t n = min(p.ctr->seg_ap[seg], seg_cap);
+    const uint64_t *ap = p.ap + (uint64_t)seg * seg_cap;
+    const uint32_t stride = (gridDim.x / kApSegments) * blockDim.x;
+    for (uint32_t i = (blockIdx.x / kApSegments) * blockDim.x + threadIdx.x;; i += stride) {
+        // whole waves stay in the loop together so wave_append's ballot is uniform
+        const uint32_t wave_first = i - (threadIdx.x & 63);
+        if (wave_first >= n) break;
+        bool has = false;
+        uint64_t e = 0;
+        if (i < n) {
+            e = ap[i];
+            const uint32_t code = entry_code(e);
+            uint32_t c = entry_value(e);
+            if (code < 5)
+                c = gf_apply(stab, c);
+            else if (code < 10)
+                c = gf_apply(stab + 3 * 256, c);
+            has = (p.bitmap[c >> 5] >> (c & 31)) & 1u;
+        }
+        wave_append(has, e, p.hits, p.hits_cap, &p.ctr->n_hits, &p.ctr->overflow, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// records.  One wave per hit: lanes are message bits.  The 291-sample window behind
+// j is rebuilt from IQ (rare path: a handful of hits per chunk, so magnitudes are not
+// kept in HBM), the 112 bits of the trial phase are sliced (demod_2400.rs:158-182)
+// and the 33-sample power summed (:191-196).
+// ---------------------------------------------------------------------------
+template <bool FROM_MAG>
+struct WindowReader {
+    const void *src;
+    uint64_t chunk;
+    int len;
+    int j;
+    __device__ uint32_t operator[](int off) const
+    {
+        const int d = j + off;  // index into MagnitudeBuffer.data
+        if (FROM_MAG) return ((const uint16_t *)src)[d];
+        const int k = d - kLead;
+        if (k < 0 || k >= len) return 0;
+        return mag_of_dword(((const uint32_t *)src)[chunk * (uint64_t)kChunkSamples + k]);
+    }
+    __device__ WindowReader operator+(int off) const
+    {
+        WindowReader r = *this;
+        r.j += off;
+        return r;
+    }
+};
+
+template <bool FROM_MAG>
+__global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
+{
+    const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < n; i += nwaves) {
+        const uint64_t e = p.hits[i];
+        const uint64_t chunk = entry_chunk(e);
+        const uint32_t j = entry_j(e), tp = entry_tp(e);
+        const int len = FROM_MAG ? (int)p.n_samples : chunk_len(p.n_samples, chunk);
+        const WindowReader<FROM_MAG> win{p.src, chunk, len, (int)j};
+
+        unsigned long long half[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int nbit = lane + 64 * h;
+            bool bit = false;
+            if (nbit < 112) {
+                const int pos = 5 * 19 + (int)tp + 12 * nbit;
+                const int s = pos / 5;
+                bit = slice_value(win + s, pos - 5 * s) > 0;
+            }
+            // lane n holds message bit n; the message is MSB-first
+            half[h] = __brevll(__ballot(bit));
+        }
+        unsigned long long pw = 0;
+        if (lane < 33) {
+            const unsigned long long m = win[19 + lane];
+            pw = m * m;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pw += __shfl_down(pw, off);
+        if (lane == 0) {
+            TrialRecord r;
+            r.power = pw;
+            r.chunk = (uint32_t)chunk;
+            r.j_tp = j | (tp << 24);
+#pragma unroll
+            for (int b = 0; b < 8; b++) r.msg[b] = (uint8_t)(half[0] >> (56 - 8 * b));
+#pragma unroll
+            for (int b = 0; b < 6; b++) r.msg[8 + b] = (uint8_t)(half[1] >> (56 - 8 * b));
+            r.pad = 0;
+            rec[i] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// self-test: digest of the magnitude tail over consecutive f32 bit patterns of
+// X = im^2 + rn(re^2) (an integer-valued float in [0, 2^31]).  Lets a test sweep every
+// representable X against the CPU pipeline, which proves the folded constant and
+// the device sqrt exactly.  out[0] += sum of outputs, out[1] ^= order-free hash.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mag_digest(uint32_t first_bits, uint32_t count,
+                                                    unsigned long long *out)
+{
+    unsigned long long sum = 0, h = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint32_t bits = first_bits + i;
+        const uint32_t u = mag_from_x(__uint_as_float(bits));
+        sum += u;
+        h ^= ((unsigned long long)u + 1ull) * (2ull * bits + 1ull);
+    }
+    atomicAdd(&out[0], sum);
+    atomicXor(&out[1], h);
+}
+
+inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace
+
+int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream)
+{
+    const int blocks = (kMagDataLen + 255) / 256;
+    hipLaunchKernelGGL(k_to_mag, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t *)d_iq, n, d_data);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_match(const ScanParams &p, void *stream)
+{
+    // grid-stride over a count only the device knows; sized for the usual ~2 % of samples
+    uint64_t guess = p.n_samples / 32 + 1;
+    uint32_t blocks = (uint32_t)((guess + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    blocks = (blocks + kApSegments - 1) / kApSegments * kApSegments;
+    hipLaunchKernelGGL(k_match, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream)
+{
+    uint32_t blocks = p.n_chunks / 2 + 8;  // 4 waves each; ~a few hits per chunk
+    if (blocks > 4096) blocks = 4096;
+    if (from_mag)
+        hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+    else
+        hipLaunchKernelGGL(k_records<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream)
+{
+    hipLaunchKernelGGL(k_mag_digest, dim3(1024), dim3(256), 0, (hipStream_t)stream, first_bits, count,
+                       d_out);
+    return hip_ok(hipGetLastError());
+}
+
+}  // namespace adsb

@@ -1,0 +1,227 @@
+// adsb_dev_common.h -- device helpers shared by the gfx950 kernels.
+//
+// What they compute is fixed by the reference (rsadsb/dump1090_rs v0.8.1):
+//   magnitude      src/utils.rs:43-58
+//   preamble+gates src/demod_2400.rs:127-146, 215-321
+//   bit slicing    src/demod_2400.rs:7-84, 158-182
+//   DF / CRC-24    src/mode_s/mod.rs:41-47, src/crc.rs:263-282
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the magnitude pipeline
+// must keep its one rounded multiply and two fused multiply-adds exactly).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "adsb_device.h"
+
+namespace adsb {
+
+// ---------------------------------------------------------------------------
+// magnitude: src/utils.rs:47-55
+//   fi = im/2^15, fq = re/2^15, mag = sqrt(fma(fi,fi,rn(fq*fq))),
+//   out = sat_u16(trunc(fma(mag, 65535, 0.5)))
+// Scaling by 2^-15 is exact and commutes with every rounding here (no value is
+// subnormal or overflows: X = rn(im^2 + rn(re^2)) is 0 or in [1, 2^31]), so the
+// two divisions fold into the last constant: 65535 * 2^-15 is a 16-bit value.
+// sqrt must be the correctly rounded one (IEEE), as Rust's f32::sqrt is.  HIP's
+// __fsqrt_rn is the raw v_sqrt_f32 (1 ulp) -- not good enough: it flips the u16
+// result for about one sample in 10^5.  sqrt_rn below is v_sqrt_f32 plus the
+// neighbour test LLVM uses for IEEE sqrtf, without the subnormal scaling and
+// class checks x never needs (x is 0 or in [1, 2^31]): the correctly rounded root is
+// the candidate s, or its lower neighbour if s_dn*s >= x, or its upper one if
+// s_up*s < x (the products stand for the squared midpoints).  For x = 0 both
+// residuals are NaN / 0 and s = 0 stays.  tests/test_gpu_parity.py sweeps every
+// f32 x in the range against the CPU.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __fmaf_rn(-s_dn, s, x);
+    const float r_up = __fmaf_rn(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t mag_from_x(float x)
+{
+    float m = sqrt_rn(x);
+    float o = __fmaf_rn(m, 65535.0f / 32768.0f, 0.5f);
+    o = fminf(o, 65535.0f);  // Rust `as u16` saturates; o >= 0.5 always
+    return (uint32_t)o;      // truncates
+}
+
+__device__ __forceinline__ uint32_t mag_u16(int re, int im)
+{
+    float fq = (float)re, fi = (float)im;
+    float t = __fmul_rn(fq, fq);       // the separately rounded square (utils.rs:53)
+    float x = __fmaf_rn(fi, fi, t);    // fi.mul_add(fi, fq*fq)
+    return mag_from_x(x);
+}
+
+// one dword = one IQ sample in memory order {re (low half), im (high half)}
+__device__ __forceinline__ uint32_t mag_of_dword(uint32_t w)
+{
+    return mag_u16((int)(int16_t)(w & 0xFFFFu), (int)(int16_t)(w >> 16));
+}
+
+// Four consecutive IQ samples starting at sample k of a chunk of `len` samples ->
+// four magnitudes packed as u16 pairs.  k is a multiple of 4 (16-byte aligned
+// load) and may be negative (lead-in) or run past len (zero tail / short chunk).
+__device__ __forceinline__ uint2 mag4(const uint32_t *__restrict__ iq, int k, int len)
+{
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    if (k >= 0 && k + 3 < len) {
+        const uint4 v = *(const uint4 *)(iq + k);
+        m0 = mag_of_dword(v.x);
+        m1 = mag_of_dword(v.y);
+        m2 = mag_of_dword(v.z);
+        m3 = mag_of_dword(v.w);
+    } else if (k >= 0 && k < len) {  // ragged end of a short last chunk
+        m0 = mag_of_dword(iq[k]);
+        if (k + 1 < len) m1 = mag_of_dword(iq[k + 1]);
+        if (k + 2 < len) m2 = mag_of_dword(iq[k + 2]);
+    }
+    uint2 pk;
+    pk.x = m0 | (m1 << 16);
+    pk.y = m2 | (m3 << 16);
+    return pk;
+}
+
+// ---------------------------------------------------------------------------
+// CRC-24, generator 0xFFF409 (src/crc.rs).  Table entry i = i<<16 through 8
+// MSB-first steps.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t crc_table_entry(uint32_t i)
+{
+    uint32_t c = i << 16;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c = (c & 0x800000u) ? ((c << 1) ^ 0xFFF409u) : (c << 1);
+    return c & 0xFFFFFFu;
+}
+
+// message held MSB-first in 4 words: w[0] bits 31..0 = message bits 0..31, ...
+__device__ __forceinline__ uint32_t msg_byte(const uint32_t w[4], int i)
+{
+    return (w[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
+}
+
+// src/crc.rs:263-282 over nbytes (7 or 14)
+__device__ __forceinline__ uint32_t modes_checksum(const uint32_t w[4], int nbytes,
+                                                   const uint32_t *tab)
+{
+    uint32_t rem = 0;
+    for (int i = 0; i < nbytes - 3; i++)
+        rem = ((rem << 8) ^ tab[msg_byte(w, i) ^ ((rem >> 16) & 0xFFu)]) & 0xFFFFFFu;
+    rem ^= (msg_byte(w, nbytes - 3) << 16) | (msg_byte(w, nbytes - 2) << 8) | msg_byte(w, nbytes - 1);
+    return rem;
+}
+
+// ---------------------------------------------------------------------------
+// preamble + gates: src/demod_2400.rs:127-146, 215-321.  p = &data[j].
+// Returns true when j goes on to be sliced.
+// ---------------------------------------------------------------------------
+template <typename Ptr>
+__device__ __forceinline__ bool preamble_gates(Ptr p)
+{
+    const int p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6],
+              p7 = p[7], p8 = p[8], p9 = p[9], p10 = p[10], p11 = p[11], p12 = p[12],
+              p13 = p[13];
+    if (!(p0 < p1 && p12 > p13)) return false;  // :221
+    int high;
+    unsigned sig, noise;
+    if (p1 > p2 && p2 < p3 && p3 > p4 && p8 < p9 && p9 > p10 && p10 < p11) {         // :227
+        high = (p1 + p3 + p9 + p11 + p12) / 4;
+        sig = p1 + p3 + p9;
+        noise = p5 + p6 + p7;
+    } else if (p1 > p2 && p2 < p3 && p3 > p4 && p8 < p9 && p9 > p10 && p11 < p12) {  // :242
+        high = (p1 + p3 + p9 + p12) / 4;
+        sig = p1 + p3 + p9 + p12;
+        noise = p5 + p6 + p7 + p8;
+    } else if (p1 > p2 && p2 < p3 && p4 > p5 && p8 < p9 && p10 > p11 && p11 < p12) { // :262
+        high = (p1 + p3 + p4 + p9 + p10 + p12) / 4;
+        sig = p1 + p12;
+        noise = p6 + p7;
+    } else if (p1 > p2 && p3 < p4 && p4 > p5 && p9 < p10 && p10 > p11 && p11 < p12) { // :280
+        high = (p1 + p4 + p10 + p12) / 4;
+        sig = p1 + p4 + p10 + p12;
+        noise = p5 + p6 + p7 + p8;
+    } else if (p2 > p3 && p3 < p4 && p4 > p5 && p9 < p10 && p10 > p11 && p11 < p12) { // :300
+        high = (p1 + p2 + p4 + p10 + p12) / 4;
+        sig = p4 + p10 + p12;
+        noise = p6 + p7 + p8;
+    } else {
+        return false;
+    }
+    if (sig * 2 < 3 * noise) return false;  // :129
+    const int p14 = p[14], p15 = p[15], p16 = p[16], p17 = p[17], p18 = p[18];
+    if (p5 >= high || p6 >= high || p7 >= high || p8 >= high || p14 >= high || p15 >= high ||
+        p16 >= high || p17 >= high || p18 >= high)
+        return false;  // :135-146
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// bit slicer: src/demod_2400.rs:72-83 (+ the Phase walk :22-70 in closed form).
+// Bit n of trial phase tp at preamble j sits at 5x-oversampled position
+// 5*(j+19) + tp + 12*n; sample = pos/5, phase = pos%5.  m = &data[j] here.
+// ---------------------------------------------------------------------------
+template <typename Ptr>
+__device__ __forceinline__ int slice_value(Ptr m, int phase)
+{
+    const int m0 = m[0], m1 = m[1], m2 = m[2];
+    switch (phase) {
+    case 0: return 5 * m0 - 3 * m1 - 2 * m2;
+    case 1: return 4 * m0 - m1 - 3 * m2;
+    case 2: return 3 * m0 + m1 - 4 * m2;
+    case 3: return 2 * m0 + 3 * m1 - 5 * m2;
+    default: return m0 + 5 * m1 - 5 * m2 - (int)m[3];
+    }
+}
+
+template <typename Ptr>
+__device__ __forceinline__ void slice_message(Ptr at_j, int tp, uint32_t w[4])
+{
+    w[0] = w[1] = w[2] = w[3] = 0;
+    int pos = 5 * 19 + tp;
+    for (int n = 0; n < 112; n++, pos += 12) {
+        const int s = pos / 5, ph = pos - 5 * s;
+        if (slice_value(at_j + s, ph) > 0) w[n >> 5] |= 0x80000000u >> (n & 31);
+    }
+}
+
+// append `e` to a global list for the lanes with `has`; one atomic per wave.
+// Must be reached by whole waves.
+__device__ __forceinline__ void wave_append(bool has, uint64_t e, uint64_t *list, uint32_t cap,
+                                            uint32_t *count, uint32_t *overflow, uint32_t ovf_bit)
+{
+    const unsigned long long mask = __ballot(has);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (has) {
+        const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (idx < cap)
+            list[idx] = e;
+        else
+            atomicOr(overflow, ovf_bit);
+    }
+}
+
+__device__ __forceinline__ void bitmap_set(uint32_t *bitmap, uint32_t addr)
+{
+    atomicOr(&bitmap[addr >> 5], 1u << (addr & 31));
+}
+
+// samples in `chunk` of a call over n_samples (the last chunk may be short)
+__device__ __forceinline__ int chunk_len(uint64_t n_samples, uint64_t chunk)
+{
+    const uint64_t remaining = n_samples - chunk * (uint64_t)kChunkSamples;
+    return remaining < (uint64_t)kChunkSamples ? (int)remaining : kChunkSamples;
+}
+
+}  // namespace adsb

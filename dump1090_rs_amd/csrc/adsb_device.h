@@ -3,11 +3,14 @@
 // Device pipeline for one call over C chunks (chunk = one MagnitudeBuffer's worth of
 // samples, 131072, reference src/lib.rs:22):
 //
-//   scan    IQ (or u16 magnitudes) -> per-tile magnitudes in LDS -> preamble/SNR/quiet
-//           gates -> 5 trial phases sliced -> DF + CRC-24 residual per trial ->
+//   scan    IQ -> per-tile magnitudes in LDS -> sign planes -> preamble pattern
+//           (bit-parallel) -> SNR/quiet gates -> 5 trial phases per candidate: DF + CRC-24
+//           syndrome straight from the sign planes ->
 //             * self-validating trials (clean DF11 / DF17 / DF18)  -> hit list,
 //               and their address is OR-ed into the 2^24-bit address bitmap
 //             * address/parity trials (DF 0,4,5,16,20,21,24..31)   -> AP list
+//           (tiles too dense for the fast kernel's LDS lists -> deferred-tile list)
+//   dense   deferred tiles through the simple kernel (normally none)
 //   match   AP list x bitmap -> hit list      (bitmap is now complete for the call)
 //   records hit list -> {chunk, j, try_phase, 14 message bytes, 33-sample power}
 //
@@ -25,18 +28,25 @@ constexpr int kLead = 326;             // TRAILING_SAMPLES, src/lib.rs:24
 constexpr int kMagDataLen = kLead + kChunkSamples;
 constexpr int kReach = 290;            // furthest sample a preamble at j touches: j+290
 
-// 64-bit list entry: crc24 | tp_idx<<24 | j<<27 | chunk<<44   (tp_idx = try_phase-4)
-__host__ __device__ inline uint64_t pack_entry(uint32_t crc, uint32_t tp_idx, uint32_t j,
+// 64-bit list entry: value24 | code<<24 | j<<28 | chunk<<45
+//   code 0..4   short message (56 bits), try_phase = 4 + code, value = H (see below)
+//   code 5..9   long message (112 bits), try_phase = 4 + code - 5, value = H
+//   code 10..14 try_phase = 4 + code - 10, value = the CRC residual itself
+// H is the CRC syndrome before its final constant multiplier: residual =
+// x^51 * H (short) or x^107 * H (long) in GF(2)[x]/(0x1FFF409) -- the match kernel
+// applies the multiplier (adsb_tables.h explains the factorisation).
+__host__ __device__ inline uint64_t pack_entry(uint32_t value, uint32_t code, uint32_t j,
                                                uint64_t chunk)
 {
-    return (uint64_t)(crc & 0xFFFFFFu) | ((uint64_t)tp_idx << 24) | ((uint64_t)j << 27) |
-           (chunk << 44);
+    return (uint64_t)(value & 0xFFFFFFu) | ((uint64_t)code << 24) | ((uint64_t)j << 28) |
+           (chunk << 45);
 }
-__host__ __device__ inline uint32_t entry_crc(uint64_t e) { return (uint32_t)e & 0xFFFFFFu; }
-__host__ __device__ inline uint32_t entry_tp(uint64_t e) { return (uint32_t)(e >> 24) & 7u; }
-__host__ __device__ inline uint32_t entry_j(uint64_t e) { return (uint32_t)(e >> 27) & 0x1FFFFu; }
-__host__ __device__ inline uint64_t entry_chunk(uint64_t e) { return e >> 44; }
-constexpr uint64_t kMaxChunks = 1ull << 20;
+__host__ __device__ inline uint32_t entry_value(uint64_t e) { return (uint32_t)e & 0xFFFFFFu; }
+__host__ __device__ inline uint32_t entry_code(uint64_t e) { return (uint32_t)(e >> 24) & 15u; }
+__host__ __device__ inline uint32_t entry_tp(uint64_t e) { return 4u + entry_code(e) % 5u; }
+__host__ __device__ inline uint32_t entry_j(uint64_t e) { return (uint32_t)(e >> 28) & 0x1FFFFu; }
+__host__ __device__ inline uint64_t entry_chunk(uint64_t e) { return e >> 45; }
+constexpr uint64_t kMaxChunks = 1ull << 19;  // per device pass (256 GiB of IQ)
 
 // One trial message handed to the host replay (32 bytes).
 struct TrialRecord {
@@ -48,14 +58,24 @@ struct TrialRecord {
 };
 static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 
+// The AP list is split into kApSegments equal segments, each with its own fill counter,
+// so the per-tile reservations of ~9000 workgroups do not serialise on one word
+// (one hot counter saturates near 90 atomics/us on this chip).  Tile b uses segment
+// b % kApSegments.
+constexpr int kApSegments = 64;
+
 // Device counters block (one per context).
 struct Counters {
     uint32_t n_hits;       // entries in the hit list
-    uint32_t n_ap;         // entries in the AP list
-    uint32_t n_cand;       // candidates (diagnostic)
-    uint32_t overflow;     // bit0: hit list full, bit1: AP list full
-    uint32_t pad[4];
+    uint32_t overflow;     // bit0: hit list full, bit1: an AP segment full, bit2: deferred list full
+    uint32_t n_deferred;   // tiles handed to the dense kernel
+    uint32_t pad;
+    uint32_t seg_ap[kApSegments];    // entries in each AP segment
+    uint32_t seg_cand[kApSegments];  // candidates seen (diagnostic), same striping
 };
+
+// GF(2) tables, 256 u32 each (adsb_tables.h): F0 F1 F2 | X51_0..2 | X107_0..2
+constexpr int kTabF = 0, kTabX51 = 3, kTabX107 = 6, kTabCount = 9;
 
 struct ScanParams {
     const void *src;        // IQ as {re,im} int16 pairs, or u16 magnitudes (from_mag)
@@ -64,16 +84,21 @@ struct ScanParams {
     uint32_t *bitmap;       // 2^24 bits
     uint64_t *hits;
     uint32_t hits_cap;
-    uint64_t *ap;
-    uint32_t ap_cap;
+    uint64_t *ap;           // kApSegments segments of ap_cap / kApSegments entries
+    uint32_t ap_cap;        // a multiple of kApSegments
+    uint32_t *deferred;     // (chunk << 8 | fast-tile index) of tiles the fast kernel gave up on
+    uint32_t deferred_cap;
+    const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
 };
 
-// launches (adsb_kernels.hip); all asynchronous on `stream`
+// launches; all asynchronous on `stream`, return a hipError_t as int
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
-int launch_scan(const ScanParams &p, bool from_mag, void *stream);
-int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream);
+int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
+int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
+int launch_dense(const ScanParams &p, void *stream);
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);
+int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream);
 
 }  // namespace adsb

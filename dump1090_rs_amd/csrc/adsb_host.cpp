@@ -15,6 +15,7 @@
 
 #include "../../include/adsb_hip.h"
 #include "adsb_device.h"
+#include "adsb_tables.h"
 #include "mode_s_host.hpp"
 
 using namespace adsb;
@@ -33,11 +34,13 @@ struct adsb_ctx {
     Counters *d_ctr = nullptr;
     uint64_t *d_hits = nullptr, *d_ap = nullptr;
     TrialRecord *d_rec = nullptr;
-    uint32_t hits_cap = 0, ap_cap = 0;
+    uint32_t *d_deferred = nullptr;
+    uint32_t *d_tables = nullptr;
+    uint32_t hits_cap = 0, ap_cap = 0, deferred_cap = 0;
 
     Counters *h_ctr = nullptr;     // pinned
     TrialRecord *h_rec = nullptr;  // pinned, hits_cap entries
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
     IcaoFilter filter;
     Crc24 crc;
@@ -125,17 +128,23 @@ int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples,
     p.hits_cap = c->hits_cap;
     p.ap = c->d_ap;
     p.ap_cap = c->ap_cap;
+    p.deferred = c->d_deferred;
+    p.deferred_cap = c->deferred_cap;
+    p.tables = c->d_tables;
     p.ctr = c->d_ctr;
 
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
+    if (!from_mag)  // tiles the fast scan deferred (normally none; the kernel then exits at once)
+        if (int e = launch_dense(p, c->stream)) return fail(c, (hipError_t)e, "launch_dense");
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     if (int e = launch_records(p, from_mag, c->d_rec, c->stream))
         return fail(c, (hipError_t)e, "launch_records");
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -152,14 +161,19 @@ int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples,
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         c->stats.ms_scan += ms;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-        c->stats.ms_match += ms;
+        c->stats.ms_dense += ms;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        c->stats.ms_match += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         c->stats.ms_records += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3]));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
         c->stats.ms_total_device += ms;
     }
-    c->stats.n_candidates += c->h_ctr->n_cand;
-    c->stats.n_ap_entries += c->h_ctr->n_ap;
+    for (int sgm = 0; sgm < kApSegments; sgm++) {
+        c->stats.n_candidates += c->h_ctr->seg_cand[sgm];
+        c->stats.n_ap_entries += c->h_ctr->seg_ap[sgm];
+    }
+    c->stats.n_deferred += c->h_ctr->n_deferred;
     c->stats.n_records += n;
     replay(c->filter, c->crc, c->h_rec, n, chunk_offset, out);
     return 0;
@@ -235,9 +249,14 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     c->max_chunks = max_chunks;
     // lists sized for ~5x the rate pure noise produces (2.3 % of samples become
     // address/parity entries); denser input falls back to per-chunk passes
-    const uint64_t ap = std::max<uint64_t>(kWorstPerChunk, max_chunks * (uint64_t)kChunkSamples / 8 + 65536);
-    c->ap_cap = (uint32_t)std::min<uint64_t>(ap, 0xFFFFFFF0u);
+    // Each of the kApSegments AP segments must hold the worst case of the blocks that can
+    // map to it in a single-chunk pass (one half-tile of the dense kernel, every j sliced,
+    // plus one fast tile's staging buffer): 24576 entries.
+    uint64_t ap = std::max<uint64_t>((uint64_t)kApSegments * 24576, max_chunks * (uint64_t)kChunkSamples / 8 + 65536);
+    ap = (ap + kApSegments - 1) / kApSegments * kApSegments;
+    c->ap_cap = (uint32_t)std::min<uint64_t>(ap, 0xFFFFFFC0u);
     c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
+    c->deferred_cap = (uint32_t)std::min<uint64_t>(max_chunks * 32, 1u << 24);
 
     int rc = ADSB_OK;
     auto body = [&]() -> int {
@@ -250,6 +269,13 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_rec, (size_t)c->hits_cap * sizeof(TrialRecord)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_deferred, (size_t)c->deferred_cap * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabCount * 256 * sizeof(uint32_t)));
+        {
+            const std::vector<uint32_t> tab = build_gf_tables();
+            HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
+                                 hipMemcpyHostToDevice));
+        }
         HIP_TRY(c, hipHostMalloc((void **)&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
         HIP_TRY(c, hipHostMalloc((void **)&c->h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
                                  hipHostMallocDefault));
@@ -280,6 +306,8 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_ap) (void)hipFree(c->d_ap);
     if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_deferred) (void)hipFree(c->d_deferred);
+    if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -388,6 +416,8 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
         total.n_ap_entries += c->stats.n_ap_entries;
         total.n_records += c->stats.n_records;
         total.ms_scan += c->stats.ms_scan;
+        total.ms_dense += c->stats.ms_dense;
+        total.n_deferred += c->stats.n_deferred;
         total.ms_match += c->stats.ms_match;
         total.ms_records += c->stats.ms_records;
         total.ms_total_device += c->stats.ms_total_device;
@@ -475,6 +505,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.1 gfx950 scan=v0"; }
+const char *adsb_version(void) { return "adsb_hip 0.2 gfx950 scan=v1-planes"; }
 
 }  // extern "C"

@@ -1,0 +1,448 @@
+// adsb_scan_fast.hip -- the gfx950 scan kernel: IQ in, trial syndromes out, magnitudes
+// never leave the CU.
+//
+// One workgroup (256 threads = 4 wave64) owns a tile of 7712 preamble positions j of
+// one chunk; the 8004 magnitudes those positions can touch (j .. j+290) live in LDS.
+// The reference walks j serially and slices 5 x 112 bits per surviving j with a small
+// state machine (src/demod_2400.rs:121-207).  Here the same decisions are taken densely
+// and bit-parallel:
+//
+//  P1 magnitudes   dwordx4 IQ loads (4 samples / lane, aligned, coalesced) -> exact f32
+//                  magnitude (src/utils.rs:47-55) -> u16 in LDS.
+//  P2 sign planes  every decision the reference can ever take on this tile is the sign of
+//                  a short integer correlation of neighbouring magnitudes:
+//                    slicer phase ph at sample s (demod_2400.rs:72-83)   5 kinds
+//                    m[s] < m[s+1], m[s] > m[s+1] (check_preamble :221-317) 2 kinds
+//                  All seven are taken for every sample.  A lane walks samples 12 apart
+//                  (bit n and bit n+5 of a message are 12 samples apart), four
+//                  neighbouring residues at a time so the first differences are shared,
+//                  and shifts each sign into an accumulator with one v_alignbit -- no
+//                  compare, no cross-lane traffic.  The accumulators are stored as bytes
+//                  of bit planes: plane (kind, s mod 12), bit s div 12.
+//  P3 preamble     check_preamble's five patterns are AND/OR of the LT/GT planes at fixed
+//                  offsets: one lane evaluates 32 positions j per instruction.
+//  P4 gates        the ~4.5 % of positions that match a pattern get the value tests
+//                  (high/SNR/quiet, :129-146) from LDS magnitudes, one lane each.
+//  P5 trials       for the ~1 % that survive, each (j, try_phase) is one lane: the five
+//                  bit classes n mod 5 of the message are five 23-bit fields cut out of the
+//                  sign planes with two dword loads and a funnel shift; DF and the CRC-24
+//                  syndrome come from table lookups on the fields (adsb_tables.h); the
+//                  message bytes are never assembled here.
+//
+// Outputs are staged in LDS and flushed with one atomic per tile.  A tile whose LDS
+// lists would overflow (far denser than any real signal) is handed, untouched, to the
+// simple kernel through the deferred list, so the fast path has fixed capacity and the
+// result stays exact.
+#include "adsb_dev_common.h"
+#include "adsb_scan_geometry.h"
+
+namespace adsb {
+
+namespace {
+
+using namespace fastgeo;
+
+constexpr int kThreads = 256;
+constexpr int kK = (kSlots + 11) / 12;        // 667 plane bits per residue
+constexpr int kKBytes = (kK + 7) / 8;         // 84 bytes of plane per residue
+static_assert(kKBytes % 4 == 0, "planes are whole dwords");
+constexpr int kPlaneDw = kKBytes / 4 + 1;     // 22: one dword of read slack (always zero)
+constexpr int kAllocSlots = 96 * kKBytes + 8; // 8072 magnitudes P2 may read
+constexpr int kPlaneLT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
+constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..107: GT 0..23
+constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
+constexpr int kItems2 = 3 * kKBytes;          // 252 P2 items: (residue group, plane byte)
+constexpr int kItems3 = 12 * (kKBytes / 4);   // 252 P3 items: (residue, plane dword)
+static_assert(kItems2 <= kThreads && kItems3 <= kThreads, "one item per thread");
+constexpr int kPatCap = 1024;                 // positions matching a preamble pattern
+constexpr int kCandCap = 512;                 // positions passing every gate
+constexpr int kApCap = kAllocSlots / 4;       // 2018 staged AP entries (aliases the magnitudes)
+constexpr int kHitCap = 32;
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh)[31:0], sh in 0..31
+}
+
+// shift the sign bit of v into acc from the right
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, int v)
+{
+    return alignbit(acc, (uint32_t)v, 31);
+}
+
+__device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped to 0..32
+{
+    return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
+}
+
+__device__ __forceinline__ uint32_t gf_mulx(uint32_t a)  // * x mod (x^24 + 0xFFF409)
+{
+    return ((a << 1) & 0xFFFFFFu) ^ ((a & 0x800000u) ? 0xFFF409u : 0u);
+}
+
+__device__ __forceinline__ uint32_t tab3(const uint32_t *t, uint32_t f)
+{
+    return t[f & 255u] ^ t[256 + ((f >> 8) & 255u)] ^ t[512 + (f >> 16)];
+}
+
+struct alignas(16) FastLds {
+    union {
+        uint16_t mag[kAllocSlots];     // P1..P4
+        uint64_t ap[kApCap];           // P5 staging (magnitudes are dead by then)
+    };
+    uint32_t plane[kPlanes * kPlaneDw];
+    uint32_t tab[6 * 256];             // F0 F1 F2 X51_0 X51_1 X51_2
+    uint16_t pat[kPatCap];             // slot | branch << 13
+    uint16_t cand[kCandCap];           // slot of p0
+    uint64_t hit[kHitCap];
+    uint32_t npat, ncand, nap, nhit, overflow, ap_base, hit_base;
+};
+
+__global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
+{
+    __shared__ FastLds s;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    const uint32_t chunk = blockIdx.x / kTilesPerChunk;
+    const int tile = (int)(blockIdx.x % kTilesPerChunk);
+    const int len = chunk_len(p.n_samples, chunk);
+    const int jbase = tile * kTile;
+    if (jbase >= len) return;
+    const int jn = min(kTile, len - jbase);
+
+    // ---------------------------------------------------------------- P0 setup
+    for (int i = tid; i < 6 * 256; i += kThreads) s.tab[i] = p.tables[i];
+    if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
+    if (tid == 0) {
+        s.npat = 0;
+        s.ncand = 0;
+        s.nap = 0;
+        s.nhit = 0;
+        s.overflow = 0;
+    }
+
+    // ---------------------------------------------------------------- P1 magnitudes
+    {
+        const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
+        const int k0 = jbase - kPad - kLead;  // IQ sample index of slot 0 (multiple of 4)
+#pragma unroll 2
+        for (int g = tid; g < kAllocSlots / 4; g += kThreads)
+            *(uint2 *)(s.mag + 4 * g) = mag4(iq, k0 + 4 * g, len);
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- P2 sign planes
+    // item = (g, kw): residues 4g..4g+3, plane bits k = 8kw..8kw+7, i.e. samples
+    // 12k + 4g + {0..3} (+3 of look-ahead).  Bit k of plane (kind, r) is the sign taken
+    // at sample 12k + r.  Walking k downwards leaves bit (k & 7) of the byte = k.
+    if (tid < kItems2) {
+        const int g = tid % 3, kw = tid / 3;
+        const uint16_t *base = s.mag + 96 * kw + 4 * g;
+        uint32_t acc[7][4];
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[q][r] = 0;
+#pragma unroll
+        for (int kk = 7; kk >= 0; --kk) {
+            const uint2 lo = *(const uint2 *)(base + 12 * kk);      // m0..m3
+            const uint2 hi = *(const uint2 *)(base + 12 * kk + 4);  // m4..m7
+            int m[7];
+            m[0] = (int)(lo.x & 0xFFFFu);
+            m[1] = (int)(lo.x >> 16);
+            m[2] = (int)(lo.y & 0xFFFFu);
+            m[3] = (int)(lo.y >> 16);
+            m[4] = (int)(hi.x & 0xFFFFu);
+            m[5] = (int)(hi.x >> 16);
+            m[6] = (int)(hi.y & 0xFFFFu);
+            int e[6];  // first differences m[s+1] - m[s]
+#pragma unroll
+            for (int i = 0; i < 6; i++) e[i] = m[i + 1] - m[i];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // slicer value D(ph) at this sample (demod_2400.rs:72-83), negated so that
+                // "D > 0" is the sign bit:  with a = m0-m1 = -e0, b = m1-m2 = -e1, c = m2-m3:
+                //   D0 = 5a+2b  D1 = 4a+3b  D2 = 3a+4b  D3 = 2a+5b  D4 = a+6b+c
+                const int ea = e[r], eb = e[r + 1], ec = e[r + 2];
+                const int n0 = 5 * ea + 2 * eb;
+                const int u = eb - ea;
+                const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
+                const int n4 = ea + 6 * eb + ec;
+                acc[0][r] = push_sign(acc[0][r], n0);
+                acc[1][r] = push_sign(acc[1][r], n1);
+                acc[2][r] = push_sign(acc[2][r], n2);
+                acc[3][r] = push_sign(acc[3][r], n3);
+                acc[4][r] = push_sign(acc[4][r], n4);
+                acc[5][r] = push_sign(acc[5][r], -ea);  // LT: m[s] < m[s+1]
+                acc[6][r] = push_sign(acc[6][r], ea);   // GT: m[s] > m[s+1]
+            }
+        }
+        uint8_t *pb = (uint8_t *)s.plane;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int res = 4 * g + r;
+#pragma unroll
+            for (int q = 0; q < 5; q++) pb[(q * 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[q][r];
+            pb[(kPlaneLT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[5][r];
+            pb[(kPlaneGT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[6][r];
+        }
+    }
+    __syncthreads();
+
+    // LT/GT planes for residues 12..23: the same plane advanced by one bit, so that P3
+    // can address "sample j + o" as plane (j mod 12) + o with no carry logic.
+    for (int it = tid; it < 2 * 12 * (kPlaneDw - 1); it += kThreads) {
+        const int w = it % (kPlaneDw - 1);
+        const int pr = it / (kPlaneDw - 1);  // 0..23: LT 0..11, GT 0..11
+        const int src = (pr < 12 ? kPlaneLT + pr : kPlaneGT + pr - 12) * kPlaneDw + w;
+        s.plane[src + 12 * kPlaneDw] = alignbit(s.plane[src + 1], s.plane[src], 1);
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- P3 preamble patterns
+    // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
+    if (tid < kItems3) {
+        const int res = tid % 12, w = tid / 12;
+        const uint32_t *LT = s.plane + (kPlaneLT + res) * kPlaneDw + w;
+        const uint32_t *GT = s.plane + (kPlaneGT + res) * kPlaneDw + w;
+#define LTO(o) LT[(o) * kPlaneDw]  // p[o] < p[o+1]
+#define GTO(o) GT[(o) * kPlaneDw]  // p[o] > p[o+1]
+        // positions that are real j of this tile: kPad <= slot < kPad + jn
+        const int kmin = (kPad - res + 11) / 12, kmax = (kPad + jn - res + 11) / 12;
+        uint32_t ok = lowmask(kmax - 32 * w) & ~lowmask(kmin - 32 * w);
+        ok &= LTO(0) & GTO(12);                               // demod_2400.rs:221
+        const uint32_t A = GTO(1) & LTO(2);                   // p1>p2 p2<p3
+        const uint32_t C = LTO(8) & GTO(9);                   // p8<p9 p9>p10
+        const uint32_t E = GTO(4) & LTO(9) & GTO(10) & LTO(11);
+        const uint32_t b1 = ok & A & GTO(3) & C & LTO(10);                    // :227
+        const uint32_t b2 = ok & A & GTO(3) & C & LTO(11) & ~b1;              // :242
+        const uint32_t b3 = ok & A & GTO(4) & LTO(8) & GTO(10) & LTO(11) & ~(b1 | b2);  // :262
+        const uint32_t b4 = ok & GTO(1) & LTO(3) & E & ~(b1 | b2 | b3);       // :280
+        const uint32_t b5 = ok & GTO(2) & LTO(3) & E & ~(b1 | b2 | b3 | b4);  // :300
+#undef LTO
+#undef GTO
+        const uint32_t any = b1 | b2 | b3 | b4 | b5;
+        if (any) {
+            uint32_t at = atomicAdd(&s.npat, (uint32_t)__popc(any));
+            const uint32_t bw[5] = {b1, b2, b3, b4, b5};
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+                uint32_t m = bw[b];
+                while (m) {
+                    const int bit = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (at < (uint32_t)kPatCap)
+                        s.pat[at] = (uint16_t)((12 * (32 * w + bit) + res) | (b << 13));
+                    at++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s.npat > (uint32_t)kPatCap) {  // far denser than any real signal: simple kernel
+        if (tid == 0) {
+            const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
+            if (d < p.deferred_cap)
+                p.deferred[d] = (chunk << 8) | (uint32_t)tile;
+            else
+                atomicOr(&p.ctr->overflow, 4u);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- P4 value gates
+    // one lane per pattern match: high / base_signal / base_noise of the branch that
+    // matched first (:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
+    {
+        const int npat = (int)s.npat;
+        for (int base = 0; base < npat; base += kThreads) {
+            const int idx = base + tid;
+            bool pass = false;
+            int slot = 0;
+            if (idx < npat) {
+                const uint32_t ent = s.pat[idx];
+                slot = (int)(ent & 0x1FFFu);
+                const int br = (int)(ent >> 13);
+                // p[0..19] as 10 packed pairs, whatever the parity of slot
+                const uint32_t *q = (const uint32_t *)s.mag + (slot >> 1);
+                const uint32_t sh = (uint32_t)(slot & 1) * 16u;
+                uint32_t x[10];
+                uint32_t d0 = q[0];
+#pragma unroll
+                for (int k = 0; k < 10; k++) {
+                    const uint32_t d1 = q[k + 1];
+                    x[k] = alignbit(d1, d0, sh);
+                    d0 = d1;
+                }
+#define PV(i) ((int)(((i) & 1) ? (x[(i) >> 1] >> 16) : (x[(i) >> 1] & 0xFFFFu)))
+                const int p1 = PV(1), p2 = PV(2), p3 = PV(3), p4 = PV(4), p5 = PV(5), p6 = PV(6),
+                          p7 = PV(7), p8 = PV(8), p9 = PV(9), p10 = PV(10), p11 = PV(11),
+                          p12 = PV(12);
+                const int high = (p1 + p12 + (br <= 2 ? p3 + p9 : 0) + (br == 0 ? p11 : 0) +
+                                  (br >= 2 ? p4 + p10 : 0) + (br == 4 ? p2 : 0)) / 4;
+                const int sig = (br != 4 ? p1 : 0) + (br <= 1 ? p3 + p9 : 0) + (br >= 1 ? p12 : 0) +
+                                (br >= 3 ? p4 + p10 : 0);
+                const int noise = p6 + p7 + ((br == 0 || br == 1 || br == 3) ? p5 : 0) +
+                                  ((br == 1 || br == 3 || br == 4) ? p8 : 0);
+                pass = 2 * sig >= 3 * noise;  // :129
+                const int loud = max(max(max(p5, p6), max(p7, p8)),
+                                     max(max(PV(14), PV(15)), max(max(PV(16), PV(17)), PV(18))));
+                pass = pass && loud < high;   // :135-146
+#undef PV
+            }
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&s.ncand, (uint32_t)__popcll(mask));
+                at = __shfl(at, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pass && at < (uint32_t)kCandCap) s.cand[at] = (uint16_t)slot;
+            }
+        }
+    }
+    __syncthreads();
+    if (s.ncand > (uint32_t)kCandCap) {
+        if (tid == 0) {
+            const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
+            if (d < p.deferred_cap)
+                p.deferred[d] = (chunk << 8) | (uint32_t)tile;
+            else
+                atomicOr(&p.ctr->overflow, 4u);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- P5 trials
+    // lane = (candidate, try_phase).  Message bit n = 5k + r of trial phase tp sits at
+    // 5x-oversampled position 5*(slot+19) + tp + 12n, i.e. sample
+    // slot + 19 + (tp+12r)/5 + 12k with slicer phase (tp+12r) % 5: field r is 23
+    // consecutive bits of one sign plane.
+    {
+        const int ntrial = (int)s.ncand * 5;
+        const uint32_t *tF = s.tab, *tX51 = s.tab + 3 * 256;
+        for (int base = 0; base < ntrial; base += kThreads) {
+            const int t = base + tid;
+            bool is_hit = false, is_ap = false;
+            uint64_t entry = 0;
+            if (t < ntrial) {
+                const int c = t / 5, tpi = t - 5 * c;
+                const int slot = s.cand[c];
+                uint32_t f[5];
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    const int P = 4 + tpi + 12 * r;
+                    const int a = P / 5, ph = P - 5 * a;
+                    const int i0 = slot + 19 + a;
+                    const int q = i0 / 12, res = i0 - 12 * q;
+                    const uint32_t *pl = s.plane + (ph * 12 + res) * kPlaneDw + (q >> 5);
+                    f[r] = alignbit(pl[1], pl[0], (uint32_t)(q & 31));
+                }
+                // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise
+                const uint32_t fl[5] = {f[0] & 0x7FFFFFu, f[1] & 0x7FFFFFu, f[2] & 0x3FFFFFu,
+                                        f[3] & 0x3FFFFFu, f[4] & 0x3FFFFFu};
+                const bool nonzero = (fl[0] | fl[1] | fl[2] | fl[3] | fl[4]) != 0;  // mod.rs:51
+                const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) |
+                                    ((f[3] & 1u) << 1) | (f[4] & 1u);              // mod.rs:41
+                const bool is_long = df >= 16;
+                // 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
+                uint32_t h = tab3(tF, is_long ? fl[0] : (f[0] & 0xFFFu));
+#pragma unroll
+                for (int r = 1; r < 5; r++) h = gf_mulx(h) ^ tab3(tF, is_long ? fl[r] : (f[r] & 0x7FFu));
+
+                const bool df11 = df == 11, df1718 = df == 17 || df == 18;
+                const bool ap_short = df == 0 || df == 4 || df == 5;
+                const bool ap_long = df == 16 || df == 20 || df == 21 || df >= 24;
+                const uint32_t j = (uint32_t)(jbase + slot - kPad);
+                const uint32_t code = (uint32_t)tpi + (is_long ? 5u : 0u);
+                bool learn = false;  // the host replay will add this address to the filter
+                if (nonzero) {
+                    if (df1718) {                       // mod.rs:91-109: clean iff H == 0
+                        is_hit = h == 0;
+                        learn = is_hit && df == 17;     // DF18 adds addr|1<<25: never matched
+                    } else if (df11) {                  // mod.rs:73-90
+                        const uint32_t crc = tab3(tX51, h);
+                        is_hit = (crc & 0xFFFF80u) == 0;
+                        learn = is_hit && (crc & 0x7Fu) == 0;
+                    } else {
+                        is_ap = ap_short || ap_long;    // mod.rs:56-72, 110-135
+                    }
+                }
+                entry = pack_entry(h, code, j, chunk);
+                if (learn) {
+                    uint32_t addr = 0;  // message bits 8..31
+#pragma unroll
+                    for (int n = 8; n < 32; n++) addr |= ((f[n % 5] >> (n / 5)) & 1u) << (31 - n);
+                    bitmap_set(p.bitmap, addr);
+                }
+            }
+            // stage in LDS; one LDS atomic per wave
+            const unsigned long long ma = __ballot(is_ap);
+            if (ma) {
+                const int leader = __ffsll((long long)ma) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&s.nap, (uint32_t)__popcll(ma));
+                at = __shfl(at, leader) + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
+                if (is_ap && at < (uint32_t)kApCap) s.ap[at] = entry;
+            }
+            const unsigned long long mh = __ballot(is_hit);
+            if (mh) {
+                const int leader = __ffsll((long long)mh) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
+                at = __shfl(at, leader) + (uint32_t)__popcll(mh & ((1ull << lane) - 1ull));
+                if (is_hit && at < (uint32_t)kHitCap) s.hit[at] = entry;
+            }
+        }
+    }
+    __syncthreads();
+    if (s.nap > (uint32_t)kApCap || s.nhit > (uint32_t)kHitCap) {
+        // nothing has been written to the global lists yet; bitmap bits already set are
+        // a harmless superset (the dense pass sets them again)
+        if (tid == 0) {
+            const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
+            if (d < p.deferred_cap)
+                p.deferred[d] = (chunk << 8) | (uint32_t)tile;
+            else
+                atomicOr(&p.ctr->overflow, 4u);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- flush
+    const uint32_t nap = s.nap, nhit = s.nhit;
+    const uint32_t seg = blockIdx.x % kApSegments;
+    if (tid == 0) {
+        s.ap_base = nap ? atomicAdd(&p.ctr->seg_ap[seg], nap) : 0u;
+        s.hit_base = nhit ? atomicAdd(&p.ctr->n_hits, nhit) : 0u;
+        if (s.ncand) atomicAdd(&p.ctr->seg_cand[seg], s.ncand);
+    }
+    __syncthreads();
+    const uint32_t seg_cap = p.ap_cap / kApSegments;
+    if (s.ap_base + nap > seg_cap) {
+        if (tid == 0) atomicOr(&p.ctr->overflow, 2u);
+    } else {
+        uint64_t *dst = p.ap + (uint64_t)seg * seg_cap + s.ap_base;
+        for (uint32_t i = tid; i < nap; i += kThreads) dst[i] = s.ap[i];
+    }
+    if (s.hit_base + nhit > p.hits_cap) {
+        if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
+    } else {
+        for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
+    }
+}
+
+inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace
+
+int launch_scan(const ScanParams &p, bool from_mag, void *stream)
+{
+    if (from_mag) return launch_scan_simple(p, true, stream);
+    const uint32_t blocks = p.n_chunks * kTilesPerChunk;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+}  // namespace adsb

@@ -1,0 +1,19 @@
+// adsb_scan_geometry.h -- tile geometry of the fast scan kernel (adsb_scan_fast.hip),
+// shared with the dense fallback, which re-does deferred fast tiles.
+#pragma once
+#include "adsb_device.h"
+
+namespace adsb {
+namespace fastgeo {
+
+// One workgroup = one tile of kTile preamble positions j of one chunk.
+// 17 tiles of 7712 cover the 131072 positions of a chunk (the last one is short).
+constexpr int kTile = 7712;
+constexpr int kTilesPerChunk = (kChunkSamples + kTile - 1) / kTile;  // 17
+constexpr int kPad = 2;   // 326 + 2 = 4 * 82: LDS slot 0 sits on a 16-byte IQ boundary
+constexpr int kSlots = kTile + kPad + kReach;  // 8004 magnitudes a tile touches
+static_assert(kTile % 4 == 0 && (kLead + kPad) % 4 == 0, "aligned dwordx4 IQ loads");
+static_assert(kTilesPerChunk < 256, "deferred entries keep the tile index in 8 bits");
+
+}  // namespace fastgeo
+}  // namespace adsb

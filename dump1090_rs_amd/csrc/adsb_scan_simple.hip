@@ -1,0 +1,176 @@
+// adsb_scan_simple.hip -- the reference-shaped scan kernel.
+//
+// One workgroup = up to 4096 preamble positions j of one chunk: magnitudes into LDS,
+// then every j through the gates (src/demod_2400.rs:121-146) exactly as the reference
+// walks them, then every trial phase sliced bit by bit (:158-182) and scored as far as
+// the device goes (DF class + CRC residual, src/mode_s/mod.rs:41-135).  It is slow
+// (every thread walks 112 bits serially) and has no capacity limits, which is why it
+// serves (a) adsb_demodulate2400, whose input is a caller-supplied MagnitudeBuffer, and
+// (b) tiles the fast kernel defers because they overflow its LDS lists.
+#include "adsb_dev_common.h"
+#include "adsb_scan_geometry.h"
+
+namespace adsb {
+
+namespace {
+
+constexpr int kTile = 4096;
+constexpr int kPad = 2;  // 326 + 2 = 4 * 82: slot 0 sits on a 16-byte IQ boundary
+constexpr int kSlots = kTile + kPad + kReach;  // 4388
+constexpr int kTilesPerChunk = kChunkSamples / kTile;
+static_assert(kSlots % 4 == 0, "slots must be whole 4-sample groups");
+static_assert((kLead + kPad) % 4 == 0, "tile origin must be 16-byte aligned in IQ space");
+
+// fill smag[0..kSlots) with data[jbase - kPad ...] of `chunk` (len = samples in the chunk)
+template <bool FROM_MAG>
+__device__ __forceinline__ void load_tile(const void *src, uint64_t chunk, int jbase, int len,
+                                          uint16_t *smag)
+{
+    const int d0 = jbase - kPad;
+    if (FROM_MAG) {
+        // src = MagnitudeBuffer.data (kMagDataLen u16), used as handed in
+        const uint16_t *data = (const uint16_t *)src;
+        for (int i = threadIdx.x; i < kSlots; i += blockDim.x) {
+            const int d = d0 + i;
+            smag[i] = (d >= 0 && d < kMagDataLen) ? data[d] : (uint16_t)0;
+        }
+    } else {
+        const uint32_t *iq = (const uint32_t *)src + chunk * (uint64_t)kChunkSamples;
+        const int k0 = d0 - kLead;  // IQ sample index of slot 0 (multiple of 4, may be < 0)
+        for (int g = threadIdx.x; g < kSlots / 4; g += blockDim.x)
+            *(uint2 *)(smag + 4 * g) = mag4(iq, k0 + 4 * g, len);
+    }
+}
+
+template <bool FROM_MAG>
+__device__ __forceinline__ void scan_simple_tile(const ScanParams &p, uint32_t chunk, int jbase,
+                                                 int jn, int len, uint16_t *smag, uint32_t *scrc,
+                                                 uint16_t *scand, uint32_t *sncand)
+{
+    scrc[threadIdx.x] = crc_table_entry(threadIdx.x);
+    if (threadIdx.x == 0) *sncand = 0;
+    load_tile<FROM_MAG>(p.src, chunk, jbase, len, smag);
+    __syncthreads();
+
+    // --- preamble / SNR / quiet gates for every j of the tile (demod_2400.rs:121-146)
+    for (int jj = threadIdx.x; jj < jn; jj += blockDim.x) {
+        if (preamble_gates(smag + kPad + jj)) {
+            const uint32_t slot = atomicAdd(sncand, 1u);
+            scand[slot] = (uint16_t)jj;
+        }
+    }
+    __syncthreads();
+    const int ncand = (int)*sncand;
+    const uint32_t seg = blockIdx.x % kApSegments;
+    const uint32_t seg_cap = p.ap_cap / kApSegments;
+    if (threadIdx.x == 0 && ncand) atomicAdd(&p.ctr->seg_cand[seg], (uint32_t)ncand);
+
+    // --- five trial phases per candidate (demod_2400.rs:158-184): slice, DF, CRC
+    const int ntrial = ncand * 5;
+    for (int base = 0; base < ntrial; base += blockDim.x) {
+        const int t = base + threadIdx.x;
+        bool is_hit = false, is_ap = false;
+        uint64_t entry = 0;
+        if (t < ntrial) {
+            const int jj = scand[t / 5];
+            const uint32_t code = 10u + (uint32_t)(t % 5);  // value = residual itself
+            uint32_t w[4];
+            slice_message(smag + kPad + jj, 4 + t % 5, w);
+            const uint32_t df = w[0] >> 27;  // mode_s/mod.rs:41
+            const bool nonzero = (w[0] | w[1] | w[2] | w[3]) != 0;  // :51
+            if (nonzero) {
+                const uint32_t j = (uint32_t)(jbase + jj);
+                const uint32_t addr = w[0] & 0xFFFFFFu;  // message bits 9..32
+                if (df == 11) {  // :73-90
+                    const uint32_t c = modes_checksum(w, 7, scrc);
+                    if ((c & 0xFFFF80u) == 0) {
+                        is_hit = true;
+                        entry = pack_entry(c, code, j, chunk);
+                        if ((c & 0x7Fu) == 0) bitmap_set(p.bitmap, addr);  // the replay adds it
+                    }
+                } else if (df == 17 || df == 18) {  // :91-109
+                    const uint32_t c = modes_checksum(w, 14, scrc);
+                    if (c == 0) {
+                        is_hit = true;
+                        entry = pack_entry(c, code, j, chunk);
+                        // DF18 adds addr | 1<<25, which no 24-bit test can match
+                        if (df == 17) bitmap_set(p.bitmap, addr);
+                    }
+                } else if (df == 0 || df == 4 || df == 5) {  // :56-72
+                    is_ap = true;
+                    entry = pack_entry(modes_checksum(w, 7, scrc), code, j, chunk);
+                } else if (df == 16 || df == 20 || df == 21 || df >= 24) {  // :110-135
+                    is_ap = true;
+                    entry = pack_entry(modes_checksum(w, 14, scrc), code, j, chunk);
+                }
+            }
+        }
+        wave_append(is_hit, entry, p.hits, p.hits_cap, &p.ctr->n_hits, &p.ctr->overflow, 1u);
+        wave_append(is_ap, entry, p.ap + (uint64_t)seg * seg_cap, seg_cap, &p.ctr->seg_ap[seg],
+                    &p.ctr->overflow, 2u);
+    }
+}
+
+// regular grid: block -> (chunk, 4096-tile)
+template <bool FROM_MAG>
+__global__ __launch_bounds__(256) void k_scan_simple(ScanParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t smag[kSlots];
+    __shared__ uint32_t scrc[256];
+    __shared__ uint16_t scand[kTile];
+    __shared__ uint32_t sncand;
+
+    const uint32_t chunk = blockIdx.x / kTilesPerChunk;
+    const int jbase = (int)(blockIdx.x % kTilesPerChunk) * kTile;
+    const int len = FROM_MAG ? (int)p.n_samples : chunk_len(p.n_samples, chunk);
+    if (jbase >= len) return;
+    scan_simple_tile<FROM_MAG>(p, chunk, jbase, min(kTile, len - jbase), len, smag, scrc, scand,
+                               &sncand);
+}
+
+// deferred tiles of the fast kernel: two blocks per deferred tile (half a fast tile each)
+__global__ __launch_bounds__(256) void k_scan_dense(ScanParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t smag[kSlots];
+    __shared__ uint32_t scrc[256];
+    __shared__ uint16_t scand[kTile];
+    __shared__ uint32_t sncand;
+    static_assert(fastgeo::kTile % 8 == 0 && fastgeo::kTile / 2 <= kTile, "half a fast tile per block");
+
+    const uint32_t n = min(p.ctr->n_deferred, p.deferred_cap);
+    for (uint32_t item = blockIdx.x; item < 2 * n; item += gridDim.x) {
+        const uint32_t e = p.deferred[item >> 1];
+        const uint32_t chunk = e >> 8;
+        const int len = chunk_len(p.n_samples, chunk);
+        const int jbase = (int)(e & 0xFFu) * fastgeo::kTile + (int)(item & 1u) * (fastgeo::kTile / 2);
+        const int jend = min(len, (int)(e & 0xFFu) * fastgeo::kTile + (int)((item & 1u) + 1) * (fastgeo::kTile / 2));
+        if (jbase < jend)
+            scan_simple_tile<false>(p, chunk, jbase, jend - jbase, len, smag, scrc, scand, &sncand);
+        __syncthreads();
+    }
+}
+
+inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace
+
+int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream)
+{
+    const uint32_t blocks = p.n_chunks * kTilesPerChunk;
+    if (blocks == 0) return 0;
+    if (from_mag)
+        hipLaunchKernelGGL(k_scan_simple<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_scan_simple<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_dense(const ScanParams &p, void *stream)
+{
+    // the deferred count lives on the device; a small fixed grid strides over it and
+    // exits at once when it is zero (the normal case)
+    hipLaunchKernelGGL(k_scan_dense, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+}  // namespace adsb

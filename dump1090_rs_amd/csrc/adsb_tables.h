@@ -1,0 +1,74 @@
+// adsb_tables.h -- GF(2) lookup tables for the Mode-S CRC-24 as the scan kernel computes it.
+//
+// The reference computes  residual = crc24(first n-3 bytes) XOR last 3 bytes
+// (src/crc.rs:263-282), which is M(x) mod g(x) for the whole `bits`-bit message
+// M(x) = sum_n bit_n * x^(bits-1-n), g(x) = x^24 + 0xFFF409.
+//
+// The scan kernel never assembles the message: it pulls, for each of the five bit
+// classes r = n mod 5, one field f_r whose bit k is message bit n = 5k + r (those bits
+// are 12 samples apart, which is how the sign planes are laid out).  With
+// y = x^-5 mod g:
+//     M(x) = sum_r x^(bits-1-r) * F(f_r),      F(f) = sum_k f[k] * y^k
+//          = x^(bits-5) * H,                   H = sum_r x^(4-r) * F(f_r)   (Horner in x)
+// F is three 256-entry table lookups (one per byte of the field); the constant
+// multipliers x^51 (bits = 56) and x^107 (bits = 112) are three lookups each and are
+// only applied where the residual's value matters (DF11 in the scan kernel, address/
+// parity trials in the match kernel).  A clean DF17/18 is simply H == 0.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace adsb {
+
+constexpr uint32_t kCrcPoly = 0xFFF409u;  // src/crc.rs: g(x) minus the x^24 term
+
+// multiply by x in GF(2)[x]/g
+inline uint32_t gf_mulx(uint32_t a)
+{
+    const uint32_t hi = a & 0x800000u;
+    a = (a << 1) & 0xFFFFFFu;
+    return hi ? a ^ kCrcPoly : a;
+}
+// multiply by x^-1 (g has constant term 1, so x is invertible)
+inline uint32_t gf_divx(uint32_t a)
+{
+    return (a & 1u) ? ((a ^ kCrcPoly) >> 1) | 0x800000u : a >> 1;
+}
+
+// tables[t][v]: t = kTabF+b: sum of y^(8b+i) over set bits i of v
+//               t = kTabX51+b / kTabX107+b: (v << 8b) * x^51 / x^107
+inline std::vector<uint32_t> build_gf_tables()
+{
+    std::vector<uint32_t> t(9 * 256, 0);
+    // powers of y = x^-5
+    uint32_t ypow[24];
+    uint32_t p = 1;
+    for (int k = 0; k < 24; k++) {
+        ypow[k] = p;
+        for (int s = 0; s < 5; s++) p = gf_divx(p);
+    }
+    // x^51 * x^i and x^107 * x^i for i = 0..23
+    uint32_t x51[24], x107[24];
+    p = 1;
+    for (int e = 0; e < 51; e++) p = gf_mulx(p);
+    for (int i = 0; i < 24; i++, p = gf_mulx(p)) x51[i] = p;
+    p = 1;
+    for (int e = 0; e < 107; e++) p = gf_mulx(p);
+    for (int i = 0; i < 24; i++, p = gf_mulx(p)) x107[i] = p;
+    for (int b = 0; b < 3; b++)
+        for (uint32_t v = 0; v < 256; v++) {
+            uint32_t f = 0, a = 0, c = 0;
+            for (int i = 0; i < 8; i++)
+                if (v & (1u << i)) {
+                    f ^= ypow[8 * b + i];
+                    a ^= x51[8 * b + i];
+                    c ^= x107[8 * b + i];
+                }
+            t[(0 + b) * 256 + v] = f;
+            t[(3 + b) * 256 + v] = a;
+            t[(6 + b) * 256 + v] = c;
+        }
+    return t;
+}
+
+}  // namespace adsb

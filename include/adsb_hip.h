@@ -79,10 +79,12 @@ typedef struct {
     uint64_t n_records;     /* trial records replayed on the host */
     uint64_t n_messages;
     float ms_scan;          /* scan kernel (IQ -> candidates -> trials), HIP events */
+    float ms_dense;         /* dense-tile fallback kernel (normally finds nothing to do) */
     float ms_match;         /* address/parity match kernel */
     float ms_records;       /* record builder kernel */
     float ms_total_device;  /* first launch -> last kernel end */
     uint32_t retries;       /* device-list overflow fallbacks taken */
+    uint32_t n_deferred;    /* tiles the fast scan handed to the dense fallback */
     uint32_t reserved;
 } adsb_stats;
 
