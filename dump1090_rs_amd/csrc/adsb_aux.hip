@@ -150,11 +150,19 @@ __global__ __launch_bounds__(256) void k_mag_digest(uint32_t first_bits, uint32_
                                                     unsigned long long *out)
 {
     unsigned long long sum = 0, h = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const uint32_t bits = first_bits + i;
-        const uint32_t u = mag_from_x(__uint_as_float(bits));
-        sum += u;
-        h ^= ((unsigned long long)u + 1ull) * (2ull * bits + 1ull);
+    // pairs (i, i + half) so that both lanes of the packed pipeline are exercised
+    const uint32_t half = (count + 1) / 2;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < half; i += gridDim.x * blockDim.x) {
+        const uint32_t b0 = first_bits + i, b1 = first_bits + i + half;
+        const f32x2 x = {__uint_as_float(b0), __uint_as_float(i + half < count ? b1 : 0u)};
+        const uint32_t pk = mag_tail2(x);
+        const uint32_t u0 = pk & 0xFFFFu, u1 = pk >> 16;
+        sum += u0;
+        h ^= ((unsigned long long)u0 + 1ull) * (2ull * b0 + 1ull);
+        if (i + half < count) {
+            sum += u1;
+            h ^= ((unsigned long long)u1 + 1ull) * (2ull * b1 + 1ull);
+        }
     }
     atomicAdd(&out[0], sum);
     atomicXor(&out[1], h);

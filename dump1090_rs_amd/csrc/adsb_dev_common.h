@@ -22,71 +22,84 @@ namespace adsb {
 // Scaling by 2^-15 is exact and commutes with every rounding here (no value is
 // subnormal or overflows: X = rn(im^2 + rn(re^2)) is 0 or in [1, 2^31]), so the
 // two divisions fold into the last constant: 65535 * 2^-15 is a 16-bit value.
+//
 // sqrt must be the correctly rounded one (IEEE), as Rust's f32::sqrt is.  HIP's
 // __fsqrt_rn is the raw v_sqrt_f32 (1 ulp) -- not good enough: it flips the u16
-// result for about one sample in 10^5.  sqrt_rn below is v_sqrt_f32 plus the
-// neighbour test LLVM uses for IEEE sqrtf, without the subnormal scaling and
-// class checks x never needs (x is 0 or in [1, 2^31]): the correctly rounded root is
-// the candidate s, or its lower neighbour if s_dn*s >= x, or its upper one if
-// s_up*s < x (the products stand for the squared midpoints).  For x = 0 both
-// residuals are NaN / 0 and s = 0 stays.  tests/test_gpu_parity.py sweeps every
-// f32 x in the range against the CPU.
+// result for about one sample in 10^5.  The fix-up is the neighbour test LLVM uses
+// for IEEE sqrtf, without the subnormal scaling and class checks x never needs: with
+// s = v_sqrt_f32(x), the correctly rounded root is s, or its lower neighbour s_dn if
+// s_dn*s >= x, or its upper neighbour s_up if s_up*s < x (the products stand for the
+// squared midpoints).  Both tests are sign bits of a fused s_n*s - x, so the result's
+// bit pattern is  bits(s) - 1 + sign(s_dn*s - x) + sign(s_up*s - x)  with no compare
+// or select.  For x = 0: s = 0, s_dn is a NaN with the sign bit set (+1) and
+// s_up*s - x = +0 (+0), so bits(s) stays 0.
+//
+// Everything is done on pairs so the multiplies and fused multiply-adds are
+// v_pk_mul_f32 / v_pk_fma_f32 (two samples per instruction) and the saturating cast +
+// pack is one v_cvt_pk_u16_u32.  tests/test_gpu_parity.py sweeps every f32 x in
+// {0} U [1, 2^31] through mag_tail2 against the CPU.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float sqrt_rn(float x)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
 {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
-    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    const float r_dn = __fmaf_rn(-s_dn, s, x);
-    const float r_up = __fmaf_rn(-s_up, s, x);
-    float r = (r_dn <= 0.0f) ? s_dn : s;
-    r = (r_up > 0.0f) ? s_up : r;
-    return r;
+    return __builtin_elementwise_fma(a, b, c);
 }
 
-__device__ __forceinline__ uint32_t mag_from_x(float x)
+// two X = im^2 + rn(re^2) -> two magnitudes packed as u16 (low half = first)
+__device__ __forceinline__ uint32_t mag_tail2(f32x2 x)
 {
-    float m = sqrt_rn(x);
-    float o = __fmaf_rn(m, 65535.0f / 32768.0f, 0.5f);
-    o = fminf(o, 65535.0f);  // Rust `as u16` saturates; o >= 0.5 always
-    return (uint32_t)o;      // truncates
+    const f32x2 s = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const u32x2 sb = __builtin_bit_cast(u32x2, s);
+    const u32x2 dnb = sb - 1u, upb = sb + 1u;
+    const f32x2 qdn = pk_fma(__builtin_bit_cast(f32x2, dnb), s, -x);  // >= 0: root is s_dn
+    const f32x2 qup = pk_fma(__builtin_bit_cast(f32x2, upb), s, -x);  // <  0: root is s_up
+    const u32x2 rb = dnb + (__builtin_bit_cast(u32x2, qup) >> 31) + (__builtin_bit_cast(u32x2, qdn) >> 31);
+    const f32x2 c = {65535.0f / 32768.0f, 65535.0f / 32768.0f}, half = {0.5f, 0.5f};
+    const f32x2 o = pk_fma(__builtin_bit_cast(f32x2, rb), c, half);
+    // o >= 0.5; the u32 conversion truncates, the pack saturates at 65535 (Rust `as u16`)
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16((uint32_t)o.x, (uint32_t)o.y));
 }
 
-__device__ __forceinline__ uint32_t mag_u16(int re, int im)
+// two IQ dwords {re (low half), im (high half)} -> two magnitudes packed as u16
+__device__ __forceinline__ uint32_t mag2(uint32_t w0, uint32_t w1)
 {
-    float fq = (float)re, fi = (float)im;
-    float t = __fmul_rn(fq, fq);       // the separately rounded square (utils.rs:53)
-    float x = __fmaf_rn(fi, fi, t);    // fi.mul_add(fi, fq*fq)
-    return mag_from_x(x);
+    const f32x2 fq = {(float)(int16_t)(w0 & 0xFFFFu), (float)(int16_t)(w1 & 0xFFFFu)};
+    const f32x2 fi = {(float)((int32_t)w0 >> 16), (float)((int32_t)w1 >> 16)};
+    const f32x2 t = fq * fq;               // the separately rounded square (utils.rs:53)
+    return mag_tail2(pk_fma(fi, fi, t));   // fi.mul_add(fi, fq*fq)
 }
 
-// one dword = one IQ sample in memory order {re (low half), im (high half)}
-__device__ __forceinline__ uint32_t mag_of_dword(uint32_t w)
-{
-    return mag_u16((int)(int16_t)(w & 0xFFFFu), (int)(int16_t)(w >> 16));
-}
+__device__ __forceinline__ uint32_t mag_of_dword(uint32_t w) { return mag2(w, 0u) & 0xFFFFu; }
 
 // Four consecutive IQ samples starting at sample k of a chunk of `len` samples ->
 // four magnitudes packed as u16 pairs.  k is a multiple of 4 (16-byte aligned
 // load) and may be negative (lead-in) or run past len (zero tail / short chunk).
+__device__ __forceinline__ uint4 load_iq4(const uint32_t *__restrict__ iq, int k, int len)
+{
+    uint4 v = {0u, 0u, 0u, 0u};  // mag(0,0) = 0, so zero IQ stands for "no sample"
+    if (k >= 0 && k + 3 < len) {
+        v = *(const uint4 *)(iq + k);
+    } else if (k >= 0 && k < len) {  // ragged end of a short last chunk
+        v.x = iq[k];
+        if (k + 1 < len) v.y = iq[k + 1];
+        if (k + 2 < len) v.z = iq[k + 2];
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint2 mag4_of(uint4 v)
+{
+    uint2 pk;
+    pk.x = mag2(v.x, v.y);
+    pk.y = mag2(v.z, v.w);
+    return pk;
+}
+
 __device__ __forceinline__ uint2 mag4(const uint32_t *__restrict__ iq, int k, int len)
 {
-    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-    if (k >= 0 && k + 3 < len) {
-        const uint4 v = *(const uint4 *)(iq + k);
-        m0 = mag_of_dword(v.x);
-        m1 = mag_of_dword(v.y);
-        m2 = mag_of_dword(v.z);
-        m3 = mag_of_dword(v.w);
-    } else if (k >= 0 && k < len) {  // ragged end of a short last chunk
-        m0 = mag_of_dword(iq[k]);
-        if (k + 1 < len) m1 = mag_of_dword(iq[k + 1]);
-        if (k + 2 < len) m2 = mag_of_dword(iq[k + 2]);
-    }
-    uint2 pk;
-    pk.x = m0 | (m1 << 16);
-    pk.y = m2 | (m3 << 16);
-    return pk;
+    return mag4_of(load_iq4(iq, k, len));
 }
 
 // ---------------------------------------------------------------------------

@@ -90,6 +90,8 @@ struct ScanParams {
     uint32_t deferred_cap;
     const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
+    int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
+    unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
 };
 
 // launches; all asynchronous on `stream`, return a hipError_t as int

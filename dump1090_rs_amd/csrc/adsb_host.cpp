@@ -25,6 +25,8 @@ struct adsb_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool profiling = true;
+    int debug_stop = 0;  // ADSB_DEBUG_STOP: profiling aid, breaks results when non-zero
+    unsigned long long *d_timeline = nullptr;  // ADSB_TIMELINE=1: 8 blocks x 8 tiles x 8 stamps
     size_t max_chunks = 0;
 
     void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
@@ -132,6 +134,8 @@ int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples,
     p.deferred_cap = c->deferred_cap;
     p.tables = c->d_tables;
     p.ctr = c->d_ctr;
+    p.debug_stop = c->debug_stop;
+    p.timeline = c->d_timeline;
 
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
@@ -247,6 +251,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     if (!c) return ADSB_ERR_NOMEM;
     c->device = device;
     c->max_chunks = max_chunks;
+    if (const char *ds = std::getenv("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     // lists sized for ~5x the rate pure noise produces (2.3 % of samples become
     // address/parity entries); denser input falls back to per-chunk passes
     // Each of the kApSegments AP segments must hold the worst case of the blocks that can
@@ -280,6 +285,10 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipHostMalloc((void **)&c->h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
                                  hipHostMallocDefault));
         for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+        if (std::getenv("ADSB_TIMELINE")) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_timeline, 512 * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemset(c->d_timeline, 0, 512 * sizeof(unsigned long long)));
+        }
         return reset_bitmap(c);
     };
     rc = body();
@@ -308,6 +317,21 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_deferred) (void)hipFree(c->d_deferred);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_timeline) {
+        // profiling aid: dump the stamps of the last scan on the way out
+        unsigned long long tl[512];
+        if (hipMemcpy(tl, c->d_timeline, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int b = 0; b < 8; b++)
+                for (int it = 0; it < 8; it++) {
+                    const unsigned long long *r = tl + (b * 8 + it) * 8;
+                    if (!r[0]) continue;
+                    std::fprintf(stderr, "timeline block %d tile %d: start %8lld |", b * 128, it,
+                                 (long long)(r[0] - tl[0]));
+                    for (int k = 1; k < 7; k++) std::fprintf(stderr, " %6lld", (long long)(r[k] - r[k - 1]));
+                    std::fprintf(stderr, "  total %lld\n", (long long)(r[6] - r[0]));
+                }
+        (void)hipFree(c->d_timeline);
+    }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -33,6 +33,9 @@
 // lists would overflow (far denser than any real signal) is handed, untouched, to the
 // simple kernel through the deferred list, so the fast path has fixed capacity and the
 // result stays exact.
+#include <cstdio>
+#include <cstdlib>
+
 #include "adsb_dev_common.h"
 #include "adsb_scan_geometry.h"
 
@@ -58,6 +61,14 @@ constexpr int kPatCap = 1024;                 // positions matching a preamble p
 constexpr int kCandCap = 512;                 // positions passing every gate
 constexpr int kApCap = kAllocSlots / 4;       // 2018 staged AP entries (aliases the magnitudes)
 constexpr int kHitCap = 32;
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for the next tile's IQ prefetch at every phase boundary; here only LDS
+// traffic (lgkmcnt) is drained before s_barrier, global loads stay in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
 {
@@ -85,6 +96,15 @@ __device__ __forceinline__ uint32_t tab3(const uint32_t *t, uint32_t f)
     return t[f & 255u] ^ t[256 + ((f >> 8) & 255u)] ^ t[512 + (f >> 16)];
 }
 
+__device__ __forceinline__ void defer_tile(const ScanParams &p, uint32_t chunk, int tile)
+{
+    const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
+    if (d < p.deferred_cap)
+        p.deferred[d] = (chunk << 8) | (uint32_t)tile;
+    else
+        atomicOr(&p.ctr->overflow, 4u);
+}
+
 struct alignas(16) FastLds {
     union {
         uint16_t mag[kAllocSlots];     // P1..P4
@@ -98,39 +118,98 @@ struct alignas(16) FastLds {
     uint32_t npat, ncand, nap, nhit, overflow, ap_base, hit_base;
 };
 
+// IQ of one tile, as each thread holds it between the load and the magnitude pass:
+// 8 aligned dwordx4 = 32 samples per thread, 8072 per workgroup.
+constexpr int kLoadsPerThread = (kAllocSlots / 4 + kThreads - 1) / kThreads;  // 8
+
+struct TileRef {
+    uint32_t chunk;
+    int tile, len, jbase;
+};
+
+__device__ __forceinline__ TileRef tile_ref(const ScanParams &p, uint32_t t)
+{
+    TileRef r;
+    r.chunk = t / kTilesPerChunk;
+    r.tile = (int)(t % kTilesPerChunk);
+    r.len = chunk_len(p.n_samples, r.chunk);
+    r.jbase = r.tile * kTile;
+    return r;
+}
+
+// The tile's IQ through a buffer resource that spans exactly this chunk's samples: the
+// hardware range check returns zero for every dword outside [0, len) -- the 326-sample
+// lead-in before the chunk (negative offsets wrap to huge unsigned ones), the zero tail
+// and the ragged end of a short last chunk -- so the eight dwordx4 loads are issued
+// back to back with no branch and no wait between them.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef &r, int tid,
+                                             uint4 (&pre)[kLoadsPerThread])
+{
+    const uint32_t *iq = (const uint32_t *)p.src + r.chunk * (uint64_t)kChunkSamples;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)iq, 0, r.len * 4, 0x00020000);
+    const int k0 = r.jbase - kPad - kLead;  // IQ sample index of slot 0 (multiple of 4)
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; i++) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k0 + 4 * (tid + i * kThreads)) * 4, 0, 0);
+        pre[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
+// Persistent: the grid is a few workgroups per CU and each walks tiles t = block,
+// block + grid, ...  The IQ of the next tile is loaded into registers right after the
+// magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
+// profiling aid: wave 0 of a few workgroups stamps the shader clock at phase boundaries
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        if (p.timeline && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
+            p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
+    } while (0)
+
 __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
 
-    const uint32_t chunk = blockIdx.x / kTilesPerChunk;
-    const int tile = (int)(blockIdx.x % kTilesPerChunk);
-    const int len = chunk_len(p.n_samples, chunk);
-    const int jbase = tile * kTile;
-    if (jbase >= len) return;
-    const int jn = min(kTile, len - jbase);
-
-    // ---------------------------------------------------------------- P0 setup
+    // ---------------------------------------------------------------- P0 once per workgroup
     for (int i = tid; i < 6 * 256; i += kThreads) s.tab[i] = p.tables[i];
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
+
+    uint4 pre[kLoadsPerThread];
+    if (blockIdx.x < n_tiles) load_tile_iq(p, tile_ref(p, blockIdx.x), tid, pre);
+
+    uint32_t iter = 0;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x, iter++) {
+    const TileRef cur = tile_ref(p, t);
+    STAMP(0);
+    const uint32_t chunk = cur.chunk;
+    const int tile = cur.tile, len = cur.len, jbase = cur.jbase;
+    const int jn = min(kTile, len - jbase);  // <= 0 for tiles past the end of a short chunk
+
     if (tid == 0) {
         s.npat = 0;
         s.ncand = 0;
         s.nap = 0;
         s.nhit = 0;
-        s.overflow = 0;
     }
 
     // ---------------------------------------------------------------- P1 magnitudes
-    {
-        const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
-        const int k0 = jbase - kPad - kLead;  // IQ sample index of slot 0 (multiple of 4)
-#pragma unroll 2
-        for (int g = tid; g < kAllocSlots / 4; g += kThreads)
-            *(uint2 *)(s.mag + 4 * g) = mag4(iq, k0 + 4 * g, len);
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; i++) {
+        const int g = tid + i * kThreads;
+        if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = mag4_of(pre[i]);
     }
-    __syncthreads();
+    if (t + gridDim.x < n_tiles) load_tile_iq(p, tile_ref(p, t + gridDim.x), tid, pre);
+    lds_barrier();
+    STAMP(1);
+    if (jn <= 0 || p.debug_stop == 1) {
+        lds_barrier();
+        continue;
+    }
 
     // ---------------------------------------------------------------- P2 sign planes
     // item = (g, kw): residues 4g..4g+3, plane bits k = 8kw..8kw+7, i.e. samples
@@ -188,7 +267,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             pb[(kPlaneGT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[6][r];
         }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(2);
+    if (p.debug_stop == 2) continue;
 
     // LT/GT planes for residues 12..23: the same plane advanced by one bit, so that P3
     // can address "sample j + o" as plane (j mod 12) + o with no carry logic.
@@ -198,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
         const int src = (pr < 12 ? kPlaneLT + pr : kPlaneGT + pr - 12) * kPlaneDw + w;
         s.plane[src + 12 * kPlaneDw] = alignbit(s.plane[src + 1], s.plane[src], 1);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---------------------------------------------------------------- P3 preamble patterns
     // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
@@ -239,16 +320,16 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(3);
+    if (p.debug_stop == 3) {
+        lds_barrier();
+        continue;
+    }
     if (s.npat > (uint32_t)kPatCap) {  // far denser than any real signal: simple kernel
-        if (tid == 0) {
-            const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
-            if (d < p.deferred_cap)
-                p.deferred[d] = (chunk << 8) | (uint32_t)tile;
-            else
-                atomicOr(&p.ctr->overflow, 4u);
-        }
-        return;
+        if (tid == 0) defer_tile(p, chunk, tile);
+        lds_barrier();
+        continue;
     }
 
     // ---------------------------------------------------------------- P4 value gates
@@ -301,16 +382,16 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(4);
+    if (p.debug_stop == 4) {
+        lds_barrier();
+        continue;
+    }
     if (s.ncand > (uint32_t)kCandCap) {
-        if (tid == 0) {
-            const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
-            if (d < p.deferred_cap)
-                p.deferred[d] = (chunk << 8) | (uint32_t)tile;
-            else
-                atomicOr(&p.ctr->overflow, 4u);
-        }
-        return;
+        if (tid == 0) defer_tile(p, chunk, tile);
+        lds_barrier();
+        continue;
     }
 
     // ---------------------------------------------------------------- P5 trials
@@ -395,29 +476,29 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(5);
+    if (p.debug_stop == 5) {
+        lds_barrier();
+        continue;
+    }
     if (s.nap > (uint32_t)kApCap || s.nhit > (uint32_t)kHitCap) {
         // nothing has been written to the global lists yet; bitmap bits already set are
         // a harmless superset (the dense pass sets them again)
-        if (tid == 0) {
-            const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
-            if (d < p.deferred_cap)
-                p.deferred[d] = (chunk << 8) | (uint32_t)tile;
-            else
-                atomicOr(&p.ctr->overflow, 4u);
-        }
-        return;
+        if (tid == 0) defer_tile(p, chunk, tile);
+        lds_barrier();
+        continue;
     }
 
     // ---------------------------------------------------------------- flush
     const uint32_t nap = s.nap, nhit = s.nhit;
-    const uint32_t seg = blockIdx.x % kApSegments;
+    const uint32_t seg = t % kApSegments;
     if (tid == 0) {
         s.ap_base = nap ? atomicAdd(&p.ctr->seg_ap[seg], nap) : 0u;
         s.hit_base = nhit ? atomicAdd(&p.ctr->n_hits, nhit) : 0u;
         if (s.ncand) atomicAdd(&p.ctr->seg_cand[seg], s.ncand);
     }
-    __syncthreads();
+    lds_barrier();
     const uint32_t seg_cap = p.ap_cap / kApSegments;
     if (s.ap_base + nap > seg_cap) {
         if (tid == 0) atomicOr(&p.ctr->overflow, 2u);
@@ -430,6 +511,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
     } else {
         for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
     }
+    lds_barrier();  // the staging area is the next tile's magnitude buffer
+    STAMP(6);
+    }  // tile loop
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -439,8 +523,25 @@ inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 int launch_scan(const ScanParams &p, bool from_mag, void *stream)
 {
     if (from_mag) return launch_scan_simple(p, true, stream);
-    const uint32_t blocks = p.n_chunks * kTilesPerChunk;
-    if (blocks == 0) return 0;
+    const uint32_t tiles = p.n_chunks * kTilesPerChunk;
+    if (tiles == 0) return 0;
+    // persistent grid = what is resident at once (occupancy API x CUs), found once
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast, kThreads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            per_cu <= 0 || cus <= 0) {
+            per_cu = 2;
+            cus = 256;
+        }
+        resident = per_cu * cus;
+        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) resident = std::atoi(e) * cus;
+        if (std::getenv("ADSB_TIMELINE"))
+            std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
+    }
+    const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
     hipLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
