@@ -105,21 +105,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    scan_ms = dense_ms = match_ms = rec_ms = dev_ms = 0.0
+    # HIP events around the scan kernel and around the whole kernel chain, recorded by the
+    # library on the stream the kernels run on (level 1); read back per step
+    ctx.set_profiling(1)
+    scan_ms = 0.0
     frames = 0
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         frames += step(args.warmup + i)
-        s = ctx.stats()  # cheap host-side struct copy
-        scan_ms += s["ms_scan"]
-        dense_ms += s["ms_dense"]
-        match_ms += s["ms_match"]
-        rec_ms += s["ms_records"]
-        dev_ms += s["ms_total_device"]
+        s = ctx.stats_raw()
+        scan_ms += s.ms_scan
     fence()
     elapsed = time.perf_counter() - t0
     stats = ctx.stats()
+
+    # untimed: the same steps once more with an event after every kernel, for the split
+    ctx.set_profiling(2)
+    dense_ms = match_ms = rec_ms = dev_ms = 0.0
+    for i in range(args.steps):
+        step(args.warmup + i)
+        s = ctx.stats_raw()
+        dev_ms += s.ms_total_device
+        dense_ms += s.ms_dense
+        match_ms += s.ms_match
+        rec_ms += s.ms_records
+    ctx.set_profiling(1)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

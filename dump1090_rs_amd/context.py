@@ -164,8 +164,16 @@ class Context:
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._L.adsb_set_stream(self._h, C.c_void_p(hip_stream)), "adsb_set_stream")
 
-    def set_profiling(self, enabled: bool) -> None:
-        self._check(self._L.adsb_set_profiling(self._h, int(enabled)), "adsb_set_profiling")
+    def set_profiling(self, level: int) -> None:
+        """0 = no HIP events, 1 = scan kernel + whole chain (default), 2 = every kernel."""
+        self._check(self._L.adsb_set_profiling(self._h, int(level)), "adsb_set_profiling")
+
+    def stats_raw(self) -> AdsbStats:
+        """The adsb_stats struct itself (no dict building: for tight loops)."""
+        if not hasattr(self, "_stats_buf"):
+            self._stats_buf = AdsbStats()
+        self._check(self._L.adsb_get_stats(self._h, C.byref(self._stats_buf)), "adsb_get_stats")
+        return self._stats_buf
 
     def stats(self) -> dict:
         s = AdsbStats()

@@ -21,6 +21,23 @@ __global__ __launch_bounds__(256) void k_to_mag(const uint32_t *__restrict__ iq,
 }
 
 // ---------------------------------------------------------------------------
+// reset: one launch per pass instead of a string of memsets.  Zeroes the counters and,
+// after an icao_flush, the 2 MiB address bitmap; address 0 always tests true
+// (src/icao_filter.rs:71-80: an empty slot equals 0), so bit 0 starts set.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reset(Counters *ctr, uint32_t *bitmap)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t kCtrDwords = sizeof(Counters) / 4;
+    if (i < kCtrDwords) ((uint32_t *)ctr)[i] = 0;
+    if (bitmap) {
+        constexpr uint32_t kBitmapVec = (1u << 24) / 8 / 16;  // uint4 units
+        for (uint32_t v = i; v < kBitmapVec; v += gridDim.x * blockDim.x)
+            ((uint4 *)bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // match.  An address/parity trial can only score >= 0 if its CRC residual is in
 // the filter when it is scored (mode_s/mod.rs:71,115,130); the bitmap now holds
 // every address the filter can contain at any point of this call (plus 0, which
@@ -37,13 +54,14 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     __shared__ uint32_t stab[6 * 256];  // X51 and X107
     for (int i = threadIdx.x; i < 6 * 256; i += blockDim.x) stab[i] = p.tables[kTabX51 * 256 + i];
     __syncthreads();
-    // block b works on AP segment b % kApSegments (the grid is a multiple of kApSegments)
-    const uint32_t seg = blockIdx.x % kApSegments;
+    // blocks 0..kApSegments-1 take one segment of the fast scan's list each; the blocks
+    // beyond stride over the dap list of the simple / dense kernels
+    const bool seg_block = blockIdx.x < (uint32_t)kApSegments;
     const uint32_t seg_cap = p.ap_cap / kApSegments;
-    const uint32_t n = min(p.ctr->seg_ap[seg], seg_cap);
-    const uint64_t *ap = p.ap + (uint64_t)seg * seg_cap;
-    const uint32_t stride = (gridDim.x / kApSegments) * blockDim.x;
-    for (uint32_t i = (blockIdx.x / kApSegments) * blockDim.x + threadIdx.x;; i += stride) {
+    const uint32_t n = seg_block ? min(p.ctr->seg_ap[blockIdx.x], seg_cap) : min(p.ctr->n_dap, p.dap_cap);
+    const uint64_t *ap = seg_block ? p.ap + (uint64_t)blockIdx.x * seg_cap : p.dap;
+    const uint32_t stride = seg_block ? blockDim.x : (gridDim.x - kApSegments) * blockDim.x;
+    for (uint32_t i = (seg_block ? 0u : (blockIdx.x - kApSegments) * blockDim.x) + threadIdx.x;; i += stride) {
         // whole waves stay in the loop together so wave_append's ballot is uniform
         const uint32_t wave_first = i - (threadIdx.x & 63);
         if (wave_first >= n) break;
@@ -96,6 +114,29 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 {
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {  // one wave totals the counters for the host
+        uint32_t ap = 0, cand = 0;
+        for (int i = lane; i < kApSegments; i += 64) {
+            ap += p.ctr->seg_ap[i];
+            cand += p.ctr->seg_cand[i];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ap += __shfl_down(ap, off);
+            cand += __shfl_down(cand, off);
+        }
+        if (lane == 0) {
+            Summary sm;
+            sm.n_hits = p.ctr->n_hits;
+            sm.overflow = p.ctr->overflow;
+            sm.n_deferred = p.ctr->n_deferred;
+            sm.n_dap = p.ctr->n_dap;
+            sm.n_ap_total = ap + p.ctr->n_dap;
+            sm.n_cand_total = cand + p.ctr->n_cand_simple;
+            sm.pad[0] = sm.pad[1] = 0;
+            *p.summary = sm;
+        }
+    }
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t i = wave; i < n; i += nwaves) {
@@ -180,13 +221,18 @@ int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream)
     return hip_ok(hipGetLastError());
 }
 
+int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
+{
+    const uint32_t blocks = bitmap ? 512u : (uint32_t)((sizeof(Counters) / 4 + 255) / 256);
+    hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ctr, bitmap);
+    return hip_ok(hipGetLastError());
+}
+
 int launch_match(const ScanParams &p, void *stream)
 {
-    // grid-stride over a count only the device knows; sized for the usual ~2 % of samples
-    uint64_t guess = p.n_samples / 32 + 1;
-    uint32_t blocks = (uint32_t)((guess + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    blocks = (blocks + kApSegments - 1) / kApSegments * kApSegments;
+    // one block per segment of the fast scan's AP list + 64 blocks for the dap list; the
+    // counts live on the device
+    const uint32_t blocks = kApSegments + 64;
     hipLaunchKernelGGL(k_match, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }

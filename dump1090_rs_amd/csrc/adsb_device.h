@@ -58,20 +58,32 @@ struct TrialRecord {
 };
 static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 
-// The AP list is split into kApSegments equal segments, each with its own fill counter,
-// so the per-tile reservations of ~9000 workgroups do not serialise on one word
-// (one hot counter saturates near 90 atomics/us on this chip).  Tile b uses segment
-// b % kApSegments.
-constexpr int kApSegments = 64;
+// The AP list of the fast scan is split into kApSegments equal segments; persistent
+// workgroup b owns segment b outright, so appending needs no atomic at all (a returning
+// global atomic costs a workgroup 1-2 us per tile, and one hot counter saturates near
+// 90 atomics/us on this chip).  The simple / dense kernels append to a second list,
+// `dap`, through one shared counter: they are the slow path anyway.
+constexpr int kApSegments = 1024;
 
 // Device counters block (one per context).
 struct Counters {
     uint32_t n_hits;       // entries in the hit list
-    uint32_t overflow;     // bit0: hit list full, bit1: an AP segment full, bit2: deferred list full
+    uint32_t overflow;     // bit0: hit list, bit1: an AP segment, bit2: deferred list, bit3: dap list
     uint32_t n_deferred;   // tiles handed to the dense kernel
-    uint32_t pad;
+    uint32_t n_dap;        // entries in the dap list
+    uint32_t n_cand_simple;  // candidates seen by the simple / dense kernels (diagnostic)
+    uint32_t pad[3];
     uint32_t seg_ap[kApSegments];    // entries in each AP segment
-    uint32_t seg_cand[kApSegments];  // candidates seen (diagnostic), same striping
+    uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
+};
+
+// What the host needs after a pass, gathered by the records kernel (the last one to run)
+// so that one small copy brings it back.
+struct Summary {
+    uint32_t n_hits, overflow, n_deferred, n_dap;
+    uint32_t n_ap_total;    // all AP entries (fast segments + dap)
+    uint32_t n_cand_total;  // all candidates
+    uint32_t pad[2];
 };
 
 // GF(2) tables, 256 u32 each (adsb_tables.h): F0 F1 F2 | X51_0..2 | X107_0..2
@@ -86,16 +98,21 @@ struct ScanParams {
     uint32_t hits_cap;
     uint64_t *ap;           // kApSegments segments of ap_cap / kApSegments entries
     uint32_t ap_cap;        // a multiple of kApSegments
+    uint64_t *dap;          // AP entries of the simple / dense kernels
+    uint32_t dap_cap;
     uint32_t *deferred;     // (chunk << 8 | fast-tile index) of tiles the fast kernel gave up on
     uint32_t deferred_cap;
     const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
+    Summary *summary;
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
 };
 
 // launches; all asynchronous on `stream`, return a hipError_t as int
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
+// zero the counters block and, when `bitmap` is non-null, clear the address bitmap (bit 0 stays set)
+int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream);
 int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_dense(const ScanParams &p, void *stream);

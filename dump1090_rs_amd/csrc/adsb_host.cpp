@@ -24,7 +24,8 @@ struct adsb_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    bool profiling = true;
+    int profiling = 1;  // 0: no events, 1: around the scan kernel, 2: around every kernel
+    bool flush_pending = true;  // the bitmap is cleared by the next pass's reset kernel
     int debug_stop = 0;  // ADSB_DEBUG_STOP: profiling aid, breaks results when non-zero
     unsigned long long *d_timeline = nullptr;  // ADSB_TIMELINE=1: 8 blocks x 8 tiles x 8 stamps
     size_t max_chunks = 0;
@@ -34,13 +35,14 @@ struct adsb_ctx {
     uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
     uint32_t *d_bitmap = nullptr;
     Counters *d_ctr = nullptr;
-    uint64_t *d_hits = nullptr, *d_ap = nullptr;
+    uint64_t *d_hits = nullptr, *d_ap = nullptr, *d_dap = nullptr;
     TrialRecord *d_rec = nullptr;
     uint32_t *d_deferred = nullptr;
     uint32_t *d_tables = nullptr;
-    uint32_t hits_cap = 0, ap_cap = 0, deferred_cap = 0;
+    uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0, deferred_cap = 0;
 
-    Counters *h_ctr = nullptr;     // pinned
+    Summary *d_sum = nullptr;
+    Summary *h_sum = nullptr;      // pinned
     TrialRecord *h_rec = nullptr;  // pinned, hits_cap entries
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -54,6 +56,7 @@ namespace {
 
 constexpr size_t kBitmapBytes = (1u << 24) / 8;
 constexpr uint32_t kWorstPerChunk = 5u * kChunkSamples;  // every j sliced, 5 trials each
+constexpr size_t kInlineRecords = 1024;  // records fetched together with the summary
 
 int fail(adsb_ctx *c, hipError_t e, const char *what)
 {
@@ -68,16 +71,6 @@ int fail(adsb_ctx *c, hipError_t e, const char *what)
         hipError_t e_ = (call);                              \
         if (e_ != hipSuccess) return fail((ctx), e_, #call); \
     } while (0)
-
-int reset_bitmap(adsb_ctx *c)
-{
-    HIP_TRY(c, hipMemsetAsync(c->d_bitmap, 0, kBitmapBytes, c->stream));
-    // address 0 always tests true (src/icao_filter.rs:71-80: an empty slot equals 0)
-    const uint32_t one = 1;
-    HIP_TRY(c, hipMemcpyAsync(c->d_bitmap, &one, sizeof(one), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return ADSB_OK;
-}
 
 // Ordered replay (src/demod_2400.rs:149-207 with mode_s scoring): records sorted by
 // (chunk, j, try_phase); per (chunk, j) the best trial by strictly-greater score
@@ -130,54 +123,62 @@ int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples,
     p.hits_cap = c->hits_cap;
     p.ap = c->d_ap;
     p.ap_cap = c->ap_cap;
+    p.dap = c->d_dap;
+    p.dap_cap = c->dap_cap;
     p.deferred = c->d_deferred;
     p.deferred_cap = c->deferred_cap;
     p.tables = c->d_tables;
     p.ctr = c->d_ctr;
+    p.summary = c->d_sum;
     p.debug_stop = c->debug_stop;
     p.timeline = c->d_timeline;
 
-    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+    if (int e = launch_reset(c->d_ctr, c->flush_pending ? c->d_bitmap : nullptr, c->stream))
+        return fail(c, (hipError_t)e, "launch_reset");
+    c->flush_pending = false;
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (!from_mag)  // tiles the fast scan deferred (normally none; the kernel then exits at once)
         if (int e = launch_dense(p, c->stream)) return fail(c, (hipError_t)e, "launch_dense");
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (c->profiling > 1) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    if (c->profiling > 1) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     if (int e = launch_records(p, from_mag, c->d_rec, c->stream))
         return fail(c, (hipError_t)e, "launch_records");
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost,
-                              c->stream));
+    if (c->profiling > 1) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    // one round trip: the summary and the first kInlineRecords records come back together
+    HIP_TRY(c, hipMemcpyAsync(c->h_sum, c->d_sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_rec, c->d_rec, kInlineRecords * sizeof(TrialRecord),
+                              hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
-    if (c->h_ctr->overflow) return 1;
-    const size_t n = c->h_ctr->n_hits;
-    if (n) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_rec, c->d_rec, n * sizeof(TrialRecord),
-                                  hipMemcpyDeviceToHost, c->stream));
+    if (c->h_sum->overflow) return 1;
+    const size_t n = c->h_sum->n_hits;
+    if (n > kInlineRecords) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_rec + kInlineRecords, c->d_rec + kInlineRecords,
+                                  (n - kInlineRecords) * sizeof(TrialRecord), hipMemcpyDeviceToHost,
+                                  c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (c->profiling) {
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         c->stats.ms_scan += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-        c->stats.ms_dense += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-        c->stats.ms_match += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-        c->stats.ms_records += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
-        c->stats.ms_total_device += ms;
+        if (c->profiling > 1) {  // per-kernel split of the tail (costs a few us per pass)
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+            c->stats.ms_dense += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            c->stats.ms_match += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+            c->stats.ms_records += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
+            c->stats.ms_total_device += ms;
+        }
     }
-    for (int sgm = 0; sgm < kApSegments; sgm++) {
-        c->stats.n_candidates += c->h_ctr->seg_cand[sgm];
-        c->stats.n_ap_entries += c->h_ctr->seg_ap[sgm];
-    }
-    c->stats.n_deferred += c->h_ctr->n_deferred;
+    c->stats.n_candidates += c->h_sum->n_cand_total;
+    c->stats.n_ap_entries += c->h_sum->n_ap_total;
+    c->stats.n_deferred += c->h_sum->n_deferred;
     c->stats.n_records += n;
     replay(c->filter, c->crc, c->h_rec, n, chunk_offset, out);
     return 0;
@@ -254,12 +255,14 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     if (const char *ds = std::getenv("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     // lists sized for ~5x the rate pure noise produces (2.3 % of samples become
     // address/parity entries); denser input falls back to per-chunk passes
-    // Each of the kApSegments AP segments must hold the worst case of the blocks that can
-    // map to it in a single-chunk pass (one half-tile of the dense kernel, every j sliced,
-    // plus one fast tile's staging buffer): 24576 entries.
-    uint64_t ap = std::max<uint64_t>((uint64_t)kApSegments * 24576, max_chunks * (uint64_t)kChunkSamples / 8 + 65536);
-    ap = (ap + kApSegments - 1) / kApSegments * kApSegments;
-    c->ap_cap = (uint32_t)std::min<uint64_t>(ap, 0xFFFFFFC0u);
+    // Fast-scan AP list: kApSegments private segments, sized for ~5x the rate pure noise
+    // produces (2.3 % of samples become address/parity entries), never less than one
+    // tile's staging buffer so that a single-chunk pass always fits.  Denser input falls
+    // back to per-chunk passes.  dap (simple / dense kernels) holds a whole chunk's worst
+    // case: every j sliced, five trials each.
+    uint64_t seg = std::max<uint64_t>(2048, (max_chunks * (uint64_t)kChunkSamples / 8 + kApSegments - 1) / kApSegments);
+    c->ap_cap = (uint32_t)std::min<uint64_t>(seg * kApSegments, 0xFFFFFC00u);
+    c->dap_cap = kWorstPerChunk;
     c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
     c->deferred_cap = (uint32_t)std::min<uint64_t>(max_chunks * 32, 1u << 24);
 
@@ -273,6 +276,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_ctr, sizeof(Counters)));
         HIP_TRY(c, hipMalloc((void **)&c->d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_rec, (size_t)c->hits_cap * sizeof(TrialRecord)));
         HIP_TRY(c, hipMalloc((void **)&c->d_deferred, (size_t)c->deferred_cap * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabCount * 256 * sizeof(uint32_t)));
@@ -281,15 +285,18 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
                                  hipMemcpyHostToDevice));
         }
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&c->d_sum, sizeof(Summary)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_sum, sizeof(Summary), hipHostMallocDefault));
         HIP_TRY(c, hipHostMalloc((void **)&c->h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
                                  hipHostMallocDefault));
-        for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+        // timing-only events: no system-scope fence when they complete (that fence costs ~10 us each)
+        for (auto &e : c->ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
         if (std::getenv("ADSB_TIMELINE")) {
             HIP_TRY(c, hipMalloc((void **)&c->d_timeline, 512 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemset(c->d_timeline, 0, 512 * sizeof(unsigned long long)));
         }
-        return reset_bitmap(c);
+        c->flush_pending = true;
+        return (int)ADSB_OK;
     };
     rc = body();
     if (rc != ADSB_OK) {
@@ -314,6 +321,7 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_ap) (void)hipFree(c->d_ap);
+    if (c->d_dap) (void)hipFree(c->d_dap);
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_deferred) (void)hipFree(c->d_deferred);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -332,7 +340,8 @@ void adsb_destroy(adsb_ctx *c)
                 }
         (void)hipFree(c->d_timeline);
     }
-    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->d_sum) (void)hipFree(c->d_sum);
+    if (c->h_sum) (void)hipHostFree(c->h_sum);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -349,7 +358,7 @@ int adsb_set_stream(adsb_ctx *c, void *hip_stream)
 int adsb_set_profiling(adsb_ctx *c, int enabled)
 {
     if (!c) return ADSB_ERR_INVALID;
-    c->profiling = enabled != 0;
+    c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return ADSB_OK;
 }
 
@@ -358,7 +367,8 @@ int adsb_icao_flush(adsb_ctx *c)
     if (!c) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     c->filter.flush();
-    return reset_bitmap(c);
+    c->flush_pending = true;  // stream-ordered: done by the next pass's reset kernel
+    return ADSB_OK;
 }
 
 int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, size_t *length_out)

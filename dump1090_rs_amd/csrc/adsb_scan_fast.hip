@@ -33,6 +33,7 @@
 // lists would overflow (far denser than any real signal) is handed, untouched, to the
 // simple kernel through the deferred list, so the fast path has fixed capacity and the
 // result stays exact.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -50,7 +51,7 @@ constexpr int kK = (kSlots + 11) / 12;        // 667 plane bits per residue
 constexpr int kKBytes = (kK + 7) / 8;         // 84 bytes of plane per residue
 static_assert(kKBytes % 4 == 0, "planes are whole dwords");
 constexpr int kPlaneDw = kKBytes / 4 + 1;     // 22: one dword of read slack (always zero)
-constexpr int kAllocSlots = 96 * kKBytes + 8; // 8072 magnitudes P2 may read
+constexpr int kAllocSlots = 96 * kKBytes + 16; // 8080 magnitudes P2 may read
 constexpr int kPlaneLT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
 constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..107: GT 0..23
 constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
@@ -59,7 +60,7 @@ constexpr int kItems3 = 12 * (kKBytes / 4);   // 252 P3 items: (residue, plane d
 static_assert(kItems2 <= kThreads && kItems3 <= kThreads, "one item per thread");
 constexpr int kPatCap = 1024;                 // positions matching a preamble pattern
 constexpr int kCandCap = 512;                 // positions passing every gate
-constexpr int kApCap = kAllocSlots / 4;       // 2018 staged AP entries (aliases the magnitudes)
+constexpr int kApCap = kAllocSlots / 4;       // 2020 staged AP entries (aliases the magnitudes)
 constexpr int kHitCap = 32;
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
@@ -79,6 +80,20 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
 __device__ __forceinline__ uint32_t push_sign(uint32_t acc, int v)
 {
     return alignbit(acc, (uint32_t)v, 31);
+}
+
+// inclusive prefix sum across the 64 lanes of a wave, in registers (DPP row shifts and
+// row broadcasts; lanes with no source add 0)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)v;
 }
 
 __device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped to 0..32
@@ -115,7 +130,7 @@ struct alignas(16) FastLds {
     uint16_t pat[kPatCap];             // slot | branch << 13
     uint16_t cand[kCandCap];           // slot of p0
     uint64_t hit[kHitCap];
-    uint32_t npat, ncand, nap, nhit, overflow, ap_base, hit_base;
+    uint32_t npat, ncand, nap, nhit, hit_base;
 };
 
 // IQ of one tile, as each thread holds it between the load and the magnitude pass:
@@ -179,6 +194,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
     for (int i = tid; i < 6 * 256; i += kThreads) s.tab[i] = p.tables[i];
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
 
+    const uint32_t seg_cap = p.ap_cap / kApSegments;
+    uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this workgroup
+
     uint4 pre[kLoadsPerThread];
     if (blockIdx.x < n_tiles) load_tile_iq(p, tile_ref(p, blockIdx.x), tid, pre);
 
@@ -223,6 +241,19 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
         for (int q = 0; q < 7; q++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[q][r] = 0;
+        {   // one plane bit beyond the byte (k = 8kw + 8) for LT/GT only: it completes the
+            // "advanced by one bit" copies that P3 addresses as residues 12..23
+            const uint2 lo = *(const uint2 *)(base + 12 * 8);
+            const uint32_t hi = *(const uint32_t *)(base + 12 * 8 + 4);
+            const int m0 = (int)(lo.x & 0xFFFFu), m1 = (int)(lo.x >> 16), m2 = (int)(lo.y & 0xFFFFu),
+                      m3 = (int)(lo.y >> 16), m4 = (int)(hi & 0xFFFFu);
+            const int e8[4] = {m1 - m0, m2 - m1, m3 - m2, m4 - m3};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[5][r] = push_sign(0u, -e8[r]);
+                acc[6][r] = push_sign(0u, e8[r]);
+            }
+        }
 #pragma unroll
         for (int kk = 7; kk >= 0; --kk) {
             const uint2 lo = *(const uint2 *)(base + 12 * kk);      // m0..m3
@@ -263,28 +294,24 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             const int res = 4 * g + r;
 #pragma unroll
             for (int q = 0; q < 5; q++) pb[(q * 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[q][r];
+            // 9 bits: k = 8kw .. 8kw+8.  Residue res holds bits 0..7, residue res+12 (the
+            // same plane advanced one bit) holds bits 1..8.
             pb[(kPlaneLT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[5][r];
             pb[(kPlaneGT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[6][r];
+            pb[(kPlaneLT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[5][r] >> 1);
+            pb[(kPlaneGT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[6][r] >> 1);
         }
     }
     lds_barrier();
     STAMP(2);
     if (p.debug_stop == 2) continue;
 
-    // LT/GT planes for residues 12..23: the same plane advanced by one bit, so that P3
-    // can address "sample j + o" as plane (j mod 12) + o with no carry logic.
-    for (int it = tid; it < 2 * 12 * (kPlaneDw - 1); it += kThreads) {
-        const int w = it % (kPlaneDw - 1);
-        const int pr = it / (kPlaneDw - 1);  // 0..23: LT 0..11, GT 0..11
-        const int src = (pr < 12 ? kPlaneLT + pr : kPlaneGT + pr - 12) * kPlaneDw + w;
-        s.plane[src + 12 * kPlaneDw] = alignbit(s.plane[src + 1], s.plane[src], 1);
-    }
-    lds_barrier();
-
     // ---------------------------------------------------------------- P3 preamble patterns
     // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
+    uint32_t b[5] = {0u, 0u, 0u, 0u, 0u};
+    const int pres = tid % 12, pw = tid / 12;
     if (tid < kItems3) {
-        const int res = tid % 12, w = tid / 12;
+        const int res = pres, w = pw;
         const uint32_t *LT = s.plane + (kPlaneLT + res) * kPlaneDw + w;
         const uint32_t *GT = s.plane + (kPlaneGT + res) * kPlaneDw + w;
 #define LTO(o) LT[(o) * kPlaneDw]  // p[o] < p[o+1]
@@ -303,18 +330,31 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
         const uint32_t b5 = ok & GTO(2) & LTO(3) & E & ~(b1 | b2 | b3 | b4);  // :300
 #undef LTO
 #undef GTO
-        const uint32_t any = b1 | b2 | b3 | b4 | b5;
-        if (any) {
-            uint32_t at = atomicAdd(&s.npat, (uint32_t)__popc(any));
-            const uint32_t bw[5] = {b1, b2, b3, b4, b5};
+        b[0] = b1;
+        b[1] = b2;
+        b[2] = b3;
+        b[3] = b4;
+        b[4] = b5;
+    }
+    {
+        // compaction: wave-wide exclusive scan of the per-lane match counts (DPP, no LDS),
+        // one LDS atomic per wave for the wave's range, then every lane writes its own
+        const uint32_t any = b[0] | b[1] | b[2] | b[3] | b[4];
+        const uint32_t cnt = (uint32_t)__popc(any);
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total) {  // wave-uniform
+            uint32_t wave_base = 0;
+            if (lane == 0) wave_base = atomicAdd(&s.npat, total);
+            uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base) + incl - cnt;
 #pragma unroll
-            for (int b = 0; b < 5; b++) {
-                uint32_t m = bw[b];
+            for (int k = 0; k < 5; k++) {
+                uint32_t m = b[k];
                 while (m) {
                     const int bit = __ffs(m) - 1;
                     m &= m - 1;
                     if (at < (uint32_t)kPatCap)
-                        s.pat[at] = (uint16_t)((12 * (32 * w + bit) + res) | (b << 13));
+                        s.pat[at] = (uint16_t)((12 * (32 * pw + bit) + pres) | (k << 13));
                     at++;
                 }
             }
@@ -491,29 +531,33 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
     }
 
     // ---------------------------------------------------------------- flush
+    // AP entries go to this workgroup's own segment: no atomic, the fill count is a
+    // register that is written back once when the workgroup retires.
     const uint32_t nap = s.nap, nhit = s.nhit;
-    const uint32_t seg = t % kApSegments;
-    if (tid == 0) {
-        s.ap_base = nap ? atomicAdd(&p.ctr->seg_ap[seg], nap) : 0u;
-        s.hit_base = nhit ? atomicAdd(&p.ctr->n_hits, nhit) : 0u;
-        if (s.ncand) atomicAdd(&p.ctr->seg_cand[seg], s.ncand);
-    }
-    lds_barrier();
-    const uint32_t seg_cap = p.ap_cap / kApSegments;
-    if (s.ap_base + nap > seg_cap) {
+    cand_count += s.ncand;
+    if (ap_count + nap > seg_cap) {
         if (tid == 0) atomicOr(&p.ctr->overflow, 2u);
     } else {
-        uint64_t *dst = p.ap + (uint64_t)seg * seg_cap + s.ap_base;
+        uint64_t *dst = p.ap + (uint64_t)blockIdx.x * seg_cap + ap_count;
         for (uint32_t i = tid; i < nap; i += kThreads) dst[i] = s.ap[i];
+        ap_count += nap;
     }
-    if (s.hit_base + nhit > p.hits_cap) {
-        if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
-    } else {
-        for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
+    if (nhit) {  // rare: a handful per chunk
+        if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
+        lds_barrier();
+        if (s.hit_base + nhit > p.hits_cap) {
+            if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
+        } else {
+            for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
+        }
     }
     lds_barrier();  // the staging area is the next tile's magnitude buffer
     STAMP(6);
     }  // tile loop
+    if (tid == 0) {
+        p.ctr->seg_ap[blockIdx.x] = ap_count;
+        p.ctr->seg_cand[blockIdx.x] = cand_count;
+    }
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -537,7 +581,9 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
             cus = 256;
         }
         resident = per_cu * cus;
-        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) resident = std::atoi(e) * cus;
+        if (resident > kApSegments) resident = kApSegments;  // one private AP segment each
+        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU"))
+            resident = std::min(std::atoi(e) * cus, (int)kApSegments);
         if (std::getenv("ADSB_TIMELINE"))
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
     }

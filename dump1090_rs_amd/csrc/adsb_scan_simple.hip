@@ -61,9 +61,7 @@ __device__ __forceinline__ void scan_simple_tile(const ScanParams &p, uint32_t c
     }
     __syncthreads();
     const int ncand = (int)*sncand;
-    const uint32_t seg = blockIdx.x % kApSegments;
-    const uint32_t seg_cap = p.ap_cap / kApSegments;
-    if (threadIdx.x == 0 && ncand) atomicAdd(&p.ctr->seg_cand[seg], (uint32_t)ncand);
+    if (threadIdx.x == 0 && ncand) atomicAdd(&p.ctr->n_cand_simple, (uint32_t)ncand);
 
     // --- five trial phases per candidate (demod_2400.rs:158-184): slice, DF, CRC
     const int ntrial = ncand * 5;
@@ -106,8 +104,7 @@ __device__ __forceinline__ void scan_simple_tile(const ScanParams &p, uint32_t c
             }
         }
         wave_append(is_hit, entry, p.hits, p.hits_cap, &p.ctr->n_hits, &p.ctr->overflow, 1u);
-        wave_append(is_ap, entry, p.ap + (uint64_t)seg * seg_cap, seg_cap, &p.ctr->seg_ap[seg],
-                    &p.ctr->overflow, 2u);
+        wave_append(is_ap, entry, p.dap, p.dap_cap, &p.ctr->n_dap, &p.ctr->overflow, 8u);
     }
 }
 
@@ -169,7 +166,7 @@ int launch_dense(const ScanParams &p, void *stream)
 {
     // the deferred count lives on the device; a small fixed grid strides over it and
     // exits at once when it is zero (the normal case)
-    hipLaunchKernelGGL(k_scan_dense, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_scan_dense, dim3(64), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

@@ -97,8 +97,10 @@ void adsb_destroy(adsb_ctx *ctx);
 /* Launch on the caller's HIP stream (e.g. torch's current stream) instead of the
  * context's own.  Pass NULL to go back to the private stream. */
 int adsb_set_stream(adsb_ctx *ctx, void *hip_stream);
-/* Record HIP events around each kernel so adsb_stats.ms_* are filled (default on). */
-int adsb_set_profiling(adsb_ctx *ctx, int enabled);
+/* HIP-event timing of the kernels: 0 = off, 1 = ms_scan only (default; two events),
+ * 2 = also ms_dense / ms_match / ms_records / ms_total_device (an event costs the
+ * stream several microseconds, so level 2 slows a call down noticeably). */
+int adsb_set_profiling(adsb_ctx *ctx, int level);
 
 /* == icao_filter::icao_flush() (src/icao_filter.rs:11-17) for this context. */
 int adsb_icao_flush(adsb_ctx *ctx);
