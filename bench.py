@@ -133,12 +133,8 @@ def main():
     ctx.set_profiling(1)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        f = torch.tensor([frames], dtype=torch.int64, device=dev)
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-        frames = int(f.item())
+        from dump1090_rs_amd import sharding
+        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device=dev)
 
     total_samples = n * args.steps * world
     msps = total_samples / elapsed / 1e6
