@@ -52,6 +52,8 @@ __device__ __forceinline__ uint32_t mag_tail2(f32x2 x)
 {
     const f32x2 s = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
     const u32x2 sb = __builtin_bit_cast(u32x2, s);
+    // (v_sqrt_f32 errs low for 15 % of the x in range and high for 15049 of them: both
+    // neighbours are needed -- dropping the rare one is caught by the exhaustive sweep)
     const u32x2 dnb = sb - 1u, upb = sb + 1u;
     const f32x2 qdn = pk_fma(__builtin_bit_cast(f32x2, dnb), s, -x);  // >= 0: root is s_dn
     const f32x2 qup = pk_fma(__builtin_bit_cast(f32x2, upb), s, -x);  // <  0: root is s_up

@@ -88,6 +88,8 @@ struct Summary {
 
 // GF(2) tables, 256 u32 each (adsb_tables.h): F0 F1 F2 | X51_0..2 | X107_0..2
 constexpr int kTabF = 0, kTabX51 = 3, kTabX107 = 6, kTabCount = 9;
+// after them in the same buffer: R16 (16 u32, adsb_tables.h) and the field table (300 u32)
+constexpr int kTabR16Off = kTabCount * 256, kTabFieldOff = kTabR16Off + 16, kTabWords = kTabFieldOff + 300;
 
 struct ScanParams {
     const void *src;        // IQ as {re,im} int16 pairs, or u16 magnitudes (from_mag)

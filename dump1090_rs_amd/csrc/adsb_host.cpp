@@ -15,6 +15,7 @@
 
 #include "../../include/adsb_hip.h"
 #include "adsb_device.h"
+#include "adsb_scan_geometry.h"
 #include "adsb_tables.h"
 #include "mode_s_host.hpp"
 
@@ -279,9 +280,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_rec, (size_t)c->hits_cap * sizeof(TrialRecord)));
         HIP_TRY(c, hipMalloc((void **)&c->d_deferred, (size_t)c->deferred_cap * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabCount * 256 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
-            const std::vector<uint32_t> tab = build_gf_tables();
+            std::vector<uint32_t> tab = build_gf_tables();
+            const std::vector<uint32_t> r16 = build_r16(), ft = build_field_table(fast_plane_bytes());
+            tab.insert(tab.end(), r16.begin(), r16.end());
+            tab.insert(tab.end(), ft.begin(), ft.end());
             HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
                                  hipMemcpyHostToDevice));
         }

@@ -29,10 +29,14 @@
 //                  syndrome come from table lookups on the fields (adsb_tables.h); the
 //                  message bytes are never assembled here.
 //
-// Outputs are staged in LDS and flushed with one atomic per tile.  A tile whose LDS
-// lists would overflow (far denser than any real signal) is handed, untouched, to the
-// simple kernel through the deferred list, so the fast path has fixed capacity and the
-// result stays exact.
+// The kernel is VALU-issue bound (tools/valu_rate.hip: ~4.2 cycles per wave64 VOP3 /
+// mad / cvt / compare, ~2.7 for plain VOP2 add/and/shift), so the code below is written
+// to the instruction: 24-bit multiplies with magic constants instead of divisions,
+// shifts and masks instead of bit-field extracts, u16 LDS reads instead of unpacking.
+//
+// A tile whose LDS lists would overflow (far denser than any real signal) is handed,
+// untouched, to the simple kernel through the deferred list, so the fast path has fixed
+// capacity and the result stays exact.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -47,21 +51,17 @@ namespace {
 using namespace fastgeo;
 
 constexpr int kThreads = 256;
-constexpr int kK = (kSlots + 11) / 12;        // 667 plane bits per residue
-constexpr int kKBytes = (kK + 7) / 8;         // 84 bytes of plane per residue
-static_assert(kKBytes % 4 == 0, "planes are whole dwords");
-constexpr int kPlaneDw = kKBytes / 4 + 1;     // 22: one dword of read slack (always zero)
-constexpr int kAllocSlots = 96 * kKBytes + 16; // 8080 magnitudes P2 may read
+constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
 constexpr int kPlaneLT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
 constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..107: GT 0..23
 constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
-constexpr int kItems2 = 3 * kKBytes;          // 252 P2 items: (residue group, plane byte)
-constexpr int kItems3 = 12 * (kKBytes / 4);   // 252 P3 items: (residue, plane dword)
+constexpr int kItems2 = 3 * kPlaneBytes;      // 252 P2 items: (residue group, plane byte)
+constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
 static_assert(kItems2 <= kThreads && kItems3 <= kThreads, "one item per thread");
+static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
 constexpr int kPatCap = 1024;                 // positions matching a preamble pattern
 constexpr int kCandCap = 512;                 // positions passing every gate
-constexpr int kApCap = kAllocSlots / 4;       // 2020 staged AP entries (aliases the magnitudes)
-constexpr int kHitCap = 32;
+constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
 // would wait for the next tile's IQ prefetch at every phase boundary; here only LDS
@@ -96,19 +96,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
     return (uint32_t)v;
 }
 
+// rank of this lane among the set bits of a wave mask
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped to 0..32
 {
     return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
-}
-
-__device__ __forceinline__ uint32_t gf_mulx(uint32_t a)  // * x mod (x^24 + 0xFFF409)
-{
-    return ((a << 1) & 0xFFFFFFu) ^ ((a & 0x800000u) ? 0xFFF409u : 0u);
-}
-
-__device__ __forceinline__ uint32_t tab3(const uint32_t *t, uint32_t f)
-{
-    return t[f & 255u] ^ t[256 + ((f >> 8) & 255u)] ^ t[512 + (f >> 16)];
 }
 
 __device__ __forceinline__ void defer_tile(const ScanParams &p, uint32_t chunk, int tile)
@@ -120,21 +116,27 @@ __device__ __forceinline__ void defer_tile(const ScanParams &p, uint32_t chunk, 
         atomicOr(&p.ctr->overflow, 4u);
 }
 
+// Which magnitudes enter high / base_signal / base_noise for each of check_preamble's five
+// branches (src/demod_2400.rs:227-317), one bit per term:
+//   high  = (p1 + p12 + A*(p3+p9) + B*p11 + C*(p4+p10) + D*p2) / 4
+//   sig   = E*p1 + F*(p3+p9) + G*p12 + H*(p4+p10)
+//   noise = p6 + p7 + I*p5 + J*p8                              bits: A=0 B=1 ... J=9
+constexpr uint32_t kBranchTerms[5] = {0x133u, 0x371u, 0x055u, 0x3D4u, 0x2CCu};
+
 struct alignas(16) FastLds {
-    union {
-        uint16_t mag[kAllocSlots];     // P1..P4
-        uint64_t ap[kApCap];           // P5 staging (magnitudes are dead by then)
-    };
+    uint16_t mag[kAllocSlots];         // P1..P4
     uint32_t plane[kPlanes * kPlaneDw];
     uint32_t tab[6 * 256];             // F0 F1 F2 X51_0 X51_1 X51_2
-    uint16_t pat[kPatCap];             // slot | branch << 13
-    uint16_t cand[kCandCap];           // slot of p0
+    uint32_t r16[16];                  // x^24..x^27 reduction
+    uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
+    uint32_t pat[kPatCap];             // slot | branch terms << 13
+    uint32_t cand[kCandCap];           // slot | slot/12 << 13 | slot%12 << 23
     uint64_t hit[kHitCap];
     uint32_t npat, ncand, nap, nhit, hit_base;
 };
 
 // IQ of one tile, as each thread holds it between the load and the magnitude pass:
-// 8 aligned dwordx4 = 32 samples per thread, 8072 per workgroup.
+// 8 aligned dwordx4 = 32 samples per thread, 8080 per workgroup.
 constexpr int kLoadsPerThread = (kAllocSlots / 4 + kThreads - 1) / kThreads;  // 8
 
 struct TileRef {
@@ -173,9 +175,6 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
     }
 }
 
-// Persistent: the grid is a few workgroups per CU and each walks tiles t = block,
-// block + grid, ...  The IQ of the next tile is loaded into registers right after the
-// magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
 // profiling aid: wave 0 of a few workgroups stamps the shader clock at phase boundaries
 #define STAMP(slot)                                                                          \
     do {                                                                                     \
@@ -183,6 +182,9 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
             p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
     } while (0)
 
+// Persistent: the grid is what is resident at once and each workgroup walks tiles
+// t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
+// after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
 __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
@@ -192,9 +194,17 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
 
     // ---------------------------------------------------------------- P0 once per workgroup
     for (int i = tid; i < 6 * 256; i += kThreads) s.tab[i] = p.tables[i];
+    for (int i = tid; i < 316; i += kThreads) {
+        const uint32_t v = p.tables[kTabR16Off + i];
+        if (i < 16)
+            s.r16[i] = v;
+        else
+            s.field[i - 16] = v;
+    }
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
 
     const uint32_t seg_cap = p.ap_cap / kApSegments;
+    uint64_t *const seg = p.ap + (uint64_t)blockIdx.x * seg_cap;  // this workgroup's AP segment
     uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this workgroup
 
     uint4 pre[kLoadsPerThread];
@@ -275,10 +285,10 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
                 // "D > 0" is the sign bit:  with a = m0-m1 = -e0, b = m1-m2 = -e1, c = m2-m3:
                 //   D0 = 5a+2b  D1 = 4a+3b  D2 = 3a+4b  D3 = 2a+5b  D4 = a+6b+c
                 const int ea = e[r], eb = e[r + 1], ec = e[r + 2];
-                const int n0 = 5 * ea + 2 * eb;
+                const int n0 = __mul24(ea, 5) + (eb + eb);
                 const int u = eb - ea;
                 const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
-                const int n4 = ea + 6 * eb + ec;
+                const int n4 = __mul24(eb, 6) + (ea + ec);
                 acc[0][r] = push_sign(acc[0][r], n0);
                 acc[1][r] = push_sign(acc[1][r], n1);
                 acc[2][r] = push_sign(acc[2][r], n2);
@@ -347,14 +357,14 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             uint32_t wave_base = 0;
             if (lane == 0) wave_base = atomicAdd(&s.npat, total);
             uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base) + incl - cnt;
+            const uint32_t slot0 = (uint32_t)(12 * 32 * pw + pres);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 uint32_t m = b[k];
                 while (m) {
                     const int bit = __ffs(m) - 1;
                     m &= m - 1;
-                    if (at < (uint32_t)kPatCap)
-                        s.pat[at] = (uint16_t)((12 * (32 * pw + bit) + pres) | (k << 13));
+                    if (at < (uint32_t)kPatCap) s.pat[at] = (slot0 + 12u * (uint32_t)bit) | (kBranchTerms[k] << 13);
                     at++;
                 }
             }
@@ -380,45 +390,33 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
         for (int base = 0; base < npat; base += kThreads) {
             const int idx = base + tid;
             bool pass = false;
-            int slot = 0;
+            uint32_t slot = 0;
             if (idx < npat) {
                 const uint32_t ent = s.pat[idx];
-                slot = (int)(ent & 0x1FFFu);
-                const int br = (int)(ent >> 13);
-                // p[0..19] as 10 packed pairs, whatever the parity of slot
-                const uint32_t *q = (const uint32_t *)s.mag + (slot >> 1);
-                const uint32_t sh = (uint32_t)(slot & 1) * 16u;
-                uint32_t x[10];
-                uint32_t d0 = q[0];
-#pragma unroll
-                for (int k = 0; k < 10; k++) {
-                    const uint32_t d1 = q[k + 1];
-                    x[k] = alignbit(d1, d0, sh);
-                    d0 = d1;
-                }
-#define PV(i) ((int)(((i) & 1) ? (x[(i) >> 1] >> 16) : (x[(i) >> 1] & 0xFFFFu)))
-                const int p1 = PV(1), p2 = PV(2), p3 = PV(3), p4 = PV(4), p5 = PV(5), p6 = PV(6),
-                          p7 = PV(7), p8 = PV(8), p9 = PV(9), p10 = PV(10), p11 = PV(11),
-                          p12 = PV(12);
-                const int high = (p1 + p12 + (br <= 2 ? p3 + p9 : 0) + (br == 0 ? p11 : 0) +
-                                  (br >= 2 ? p4 + p10 : 0) + (br == 4 ? p2 : 0)) / 4;
-                const int sig = (br != 4 ? p1 : 0) + (br <= 1 ? p3 + p9 : 0) + (br >= 1 ? p12 : 0) +
-                                (br >= 3 ? p4 + p10 : 0);
-                const int noise = p6 + p7 + ((br == 0 || br == 1 || br == 3) ? p5 : 0) +
-                                  ((br == 1 || br == 3 || br == 4) ? p8 : 0);
-                pass = 2 * sig >= 3 * noise;  // :129
+                slot = ent & 0x1FFFu;
+                const uint16_t *pm = s.mag + slot;  // u16 LDS reads: no unpacking on the VALU
+                const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
+                          p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
+                // 0 / -1 masks of the branch's terms (signed 1-bit field extracts)
+#define TERM(bit) __builtin_amdgcn_sbfe((int)ent, 13 + (bit), 1)
+                const int s39 = p3 + p9, s410 = p4 + p10;
+                const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
+                const int sig = (p1 & TERM(4)) + (s39 & TERM(5)) + (p12 & TERM(6)) + (s410 & TERM(7));
+                const int noise = p6 + p7 + (p5 & TERM(8)) + (p8 & TERM(9));
+#undef TERM
                 const int loud = max(max(max(p5, p6), max(p7, p8)),
-                                     max(max(PV(14), PV(15)), max(max(PV(16), PV(17)), PV(18))));
-                pass = pass && loud < high;   // :135-146
-#undef PV
+                                     max(max((int)pm[14], (int)pm[15]), max(max((int)pm[16], (int)pm[17]), (int)pm[18])));
+                pass = (2 * sig >= 3 * noise) && (loud < high);  // :129, :135-146
             }
             const unsigned long long mask = __ballot(pass);
             if (mask) {
-                const int leader = __ffsll((long long)mask) - 1;
                 uint32_t at = 0;
-                if (lane == leader) at = atomicAdd(&s.ncand, (uint32_t)__popcll(mask));
-                at = __shfl(at, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                if (pass && at < (uint32_t)kCandCap) s.cand[at] = (uint16_t)slot;
+                if (lane == 0) at = atomicAdd(&s.ncand, (uint32_t)__popcll(mask));
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mask);
+                if (pass && at < (uint32_t)kCandCap) {
+                    const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
+                    s.cand[at] = slot | (qs << 13) | ((slot - 12u * qs) << 23);
+                }
             }
         }
     }
@@ -438,58 +436,72 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
     // lane = (candidate, try_phase).  Message bit n = 5k + r of trial phase tp sits at
     // 5x-oversampled position 5*(slot+19) + tp + 12n, i.e. sample
     // slot + 19 + (tp+12r)/5 + 12k with slicer phase (tp+12r) % 5: field r is 23
-    // consecutive bits of one sign plane.
+    // consecutive bits of one sign plane; which plane and where comes from s.field.
     {
-        const int ntrial = (int)s.ncand * 5;
+        const uint32_t ntrial = s.ncand * 5u;
         const uint32_t *tF = s.tab, *tX51 = s.tab + 3 * 256;
-        for (int base = 0; base < ntrial; base += kThreads) {
-            const int t = base + tid;
+        const char *plane_bytes = (const char *)s.plane;
+        for (uint32_t base = 0; base < ntrial; base += kThreads) {
+            const uint32_t t5 = base + (uint32_t)tid;
             bool is_hit = false, is_ap = false;
-            uint64_t entry = 0;
-            if (t < ntrial) {
-                const int c = t / 5, tpi = t - 5 * c;
-                const int slot = s.cand[c];
+            uint32_t e_lo = 0, e_hi = 0;
+            if (t5 < ntrial) {
+                const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
+                const uint32_t tpi = t5 - 5u * c;
+                const uint32_t ce = s.cand[c];
+                const uint32_t slot = ce & 0x1FFFu, qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
+                const uint32_t *ft = s.field + tpi * 60u + rs;
                 uint32_t f[5];
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
-                    const int P = 4 + tpi + 12 * r;
-                    const int a = P / 5, ph = P - 5 * a;
-                    const int i0 = slot + 19 + a;
-                    const int q = i0 / 12, res = i0 - 12 * q;
-                    const uint32_t *pl = s.plane + (ph * 12 + res) * kPlaneDw + (q >> 5);
-                    f[r] = alignbit(pl[1], pl[0], (uint32_t)(q & 31));
+                    const uint32_t fe = ft[r * 12];
+                    const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
+                    const uint32_t *pl = (const uint32_t *)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
+                    f[r] = alignbit(pl[1], pl[0], qq & 31u);
                 }
-                // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise
-                const uint32_t fl[5] = {f[0] & 0x7FFFFFu, f[1] & 0x7FFFFFu, f[2] & 0x3FFFFFu,
-                                        f[3] & 0x3FFFFFu, f[4] & 0x3FFFFFu};
-                const bool nonzero = (fl[0] | fl[1] | fl[2] | fl[3] | fl[4]) != 0;  // mod.rs:51
+                // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
                 const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) |
-                                    ((f[3] & 1u) << 1) | (f[4] & 1u);              // mod.rs:41
+                                    ((f[3] & 1u) << 1) | (f[4] & 1u);
                 const bool is_long = df >= 16;
-                // 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
-                uint32_t h = tab3(tF, is_long ? fl[0] : (f[0] & 0xFFFu));
+                // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks at
+                // all 14 bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
+                const bool nonzero = (((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0;
+                const uint32_t mk0 = is_long ? 0x7FFFFFu : 0xFFFu, mk1 = is_long ? 0x7FFFFFu : 0x7FFu,
+                               mk2 = is_long ? 0x3FFFFFu : 0x7FFu;
+                const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
+                // H' = sum_r x^(4-r) * F(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
+                uint32_t hp = 0;
 #pragma unroll
-                for (int r = 1; r < 5; r++) h = gf_mulx(h) ^ tab3(tF, is_long ? fl[r] : (f[r] & 0x7FFu));
+                for (int r = 0; r < 5; r++) {
+                    const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
+                    const uint32_t g = *(const uint32_t *)((const char *)tF + (x4 & 0x3FCu)) ^
+                                       *(const uint32_t *)((const char *)tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
+                                       *(const uint32_t *)((const char *)tF + 2048 + ((x4 >> 16) & 0x3FCu));
+                    hp ^= g << (4 - r);
+                }
+                const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
 
                 const bool df11 = df == 11, df1718 = df == 17 || df == 18;
                 const bool ap_short = df == 0 || df == 4 || df == 5;
                 const bool ap_long = df == 16 || df == 20 || df == 21 || df >= 24;
-                const uint32_t j = (uint32_t)(jbase + slot - kPad);
-                const uint32_t code = (uint32_t)tpi + (is_long ? 5u : 0u);
                 bool learn = false;  // the host replay will add this address to the filter
                 if (nonzero) {
                     if (df1718) {                       // mod.rs:91-109: clean iff H == 0
                         is_hit = h == 0;
                         learn = is_hit && df == 17;     // DF18 adds addr|1<<25: never matched
                     } else if (df11) {                  // mod.rs:73-90
-                        const uint32_t crc = tab3(tX51, h);
+                        const uint32_t crc = tX51[h & 255u] ^ tX51[256 + ((h >> 8) & 255u)] ^ tX51[512 + (h >> 16)];
                         is_hit = (crc & 0xFFFF80u) == 0;
                         learn = is_hit && (crc & 0x7Fu) == 0;
                     } else {
                         is_ap = ap_short || ap_long;    // mod.rs:56-72, 110-135
                     }
                 }
-                entry = pack_entry(h, code, j, chunk);
+                // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
+                const uint32_t j = (uint32_t)(jbase - kPad) + slot;
+                const uint32_t code = tpi + (is_long ? 5u : 0u);
+                e_lo = h | (code << 24) | (j << 28);
+                e_hi = (j >> 4) | (chunk << 13);
                 if (learn) {
                     uint32_t addr = 0;  // message bits 8..31
 #pragma unroll
@@ -497,22 +509,31 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
                     bitmap_set(p.bitmap, addr);
                 }
             }
-            // stage in LDS; one LDS atomic per wave
+            const uint64_t entry = ((uint64_t)e_hi << 32) | e_lo;
+            // AP entries: straight into this workgroup's own segment, compacted per wave
             const unsigned long long ma = __ballot(is_ap);
             if (ma) {
-                const int leader = __ffsll((long long)ma) - 1;
                 uint32_t at = 0;
-                if (lane == leader) at = atomicAdd(&s.nap, (uint32_t)__popcll(ma));
-                at = __shfl(at, leader) + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
-                if (is_ap && at < (uint32_t)kApCap) s.ap[at] = entry;
+                if (lane == 0) at = atomicAdd(&s.nap, (uint32_t)__popcll(ma));
+                at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(ma);
+                if (is_ap && at < seg_cap) seg[at] = entry;
             }
             const unsigned long long mh = __ballot(is_hit);
-            if (mh) {
-                const int leader = __ffsll((long long)mh) - 1;
+            if (mh) {  // rare
                 uint32_t at = 0;
-                if (lane == leader) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
-                at = __shfl(at, leader) + (uint32_t)__popcll(mh & ((1ull << lane) - 1ull));
-                if (is_hit && at < (uint32_t)kHitCap) s.hit[at] = entry;
+                if (lane == 0) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
+                if (is_hit) {
+                    if (at < (uint32_t)kHitCap) {
+                        s.hit[at] = entry;
+                    } else {  // more hits in one tile than the staging holds: one by one
+                        const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
+                        if (gi < p.hits_cap)
+                            p.hits[gi] = entry;
+                        else
+                            atomicOr(&p.ctr->overflow, 1u);
+                    }
+                }
             }
         }
     }
@@ -522,26 +543,17 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
         lds_barrier();
         continue;
     }
-    if (s.nap > (uint32_t)kApCap || s.nhit > (uint32_t)kHitCap) {
-        // nothing has been written to the global lists yet; bitmap bits already set are
-        // a harmless superset (the dense pass sets them again)
-        if (tid == 0) defer_tile(p, chunk, tile);
-        lds_barrier();
-        continue;
-    }
 
-    // ---------------------------------------------------------------- flush
-    // AP entries go to this workgroup's own segment: no atomic, the fill count is a
-    // register that is written back once when the workgroup retires.
-    const uint32_t nap = s.nap, nhit = s.nhit;
+    // ---------------------------------------------------------------- tile epilogue
+    // The AP fill count of the private segment is a register; it is written back once
+    // when the workgroup retires.
     cand_count += s.ncand;
-    if (ap_count + nap > seg_cap) {
+    ap_count += s.nap;
+    if (ap_count > seg_cap) {
+        ap_count = seg_cap;
         if (tid == 0) atomicOr(&p.ctr->overflow, 2u);
-    } else {
-        uint64_t *dst = p.ap + (uint64_t)blockIdx.x * seg_cap + ap_count;
-        for (uint32_t i = tid; i < nap; i += kThreads) dst[i] = s.ap[i];
-        ap_count += nap;
     }
+    const uint32_t nhit = min(s.nhit, (uint32_t)kHitCap);
     if (nhit) {  // rare: a handful per chunk
         if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
         lds_barrier();
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
             for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
         }
     }
-    lds_barrier();  // the staging area is the next tile's magnitude buffer
+    lds_barrier();  // counters and lists are reset / reused by the next tile
     STAMP(6);
     }  // tile loop
     if (tid == 0) {
@@ -581,9 +593,9 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
             cus = 256;
         }
         resident = per_cu * cus;
+        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) resident = std::atoi(e) * cus;
         if (resident > kApSegments) resident = kApSegments;  // one private AP segment each
-        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU"))
-            resident = std::min(std::atoi(e) * cus, (int)kApSegments);
+        if (resident < 1) resident = 1;
         if (std::getenv("ADSB_TIMELINE"))
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
     }

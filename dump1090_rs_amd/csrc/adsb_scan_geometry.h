@@ -15,5 +15,14 @@ constexpr int kSlots = kTile + kPad + kReach;  // 8004 magnitudes a tile touches
 static_assert(kTile % 4 == 0 && (kLead + kPad) % 4 == 0, "aligned dwordx4 IQ loads");
 static_assert(kTilesPerChunk < 256, "deferred entries keep the tile index in 8 bits");
 
+// sign planes: bit k of plane (kind, res) = decision at slot 12k + res
+constexpr int kPlaneBits = (kSlots + 11) / 12;         // 667 per residue
+constexpr int kPlaneBytes = (kPlaneBits + 7) / 8;      // 84
+static_assert(kPlaneBytes % 4 == 0, "planes are whole dwords");
+constexpr int kPlaneDw = kPlaneBytes / 4 + 1;          // 22: one dword of read slack (always zero)
+
 }  // namespace fastgeo
+
+// bytes between plane rows in the fast scan's LDS (for the host-built field table)
+inline uint32_t fast_plane_bytes() { return fastgeo::kPlaneDw * 4; }
 }  // namespace adsb

@@ -71,4 +71,37 @@ inline std::vector<uint32_t> build_gf_tables()
     return t;
 }
 
+// Reduction of x^24..x^27: R16[v] = sum of x^(24+i) over set bits i of v (16 entries).
+inline std::vector<uint32_t> build_r16()
+{
+    uint32_t xp[4];
+    uint32_t p = 1;
+    for (int e = 0; e < 24; e++) p = gf_mulx(p);
+    for (int i = 0; i < 4; i++, p = gf_mulx(p)) xp[i] = p;
+    std::vector<uint32_t> r(16, 0);
+    for (uint32_t v = 0; v < 16; v++)
+        for (int i = 0; i < 4; i++)
+            if (v & (1u << i)) r[v] ^= xp[i];
+    return r;
+}
+
+// Field addressing of the fast scan's trial phase.  Message bit n = 5k + r of trial phase
+// tp = 4 + tpi at a preamble whose LDS slot is 12*qs + rs sits in sign plane
+// (ph, res), bit qs + carry + k, with
+//     P = tp + 12r,  a = P / 5,  ph = P % 5,  res' = rs + 19 + a,  carry = res' / 12,  res = res' % 12
+// (reference src/demod_2400.rs:158-182 in closed form).  Entry [tpi][r][rs] =
+// byte offset of plane row (ph*12 + res) | carry << 16; plane rows are plane_bytes long.
+inline std::vector<uint32_t> build_field_table(uint32_t plane_bytes)
+{
+    std::vector<uint32_t> t(5 * 5 * 12, 0);
+    for (int tpi = 0; tpi < 5; tpi++)
+        for (int r = 0; r < 5; r++)
+            for (int rs = 0; rs < 12; rs++) {
+                const int P = 4 + tpi + 12 * r, a = P / 5, ph = P % 5;
+                const int rp = rs + 19 + a, carry = rp / 12, res = rp % 12;
+                t[(tpi * 5 + r) * 12 + rs] = (uint32_t)((ph * 12 + res) * plane_bytes) | ((uint32_t)carry << 16);
+            }
+    return t;
+}
+
 }  // namespace adsb
