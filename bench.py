@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--chunks", type=int, default=512, help="131072-sample buffers per step")
     ap.add_argument("--buffers", type=int, default=3, help="distinct IQ buffers rotated over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true",
+                    help="one blocking adsb_demod_iq_device call per step instead of the two-deep "
+                         "submit/collect pipeline")
     return ap.parse_args()
 
 
@@ -91,13 +94,38 @@ def main():
     cap = 1 << 20
     out = (AdsbMsg * cap)()
 
-    def step(i: int) -> int:
-        ctx.icao_flush()  # benches/demod_benchmark.rs:9
-        b = bufs[i % len(bufs)]
-        return ctx.demod_iq_device_raw(b.data_ptr(), n, out, cap)
+    def run_steps(first: int, count: int, level: int):
+        """`count` steps starting at step index `first`.  Returns (frames, summed stats).
+        A step is icao_flush (benches/demod_benchmark.rs:9) + the whole pass over one buffer.
+        Pipelined form: step i is submitted before step i-1 is collected, so the host part
+        of one step (wait, copy-back, ordered replay) overlaps the device scan of the next;
+        every step's full work still happens inside the loop."""
+        ctx.set_profiling(level)
+        tot = {"ms_scan": 0.0, "ms_dense": 0.0, "ms_match": 0.0, "ms_records": 0.0, "ms_total_device": 0.0}
+        frames = 0
 
-    for i in range(args.warmup):
-        step(i)
+        def account():
+            st = ctx.stats_raw()
+            for k in tot:
+                tot[k] += getattr(st, k)
+
+        for i in range(count):
+            b = bufs[(first + i) % len(bufs)]
+            ctx.icao_flush()
+            if args.sync:
+                frames += ctx.demod_iq_device_raw(b.data_ptr(), n, out, cap)
+                account()
+            else:
+                ctx.submit_iq_device(b.data_ptr(), n)
+                if i > 0:
+                    frames += ctx.collect_raw(out, cap)
+                    account()
+        if not args.sync and count > 0:
+            frames += ctx.collect_raw(out, cap)
+            account()
+        return frames, tot
+
+    run_steps(0, args.warmup, 1)
 
     def fence():
         torch.cuda.synchronize()
@@ -105,31 +133,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around the scan kernel and around the whole kernel chain, recorded by the
-    # library on the stream the kernels run on (level 1); read back per step
-    ctx.set_profiling(1)
-    scan_ms = 0.0
-    frames = 0
+    # Timed region: K steps with HIP events around the scan kernel only (level 1), recorded
+    # by the library on the stream the kernels run on.
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        frames += step(args.warmup + i)
-        s = ctx.stats_raw()
-        scan_ms += s.ms_scan
+    frames, tot = run_steps(args.warmup, args.steps, 1)
     fence()
     elapsed = time.perf_counter() - t0
+    scan_ms = tot["ms_scan"]
     stats = ctx.stats()
 
     # untimed: the same steps once more with an event after every kernel, for the split
-    ctx.set_profiling(2)
-    dense_ms = match_ms = rec_ms = dev_ms = 0.0
-    for i in range(args.steps):
-        step(args.warmup + i)
-        s = ctx.stats_raw()
-        dev_ms += s.ms_total_device
-        dense_ms += s.ms_dense
-        match_ms += s.ms_match
-        rec_ms += s.ms_records
+    _, tot2 = run_steps(args.warmup, args.steps, 2)
+    dense_ms, match_ms, rec_ms, dev_ms = (tot2["ms_dense"], tot2["ms_match"], tot2["ms_records"],
+                                          tot2["ms_total_device"])
     ctx.set_profiling(1)
 
     if dist is not None:
@@ -162,6 +179,8 @@ def main():
                         f"icao_flush + to_mag + demodulate2400 per buffer, {args.buffers} distinct buffers rotated",
             "per_gpu_samples_per_step": n,
             "sharding": "independent stream per GPU, no collectives",
+            "host_api": "blocking adsb_demod_iq_device per step" if args.sync else
+                        "adsb_submit_iq_device / adsb_collect, two passes in flight",
             "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_scan_dense (deferred tiles) -> k_match -> k_records -> host replay",
             "library": "",
         },

@@ -14,6 +14,7 @@ ADSB_ERR_HIP = -3
 ADSB_ERR_TOO_LONG = -4
 ADSB_ERR_CAPACITY = -5
 ADSB_ERR_NOMEM = -6
+ADSB_ERR_BUSY = -7
 
 
 class AdsbMsg(C.Structure):
@@ -86,6 +87,9 @@ def lib() -> C.CDLL:
     L.adsb_demodulate2400.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.adsb_demod_iq.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.adsb_demod_iq_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_submit_iq_device.argtypes = [vp, vp, sz]
+    L.adsb_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.adsb_pending.argtypes = [vp]
     L.adsb_read_test_data.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
     L.adsb_get_stats.argtypes = [vp, C.POINTER(AdsbStats)]
     L.adsb_replay_records.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
@@ -98,7 +102,7 @@ def lib() -> C.CDLL:
     for name in ("adsb_create", "adsb_set_stream", "adsb_set_profiling", "adsb_icao_flush",
                  "adsb_to_mag", "adsb_demodulate2400", "adsb_demod_iq", "adsb_demod_iq_device",
                  "adsb_read_test_data", "adsb_get_stats", "adsb_replay_records",
-                 "adsb_selftest_mag_digest"):
+                 "adsb_selftest_mag_digest", "adsb_submit_iq_device", "adsb_collect", "adsb_pending"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -161,6 +161,22 @@ class Context:
         self._check(st, "adsb_demod_iq_device")
         return n.value
 
+    # -- pipelined form: keep up to two passes in flight, results in submission order
+    def submit_iq_device(self, device_ptr: int, n_samples: int) -> None:
+        self._check(self._L.adsb_submit_iq_device(self._h, C.c_void_p(device_ptr), n_samples),
+                    "adsb_submit_iq_device")
+
+    def collect_raw(self, out_buf, cap: int) -> int:
+        n = C.c_size_t()
+        self._check(self._L.adsb_collect(self._h, out_buf, cap, C.byref(n)), "adsb_collect")
+        return n.value
+
+    def collect(self, cap: int = 1 << 16) -> List[ModeSMessage]:
+        return self._collect(lambda out, c, n: self._L.adsb_collect(self._h, out, c, n), "adsb_collect", cap)
+
+    def pending(self) -> int:
+        return int(self._L.adsb_pending(self._h))
+
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._L.adsb_set_stream(self._h, C.c_void_p(hip_stream)), "adsb_set_stream")
 

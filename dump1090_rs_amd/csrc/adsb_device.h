@@ -107,6 +107,7 @@ struct ScanParams {
     const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
     Summary *summary;
+    uint32_t stagger_ticks; // fast scan: start offset between the workgroups of a CU (clock64 ticks)
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
 };

@@ -21,12 +21,30 @@
 
 using namespace adsb;
 
+// One submission in flight: what was asked, and the pinned host side of its results.
+struct Slot {
+    bool busy = false;
+    bool flush_before = false;  // an icao_flush precedes this pass (host filter flushed at collect)
+    bool from_mag = false;
+    const void *src = nullptr;
+    uint64_t n_samples = 0;
+    uint32_t n_chunks = 0;
+    Summary *h_sum = nullptr;      // pinned
+    TrialRecord *h_rec = nullptr;  // pinned, hits_cap entries
+    hipEvent_t done = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int profiled = 0;  // profiling level the pass was enqueued with
+};
+
+constexpr int kSlots = 2;  // ADSB_MAX_IN_FLIGHT
+
 struct adsb_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int profiling = 1;  // 0: no events, 1: around the scan kernel, 2: around every kernel
-    bool flush_pending = true;  // the bitmap is cleared by the next pass's reset kernel
+    bool flush_pending = true;  // consumed by the next pass: its reset kernel clears the bitmap
+    uint32_t stagger_ticks = 0;
     int debug_stop = 0;  // ADSB_DEBUG_STOP: profiling aid, breaks results when non-zero
     unsigned long long *d_timeline = nullptr;  // ADSB_TIMELINE=1: 8 blocks x 8 tiles x 8 stamps
     size_t max_chunks = 0;
@@ -41,11 +59,10 @@ struct adsb_ctx {
     uint32_t *d_deferred = nullptr;
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0, deferred_cap = 0;
-
     Summary *d_sum = nullptr;
-    Summary *h_sum = nullptr;      // pinned
-    TrialRecord *h_rec = nullptr;  // pinned, hits_cap entries
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    Slot slot[kSlots];
+    uint64_t submitted = 0, collected = 0;
 
     IcaoFilter filter;
     Crc24 crc;
@@ -110,10 +127,10 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
     }
 }
 
-// One device pass over n_chunks chunks starting at d_src.  Returns 1 when a device
-// list overflowed (caller retries in smaller pieces), 0 on success, <0 on error.
-int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, uint32_t n_chunks,
-              uint64_t chunk_offset, std::vector<adsb_msg> &out)
+// Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
+// reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
+int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
+                 uint32_t n_chunks)
 {
     ScanParams p{};
     p.src = d_src;
@@ -131,86 +148,172 @@ int run_batch(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples,
     p.tables = c->d_tables;
     p.ctr = c->d_ctr;
     p.summary = c->d_sum;
+    p.stagger_ticks = c->stagger_ticks;
     p.debug_stop = c->debug_stop;
     p.timeline = c->d_timeline;
+
+    sl.src = d_src;
+    sl.from_mag = from_mag;
+    sl.n_samples = n_samples;
+    sl.n_chunks = n_chunks;
+    sl.flush_before = c->flush_pending;
+    sl.profiled = c->profiling;
+    const int prof = sl.profiled;
 
     if (int e = launch_reset(c->d_ctr, c->flush_pending ? c->d_bitmap : nullptr, c->stream))
         return fail(c, (hipError_t)e, "launch_reset");
     c->flush_pending = false;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (prof) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (prof) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
     if (!from_mag)  // tiles the fast scan deferred (normally none; the kernel then exits at once)
         if (int e = launch_dense(p, c->stream)) return fail(c, (hipError_t)e, "launch_dense");
-    if (c->profiling > 1) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], c->stream));
     if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
-    if (c->profiling > 1) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], c->stream));
     if (int e = launch_records(p, from_mag, c->d_rec, c->stream))
         return fail(c, (hipError_t)e, "launch_records");
-    if (c->profiling > 1) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], c->stream));
     // one round trip: the summary and the first kInlineRecords records come back together
-    HIP_TRY(c, hipMemcpyAsync(c->h_sum, c->d_sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_rec, c->d_rec, kInlineRecords * sizeof(TrialRecord),
+    HIP_TRY(c, hipMemcpyAsync(sl.h_sum, c->d_sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sl.h_rec, c->d_rec, kInlineRecords * sizeof(TrialRecord),
                               hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventRecord(sl.done, c->stream));
+    return ADSB_OK;
+}
 
-    if (c->h_sum->overflow) return 1;
-    const size_t n = c->h_sum->n_hits;
+// Wait for the pass in `sl` and replay it.  Returns 1 when a device list overflowed
+// (caller re-runs in smaller pieces), 0 on success, < 0 on error.
+int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out)
+{
+    HIP_TRY(c, hipEventSynchronize(sl.done));
+    if (sl.h_sum->overflow) return 1;
+    const size_t n = sl.h_sum->n_hits;
     if (n > kInlineRecords) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_rec + kInlineRecords, c->d_rec + kInlineRecords,
+        // more records than came back with the summary; the device copy is still intact
+        // unless a later pass has run, so a pipelined caller keeps passes below this size
+        HIP_TRY(c, hipMemcpyAsync(sl.h_rec + kInlineRecords, c->d_rec + kInlineRecords,
                                   (n - kInlineRecords) * sizeof(TrialRecord), hipMemcpyDeviceToHost,
                                   c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (c->profiling) {
+    if (sl.profiled) {
         float ms = 0;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        c->stats.ms_scan += ms;
-        if (c->profiling > 1) {  // per-kernel split of the tail (costs a few us per pass)
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-            c->stats.ms_dense += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-            c->stats.ms_match += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-            c->stats.ms_records += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
-            c->stats.ms_total_device += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
+        st.ms_scan += ms;
+        if (sl.profiled > 1) {  // per-kernel split of the tail (events cost a few us each)
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
+            st.ms_dense += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
+            st.ms_match += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]));
+            st.ms_records += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[4]));
+            st.ms_total_device += ms;
         }
     }
-    c->stats.n_candidates += c->h_sum->n_cand_total;
-    c->stats.n_ap_entries += c->h_sum->n_ap_total;
-    c->stats.n_deferred += c->h_sum->n_deferred;
-    c->stats.n_records += n;
-    replay(c->filter, c->crc, c->h_rec, n, chunk_offset, out);
+    st.n_candidates += sl.h_sum->n_cand_total;
+    st.n_ap_entries += sl.h_sum->n_ap_total;
+    st.n_deferred += sl.h_sum->n_deferred;
+    st.n_records += n;
+    replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out);
     return 0;
+}
+
+// Finish the oldest submission: replay it, or -- when a device list overflowed (far
+// denser input than the lists were sized for) -- drain the stream and go chunk by
+// chunk, where the worst case always fits.  Bitmap bits set by the aborted pass or by
+// later passes are a harmless superset in time.
+int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
+{
+    Slot &sl = c->slot[c->collected % kSlots];
+    adsb_stats st{};
+    st.n_samples = sl.n_samples;
+    st.n_chunks = sl.n_chunks;
+    if (sl.flush_before) c->filter.flush();  // icao_flush() took effect before this pass
+    int rc = finish_pass(c, sl, 0, st, out);
+    if (rc > 0 && !sl.from_mag && sl.n_chunks > 1) {
+        st.retries++;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // later passes have their results on the host
+        const bool keep_flush = c->flush_pending;
+        c->flush_pending = false;
+        Slot tmp = sl;  // same host buffers and events, one chunk at a time
+        rc = 0;
+        for (uint64_t ch = 0; ch < sl.n_chunks && rc == 0; ch++) {
+            const uint64_t off = ch * kChunkSamples;
+            const uint64_t n = std::min<uint64_t>(kChunkSamples, sl.n_samples - off);
+            rc = enqueue_pass(c, tmp, (const uint32_t *)sl.src + off, false, n, 1);
+            if (rc == 0) rc = finish_pass(c, tmp, ch, st, out);
+        }
+        c->flush_pending = keep_flush;
+    }
+    sl.busy = false;
+    c->collected++;
+    if (rc > 0) {
+        c->last_error = "device lists overflowed on a single chunk";
+        return ADSB_ERR_HIP;
+    }
+    if (rc < 0) return rc;
+    c->stats = st;
+    return ADSB_OK;
+}
+
+int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples)
+{
+    const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
+    if (n_chunks == 0 || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+    Slot &sl = c->slot[c->submitted % kSlots];
+    if (sl.busy) return ADSB_ERR_BUSY;
+    int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks);
+    if (rc) return rc;
+    sl.busy = true;
+    c->submitted++;
+    return ADSB_OK;
+}
+
+// synchronous pass: everything pending is finished first, in order
+int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out)
+{
+    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
+    int rc = submit(c, d_src, from_mag, n_samples);
+    if (rc) return rc;
+    return collect_oldest(c, out);
 }
 
 // IQ stream of any length resident on the device.
 int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<adsb_msg> &out)
 {
-    c->stats = adsb_stats{};
-    c->stats.n_samples = n_samples;
-    const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
-    c->stats.n_chunks = n_chunks;
-    if (n_chunks == 0) return ADSB_OK;
-    if (n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
-
-    int rc = run_batch(c, d_iq, false, n_samples, (uint32_t)n_chunks, 0, out);
-    if (rc <= 0) return rc;
-    // A device list overflowed (far denser input than the lists were sized for):
-    // go chunk by chunk, where the worst case always fits.  The bitmap bits the
-    // aborted pass set are a harmless superset.  `out` is still empty here.
-    c->stats.retries++;
-    for (uint64_t ch = 0; ch < n_chunks; ch++) {
-        const uint64_t off = ch * kChunkSamples;
-        const uint64_t n = std::min<uint64_t>(kChunkSamples, n_samples - off);
-        rc = run_batch(c, (const uint32_t *)d_iq + off, false, n, 1, ch, out);
-        if (rc > 0) {
-            c->last_error = "device lists overflowed on a single chunk";
-            return ADSB_ERR_HIP;
-        }
-        if (rc < 0) return rc;
+    if (n_samples == 0) {
+        c->stats = adsb_stats{};
+        return ADSB_OK;
     }
+    adsb_stats total{};
+    // device passes are limited to kMaxChunks chunks (entry packing): longer streams go in pieces
+    const uint64_t piece = kMaxChunks * (uint64_t)kChunkSamples;
+    for (uint64_t off = 0; off < n_samples; off += piece) {
+        const uint64_t n = std::min<uint64_t>(piece, n_samples - off);
+        std::vector<adsb_msg> part;
+        int rc = run_sync(c, (const uint32_t *)d_iq + off, false, n, part);
+        if (rc) return rc;
+        const uint64_t chunk0 = off / kChunkSamples;
+        for (auto &m : part) {
+            m.chunk += chunk0;
+            out.push_back(m);
+        }
+        total.n_chunks += c->stats.n_chunks;
+        total.n_candidates += c->stats.n_candidates;
+        total.n_ap_entries += c->stats.n_ap_entries;
+        total.n_records += c->stats.n_records;
+        total.ms_scan += c->stats.ms_scan;
+        total.ms_dense += c->stats.ms_dense;
+        total.ms_match += c->stats.ms_match;
+        total.ms_records += c->stats.ms_records;
+        total.ms_total_device += c->stats.ms_total_device;
+        total.retries += c->stats.retries;
+        total.n_deferred += c->stats.n_deferred;
+    }
+    total.n_samples = n_samples;
+    c->stats = total;
     return ADSB_OK;
 }
 
@@ -254,6 +357,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     c->device = device;
     c->max_chunks = max_chunks;
     if (const char *ds = std::getenv("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
+    if (const char *st = std::getenv("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
     // lists sized for ~5x the rate pure noise produces (2.3 % of samples become
     // address/parity entries); denser input falls back to per-chunk passes
     // Fast-scan AP list: kApSegments private segments, sized for ~5x the rate pure noise
@@ -290,11 +394,14 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                                  hipMemcpyHostToDevice));
         }
         HIP_TRY(c, hipMalloc((void **)&c->d_sum, sizeof(Summary)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_sum, sizeof(Summary), hipHostMallocDefault));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
-                                 hipHostMallocDefault));
-        // timing-only events: no system-scope fence when they complete (that fence costs ~10 us each)
-        for (auto &e : c->ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+        for (Slot &sl : c->slot) {
+            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocDefault));
+            HIP_TRY(c, hipHostMalloc((void **)&sl.h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
+                                     hipHostMallocDefault));
+            // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
+            for (auto &e : sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+            HIP_TRY(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
         if (std::getenv("ADSB_TIMELINE")) {
             HIP_TRY(c, hipMalloc((void **)&c->d_timeline, 512 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemset(c->d_timeline, 0, 512 * sizeof(unsigned long long)));
@@ -317,8 +424,13 @@ void adsb_destroy(adsb_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    for (auto &e : c->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (Slot &sl : c->slot) {
+        for (auto &e : sl.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.h_sum) (void)hipHostFree(sl.h_sum);
+        if (sl.h_rec) (void)hipHostFree(sl.h_rec);
+    }
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_mag) (void)hipFree(c->d_mag);
     if (c->d_bitmap) (void)hipFree(c->d_bitmap);
@@ -345,8 +457,6 @@ void adsb_destroy(adsb_ctx *c)
         (void)hipFree(c->d_timeline);
     }
     if (c->d_sum) (void)hipFree(c->d_sum);
-    if (c->h_sum) (void)hipHostFree(c->h_sum);
-    if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -354,6 +464,7 @@ void adsb_destroy(adsb_ctx *c)
 int adsb_set_stream(adsb_ctx *c, void *hip_stream)
 {
     if (!c) return ADSB_ERR_INVALID;
+    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return ADSB_OK;
@@ -370,8 +481,10 @@ int adsb_icao_flush(adsb_ctx *c)
 {
     if (!c) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    c->filter.flush();
-    c->flush_pending = true;  // stream-ordered: done by the next pass's reset kernel
+    // Takes effect for everything submitted after this call: the next pass's reset kernel
+    // clears the device bitmap (stream-ordered), and the host filter is flushed when that
+    // pass is collected, after the passes before it have been replayed.
+    c->flush_pending = true;
     return ADSB_OK;
 }
 
@@ -398,6 +511,7 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
     if (!c || !data || (!out && cap)) return ADSB_ERR_INVALID;
     if (length > kChunkSamples) return ADSB_ERR_TOO_LONG;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
     c->stats = adsb_stats{};
     c->stats.n_samples = length;
     c->stats.n_chunks = 1;
@@ -405,12 +519,8 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
     if (length) {
         HIP_TRY(c, hipMemcpyAsync(c->d_mag, data, kMagDataLen * sizeof(uint16_t),
                                   hipMemcpyHostToDevice, c->stream));
-        int rc = run_batch(c, c->d_mag, true, length, 1, 0, msgs);
-        if (rc > 0) {
-            c->last_error = "device lists overflowed on a single chunk";
-            return ADSB_ERR_HIP;
-        }
-        if (rc < 0) return rc;
+        int rc = run_sync(c, c->d_mag, true, length, msgs);
+        if (rc) return rc;
     }
     return deliver(c, msgs, out, cap, n_out);
 }
@@ -426,6 +536,28 @@ int adsb_demod_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples, adsb_m
     if (rc) return rc;
     return deliver(c, msgs, out, cap, n_out);
 }
+
+int adsb_submit_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples)
+{
+    if (!c || !d_iq || n_samples == 0) return ADSB_ERR_INVALID;
+    if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
+    if ((n_samples + kChunkSamples - 1) / kChunkSamples > kMaxChunks) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return submit(c, d_iq, false, n_samples);
+}
+
+int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
+{
+    if (!c || (!out && cap)) return ADSB_ERR_INVALID;
+    if (c->submitted == c->collected) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<adsb_msg> msgs;
+    int rc = collect_oldest(c, msgs);
+    if (rc) return rc;
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->collected) : 0; }
 
 int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *out, size_t cap,
                   size_t *n_out)
@@ -537,6 +669,7 @@ const char *adsb_strerror(int status)
     case ADSB_ERR_TOO_LONG: return "more than 131072 samples for a single MagnitudeBuffer";
     case ADSB_ERR_CAPACITY: return "output array too small";
     case ADSB_ERR_NOMEM: return "out of memory";
+    case ADSB_ERR_BUSY: return "submissions are pending (collect them first) or too many are in flight";
     default: return "unknown status";
     }
 }

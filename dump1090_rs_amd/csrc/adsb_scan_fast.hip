@@ -50,12 +50,17 @@ namespace {
 
 using namespace fastgeo;
 
-constexpr int kThreads = 256;
+#ifndef ADSB_SCAN_THREADS
+#define ADSB_SCAN_THREADS 512
+#endif
+constexpr int kThreads = ADSB_SCAN_THREADS;   // 512: 8 waves per workgroup, 8 per SIMD at 4 workgroups per CU
+constexpr int kWavesPerSimd = kThreads == 512 ? 8 : 4;
+constexpr int kResPerItem = kThreads == 512 ? 2 : 4;  // residues one P2 lane walks
 constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
 constexpr int kPlaneLT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
 constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..107: GT 0..23
 constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
-constexpr int kItems2 = 3 * kPlaneBytes;      // 252 P2 items: (residue group, plane byte)
+constexpr int kItems2 = (12 / kResPerItem) * kPlaneBytes;  // P2 items: (residue group, plane byte)
 constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
 static_assert(kItems2 <= kThreads && kItems3 <= kThreads, "one item per thread");
 static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
@@ -185,7 +190,7 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
 // after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
-__global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
     const int tid = threadIdx.x;
@@ -209,6 +214,15 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
 
     uint4 pre[kLoadsPerThread];
     if (blockIdx.x < n_tiles) load_tile_iq(p, tile_ref(p, blockIdx.x), tid, pre);
+
+    // Workgroups that share a CU start a fraction of a tile period apart, so that the
+    // VALU-dense phases of one overlap the latency-bound phases of the others instead of
+    // all of them marching through the same phase together.
+    if (p.stagger_ticks) {
+        const uint32_t k = (blockIdx.x * 4u) / gridDim.x;  // 0..3: which quarter of the grid
+        const unsigned long long until = clock64() + (unsigned long long)k * p.stagger_ticks;
+        while ((unsigned long long)clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
 
     uint32_t iter = 0;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x, iter++) {
@@ -244,64 +258,55 @@ __global__ __launch_bounds__(kThreads) void k_scan_fast(ScanParams p)
     // 12k + 4g + {0..3} (+3 of look-ahead).  Bit k of plane (kind, r) is the sign taken
     // at sample 12k + r.  Walking k downwards leaves bit (k & 7) of the byte = k.
     if (tid < kItems2) {
-        const int g = tid % 3, kw = tid / 3;
-        const uint16_t *base = s.mag + 96 * kw + 4 * g;
-        uint32_t acc[7][4];
+        constexpr int R = kResPerItem, G = 12 / R;
+        const int g = tid % G, kw = tid / G;
+        const uint16_t *base = s.mag + 96 * kw + R * g;  // 4-byte aligned (R even)
+        uint32_t acc[7][R];
 #pragma unroll
         for (int q = 0; q < 7; q++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[q][r] = 0;
-        {   // one plane bit beyond the byte (k = 8kw + 8) for LT/GT only: it completes the
-            // "advanced by one bit" copies that P3 addresses as residues 12..23
-            const uint2 lo = *(const uint2 *)(base + 12 * 8);
-            const uint32_t hi = *(const uint32_t *)(base + 12 * 8 + 4);
-            const int m0 = (int)(lo.x & 0xFFFFu), m1 = (int)(lo.x >> 16), m2 = (int)(lo.y & 0xFFFFu),
-                      m3 = (int)(lo.y >> 16), m4 = (int)(hi & 0xFFFFu);
-            const int e8[4] = {m1 - m0, m2 - m1, m3 - m2, m4 - m3};
+            for (int r = 0; r < R; r++) acc[q][r] = 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                acc[5][r] = push_sign(0u, -e8[r]);
-                acc[6][r] = push_sign(0u, e8[r]);
+        for (int kk = 8; kk >= 0; --kk) {
+            // m[0 .. R+2]: the R samples of this lane and three of look-ahead, as dwords
+            const uint32_t *src = (const uint32_t *)(base + 12 * kk);
+            int m[R + 4];
+#pragma unroll
+            for (int d = 0; d < (R + 4) / 2; d++) {
+                const uint32_t w = src[d];
+                m[2 * d] = (int)(w & 0xFFFFu);
+                m[2 * d + 1] = (int)(w >> 16);
             }
-        }
+            int e[R + 2];  // first differences m[s+1] - m[s]
 #pragma unroll
-        for (int kk = 7; kk >= 0; --kk) {
-            const uint2 lo = *(const uint2 *)(base + 12 * kk);      // m0..m3
-            const uint2 hi = *(const uint2 *)(base + 12 * kk + 4);  // m4..m7
-            int m[7];
-            m[0] = (int)(lo.x & 0xFFFFu);
-            m[1] = (int)(lo.x >> 16);
-            m[2] = (int)(lo.y & 0xFFFFu);
-            m[3] = (int)(lo.y >> 16);
-            m[4] = (int)(hi.x & 0xFFFFu);
-            m[5] = (int)(hi.x >> 16);
-            m[6] = (int)(hi.y & 0xFFFFu);
-            int e[6];  // first differences m[s+1] - m[s]
+            for (int i = 0; i < R + 2; i++) e[i] = m[i + 1] - m[i];
 #pragma unroll
-            for (int i = 0; i < 6; i++) e[i] = m[i + 1] - m[i];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                // slicer value D(ph) at this sample (demod_2400.rs:72-83), negated so that
-                // "D > 0" is the sign bit:  with a = m0-m1 = -e0, b = m1-m2 = -e1, c = m2-m3:
-                //   D0 = 5a+2b  D1 = 4a+3b  D2 = 3a+4b  D3 = 2a+5b  D4 = a+6b+c
+            for (int r = 0; r < R; r++) {
                 const int ea = e[r], eb = e[r + 1], ec = e[r + 2];
-                const int n0 = __mul24(ea, 5) + (eb + eb);
-                const int u = eb - ea;
-                const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
-                const int n4 = __mul24(eb, 6) + (ea + ec);
-                acc[0][r] = push_sign(acc[0][r], n0);
-                acc[1][r] = push_sign(acc[1][r], n1);
-                acc[2][r] = push_sign(acc[2][r], n2);
-                acc[3][r] = push_sign(acc[3][r], n3);
-                acc[4][r] = push_sign(acc[4][r], n4);
+                if (kk < 8) {
+                    // slicer value D(ph) at this sample (demod_2400.rs:72-83), negated so that
+                    // "D > 0" is the sign bit: with a = m0-m1 = -e0, b = m1-m2 = -e1, c = m2-m3:
+                    //   D0 = 5a+2b  D1 = 4a+3b  D2 = 3a+4b  D3 = 2a+5b  D4 = a+6b+c
+                    const int n0 = __mul24(ea, 5) + (eb + eb);
+                    const int u = eb - ea;
+                    const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
+                    const int n4 = __mul24(eb, 6) + (ea + ec);
+                    acc[0][r] = push_sign(acc[0][r], n0);
+                    acc[1][r] = push_sign(acc[1][r], n1);
+                    acc[2][r] = push_sign(acc[2][r], n2);
+                    acc[3][r] = push_sign(acc[3][r], n3);
+                    acc[4][r] = push_sign(acc[4][r], n4);
+                }
+                // kk == 8 is one plane bit beyond the byte, for LT/GT only: it completes the
+                // "advanced by one bit" copies that P3 addresses as residues 12..23
                 acc[5][r] = push_sign(acc[5][r], -ea);  // LT: m[s] < m[s+1]
                 acc[6][r] = push_sign(acc[6][r], ea);   // GT: m[s] > m[s+1]
             }
         }
         uint8_t *pb = (uint8_t *)s.plane;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int res = 4 * g + r;
+        for (int r = 0; r < R; r++) {
+            const int res = R * g + r;
 #pragma unroll
             for (int q = 0; q < 5; q++) pb[(q * 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[q][r];
             // 9 bits: k = 8kw .. 8kw+8.  Residue res holds bits 0..7, residue res+12 (the

@@ -53,8 +53,11 @@ typedef enum {
                                 the reference panics here (src/lib.rs:48) */
     ADSB_ERR_CAPACITY = -5,  /* `out` too small; *n_out holds the required count and the
                                 first `cap` messages were written */
-    ADSB_ERR_NOMEM = -6
+    ADSB_ERR_NOMEM = -6,
+    ADSB_ERR_BUSY = -7       /* submissions pending where none are allowed, or too many in flight */
 } adsb_status;
+
+#define ADSB_MAX_IN_FLIGHT 2
 
 typedef struct adsb_ctx adsb_ctx;
 
@@ -102,7 +105,8 @@ int adsb_set_stream(adsb_ctx *ctx, void *hip_stream);
  * stream several microseconds, so level 2 slows a call down noticeably). */
 int adsb_set_profiling(adsb_ctx *ctx, int level);
 
-/* == icao_filter::icao_flush() (src/icao_filter.rs:11-17) for this context. */
+/* == icao_filter::icao_flush() (src/icao_filter.rs:11-17) for this context.  Stream-ordered:
+ * costs nothing until the next demod call, whose first kernel clears the device side. */
 int adsb_icao_flush(adsb_ctx *ctx);
 
 /* == utils::to_mag (src/utils.rs:43-58).  iq_re_im is the in-memory
@@ -128,6 +132,17 @@ int adsb_demod_iq(adsb_ctx *ctx, const int16_t *iq_re_im, size_t n_samples, adsb
 /* Same, the IQ already resident in device memory (16-byte aligned). */
 int adsb_demod_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples,
                          adsb_msg *out, size_t cap, size_t *n_out);
+
+/* Asynchronous form of adsb_demod_iq_device for a host that keeps the GPU fed: enqueue one
+ * pass (kernels + result copy) and return at once; at most ADSB_MAX_IN_FLIGHT passes may
+ * be pending.  adsb_collect waits for the OLDEST pending pass, replays it through the
+ * filter and returns its messages, so results come back in submission order and the
+ * host replay of pass i overlaps the device scan of pass i+1.  adsb_icao_flush applies
+ * to the passes submitted after it.  The synchronous calls return ADSB_ERR_BUSY while
+ * anything is pending.  device_iq must stay valid and unchanged until its collect. */
+int adsb_submit_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples);
+int adsb_collect(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
+int adsb_pending(const adsb_ctx *ctx);
 
 /* src/utils.rs:23-40 read_test_data: file pairs are [im][re] little-endian;
  * writes in-memory {re, im}.  Returns samples read via *n_out. */

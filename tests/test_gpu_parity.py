@@ -272,3 +272,54 @@ def test_list_overflow_falls_back_and_stays_exact(hip_lib, oracle_mod):
     with Context(0, 1) as c:
         c.icao_flush()
         assert_same(c.demod_iq(iq), want)
+
+
+# ----------------------------------------------------------------------------- pipelined API
+def test_submit_collect_matches_blocking_calls_and_orders_flushes(ctx, oracle_mod):
+    """adsb_submit_iq_device / adsb_collect: two passes in flight, results in submission
+    order, icao_flush taking effect exactly between the passes it was called between."""
+    import torch
+    from dump1090_rs_amd._lib import AdsbError, ADSB_ERR_BUSY
+    n = 8 * 131072
+    icao = 0x4840D6
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")   # scores only once icao is known
+    host = [synth.noise_numpy(n, seed=500 + k) for k in range(3)]
+    synth.add_bursts(host[0], [synth.Burst(5 * (100000 * k + 777) + k, 21000, k, synth.df17_frame(icao, k))
+                               for k in range(1, 9)])
+    synth.add_bursts(host[1], [synth.Burst(5 * (90000 * k + 333) + k, 21000, k, df4) for k in range(1, 9)])
+    synth.add_bursts(host[2], [synth.Burst(5 * (80000 * k + 555) + k, 21000, k, df4) for k in range(1, 9)])
+    bufs = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    # schedule: flush, A, B, flush, C, A   (B sees A's address, C starts clean, the 2nd A knows it)
+    orc = oracle_mod.Oracle()
+    want = []
+    for k, flush in ((0, True), (1, False), (2, True), (0, False)):
+        if flush:
+            orc.icao_flush()
+        want.append(orc.demod_iq(host[k])[0])
+    # the DF4s decode only while the address is in the filter: B after A yes, C after the flush no
+    assert sum(w["buffer"] == df4 for w in want[1]) >= 6 and want[2] == [] and len(want[0]) >= 8
+
+    got = []
+    ctx.icao_flush()
+    ctx.submit_iq_device(bufs[0].data_ptr(), n)
+    ctx.submit_iq_device(bufs[1].data_ptr(), n)
+    assert ctx.pending() == 2
+    with pytest.raises(AdsbError) as ei:                      # a third one does not fit
+        ctx.submit_iq_device(bufs[2].data_ptr(), n)
+    assert ei.value.status == ADSB_ERR_BUSY
+    with pytest.raises(AdsbError):                            # blocking calls refuse while pending
+        ctx.demod_iq_device(bufs[2].data_ptr(), n)
+    got.append(ctx.collect())
+    ctx.icao_flush()
+    ctx.submit_iq_device(bufs[2].data_ptr(), n)
+    got.append(ctx.collect())
+    ctx.submit_iq_device(bufs[0].data_ptr(), n)
+    got.append(ctx.collect())
+    got.append(ctx.collect())
+    assert ctx.pending() == 0
+    for g, w in zip(got, want):
+        assert_same(g, w)
+    with pytest.raises(AdsbError):
+        ctx.collect()                                         # nothing pending
