@@ -51,9 +51,9 @@ namespace {
 using namespace fastgeo;
 
 #ifndef ADSB_SCAN_THREADS
-#define ADSB_SCAN_THREADS 512
+#define ADSB_SCAN_THREADS 256
 #endif
-constexpr int kThreads = ADSB_SCAN_THREADS;   // 512: 8 waves per workgroup, 8 per SIMD at 4 workgroups per CU
+constexpr int kThreads = ADSB_SCAN_THREADS;   // 256 (512 was measured: 7 % slower)
 constexpr int kWavesPerSimd = kThreads == 512 ? 8 : 4;
 constexpr int kResPerItem = kThreads == 512 ? 2 : 4;  // residues one P2 lane walks
 constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
@@ -62,10 +62,13 @@ constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..
 constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
 constexpr int kItems2 = (12 / kResPerItem) * kPlaneBytes;  // P2 items: (residue group, plane byte)
 constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
-static_assert(kItems2 <= kThreads && kItems3 <= kThreads, "one item per thread");
+static_assert(kItems2 <= kThreads && kItems3 <= 256, "one item per thread");
 static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
-constexpr int kPatCap = 1024;                 // positions matching a preamble pattern
-constexpr int kCandCap = 512;                 // positions passing every gate
+constexpr int kWaves = kThreads / 64;
+constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
+constexpr int kRoundBits = 4;                 // plane bits per round when they do not fit: 64 x 4 <= 256
+constexpr int kCandPerWave = 128;             // a wave's candidates waiting for the trial stage
+static_assert(64 * kRoundBits <= kPatPerWave && kCandPerWave >= 128, "wave-private regions");
 constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
@@ -74,6 +77,14 @@ constexpr int kHitCap = 32;                   // staged hits per tile (more go s
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Order this wave's own LDS traffic: writes before, reads after.  LDS operations of one
+// wave complete in order, so draining lgkmcnt is all it takes; "memory" keeps the
+// compiler from moving LDS accesses across.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
@@ -112,15 +123,6 @@ __device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped
     return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
 }
 
-__device__ __forceinline__ void defer_tile(const ScanParams &p, uint32_t chunk, int tile)
-{
-    const uint32_t d = atomicAdd(&p.ctr->n_deferred, 1u);
-    if (d < p.deferred_cap)
-        p.deferred[d] = (chunk << 8) | (uint32_t)tile;
-    else
-        atomicOr(&p.ctr->overflow, 4u);
-}
-
 // Which magnitudes enter high / base_signal / base_noise for each of check_preamble's five
 // branches (src/demod_2400.rs:227-317), one bit per term:
 //   high  = (p1 + p12 + A*(p3+p9) + B*p11 + C*(p4+p10) + D*p2) / 4
@@ -134,10 +136,10 @@ struct alignas(16) FastLds {
     uint32_t tab[6 * 256];             // F0 F1 F2 X51_0 X51_1 X51_2
     uint32_t r16[16];                  // x^24..x^27 reduction
     uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
-    uint32_t pat[kPatCap];             // slot | branch terms << 13
-    uint32_t cand[kCandCap];           // slot | slot/12 << 13 | slot%12 << 23
+    uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch terms << 13
+    uint32_t cand[kWaves * kCandPerWave];  // per wave: slot | slot/12 << 13 | slot%12 << 23
     uint64_t hit[kHitCap];
-    uint32_t npat, ncand, nap, nhit, hit_base;
+    uint32_t nap, nhit, hit_base;
 };
 
 // IQ of one tile, as each thread holds it between the load and the magnitude pass:
@@ -229,12 +231,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
     const TileRef cur = tile_ref(p, t);
     STAMP(0);
     const uint32_t chunk = cur.chunk;
-    const int tile = cur.tile, len = cur.len, jbase = cur.jbase;
+    const int len = cur.len, jbase = cur.jbase;
     const int jn = min(kTile, len - jbase);  // <= 0 for tiles past the end of a short chunk
 
     if (tid == 0) {
-        s.npat = 0;
-        s.ncand = 0;
         s.nap = 0;
         s.nhit = 0;
     }
@@ -268,14 +268,31 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
             for (int r = 0; r < R; r++) acc[q][r] = 0;
 #pragma unroll
         for (int kk = 8; kk >= 0; --kk) {
-            // m[0 .. R+2]: the R samples of this lane and three of look-ahead, as dwords
-            const uint32_t *src = (const uint32_t *)(base + 12 * kk);
+            // m[0 .. R+2]: the R samples of this lane and three of look-ahead.  Explicit
+            // 8-byte reads (the address is 8-byte aligned, no more): left to itself the
+            // compiler merges dword reads into one 16-byte read, and an LDS access off its
+            // natural alignment is replayed at 64 cycles (SQ_LDS_UNALIGNED_STALL).
             int m[R + 4];
+            if constexpr (R == 4) {
+                const uint2 lo = *(const uint2 *)(base + 12 * kk);
+                const uint2 hi = *(const uint2 *)(base + 12 * kk + 4);
+                m[0] = (int)(lo.x & 0xFFFFu);
+                m[1] = (int)(lo.x >> 16);
+                m[2] = (int)(lo.y & 0xFFFFu);
+                m[3] = (int)(lo.y >> 16);
+                m[4] = (int)(hi.x & 0xFFFFu);
+                m[5] = (int)(hi.x >> 16);
+                m[6] = (int)(hi.y & 0xFFFFu);
+                m[7] = (int)(hi.y >> 16);
+            } else {  // R == 2: 4-byte aligned, three separate dword reads
+                typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+                lds_u32_ptr src = (lds_u32_ptr)(base + 12 * kk);
 #pragma unroll
-            for (int d = 0; d < (R + 4) / 2; d++) {
-                const uint32_t w = src[d];
-                m[2 * d] = (int)(w & 0xFFFFu);
-                m[2 * d + 1] = (int)(w >> 16);
+                for (int d = 0; d < 3; d++) {
+                    const uint32_t w = src[d];
+                    m[2 * d] = (int)(w & 0xFFFFu);
+                    m[2 * d + 1] = (int)(w >> 16);
+                }
             }
             int e[R + 2];  // first differences m[s+1] - m[s]
 #pragma unroll
@@ -321,11 +338,27 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
     STAMP(2);
     if (p.debug_stop == 2) continue;
 
+    // ================================================================ P3..P5, wave-private
+    // From here to the end of the tile every wave works alone on the positions of its own
+    // P3 items: matches, candidates and trials stay in the wave's own LDS regions, so there
+    // is no workgroup barrier and no shared counter between the stages, the waves of a
+    // workgroup drift apart, and their latency-bound stages overlap the VALU-dense ones of
+    // the others.  Nothing here can overflow: a wave with more matches than its region
+    // holds takes them in rounds of a few plane bits, and candidates are flushed through
+    // the trial stage whenever their region fills.
+    {
+    const int wave = tid >> 6;
+    uint32_t *const wpat = s.pat + wave * kPatPerWave;
+    uint32_t *const wcand = s.cand + wave * kCandPerWave;
+
     // ---------------------------------------------------------------- P3 preamble patterns
     // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
+    // (with 512 threads an item is half a dword, so that all eight waves own positions)
+    constexpr int kHalves = kThreads / 256;
     uint32_t b[5] = {0u, 0u, 0u, 0u, 0u};
-    const int pres = tid % 12, pw = tid / 12;
-    if (tid < kItems3) {
+    const int ptid = tid % 256, phalf = tid / 256;
+    const int pres = ptid % 12, pw = ptid / 12;
+    if (ptid < kItems3) {
         const int res = pres, w = pw;
         const uint32_t *LT = s.plane + (kPlaneLT + res) * kPlaneDw + w;
         const uint32_t *GT = s.plane + (kPlaneGT + res) * kPlaneDw + w;
@@ -334,6 +367,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
         // positions that are real j of this tile: kPad <= slot < kPad + jn
         const int kmin = (kPad - res + 11) / 12, kmax = (kPad + jn - res + 11) / 12;
         uint32_t ok = lowmask(kmax - 32 * w) & ~lowmask(kmin - 32 * w);
+        if (kHalves == 2) ok &= phalf ? 0xFFFF0000u : 0x0000FFFFu;
         ok &= LTO(0) & GTO(12);                               // demod_2400.rs:221
         const uint32_t A = GTO(1) & LTO(2);                   // p1>p2 p2<p3
         const uint32_t C = LTO(8) & GTO(9);                   // p8<p9 p9>p10
@@ -351,55 +385,64 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
         b[3] = b4;
         b[4] = b5;
     }
-    {
-        // compaction: wave-wide exclusive scan of the per-lane match counts (DPP, no LDS),
-        // one LDS atomic per wave for the wave's range, then every lane writes its own
-        const uint32_t any = b[0] | b[1] | b[2] | b[3] | b[4];
-        const uint32_t cnt = (uint32_t)__popc(any);
-        const uint32_t incl = wave_inclusive_scan(cnt);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total) {  // wave-uniform
-            uint32_t wave_base = 0;
-            if (lane == 0) wave_base = atomicAdd(&s.npat, total);
-            uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base) + incl - cnt;
-            const uint32_t slot0 = (uint32_t)(12 * 32 * pw + pres);
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                uint32_t m = b[k];
-                while (m) {
-                    const int bit = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (at < (uint32_t)kPatCap) s.pat[at] = (slot0 + 12u * (uint32_t)bit) | (kBranchTerms[k] << 13);
-                    at++;
-                }
-            }
-        }
-    }
-    lds_barrier();
-    STAMP(3);
-    if (p.debug_stop == 3) {
-        lds_barrier();
-        continue;
-    }
-    if (s.npat > (uint32_t)kPatCap) {  // far denser than any real signal: simple kernel
-        if (tid == 0) defer_tile(p, chunk, tile);
-        lds_barrier();
-        continue;
-    }
+    const uint32_t slot0 = (uint32_t)(12 * 32 * pw + pres);
+    const uint32_t any_all = b[0] | b[1] | b[2] | b[3] | b[4];
+    const uint32_t total_all =
+        (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)__popc(any_all)), 63);
+    // all matches in one round when they fit the wave's region (the normal case: ~90 of
+    // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
+    const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
+    uint32_t ncand_w = 0;  // candidates waiting in wcand (wave-uniform)
 
-    // ---------------------------------------------------------------- P4 value gates
-    // one lane per pattern match: high / base_signal / base_noise of the branch that
-    // matched first (:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
-    {
-        const int npat = (int)s.npat;
-        for (int base = 0; base < npat; base += kThreads) {
-            const int idx = base + tid;
+    // One loop, one copy of each stage: take the next round of matches when the previous one
+    // is used up, run one 64-lane pass of the gates, and run the trials whenever the
+    // candidate region could not take another pass's worth (or nothing else is left).
+    int round = 0;
+    uint32_t npat_w = 0, base = 0;
+    bool in_round = false;
+    for (;;) {
+        if (round < nrounds) {
+            if (!in_round) {
+                // ---- compaction of this round's matches into wpat: exclusive scan of the lane
+                // counts (DPP, no LDS traffic), then every lane writes its own
+                const uint32_t rmask = nrounds == 1 ? 0xFFFFFFFFu
+                                                    : (((1u << kRoundBits) - 1u) << (round * kRoundBits));
+                const uint32_t cnt = (uint32_t)__popc(any_all & rmask);
+                const uint32_t incl = wave_inclusive_scan(cnt);
+                npat_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (npat_w == 0) {
+                    round++;
+                    continue;
+                }
+                uint32_t at = incl - cnt;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    uint32_t m = b[k] & rmask;
+                    while (m) {
+                        const int bit = __ffs(m) - 1;
+                        m &= m - 1;
+                        wpat[at++] = (slot0 + 12u * (uint32_t)bit) | (kBranchTerms[k] << 13);
+                    }
+                }
+                wave_lds_fence();
+                in_round = true;
+                base = 0;
+            }
+
+            // ------------------------------------------------------------ P4 value gates
+            // one lane per pattern match: high / base_signal / base_noise of the branch that
+            // matched first (:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
+            const uint32_t idx = base + (uint32_t)lane;
             bool pass = false;
             uint32_t slot = 0;
-            if (idx < npat) {
-                const uint32_t ent = s.pat[idx];
+            if (idx < npat_w) {
+                const uint32_t ent = wpat[idx];
                 slot = ent & 0x1FFFu;
-                const uint16_t *pm = s.mag + slot;  // u16 LDS reads: no unpacking on the VALU
+                // one u16 LDS read per magnitude (no unpacking on the VALU); volatile so that the
+                // compiler does not merge them into 8/16-byte reads at a 2-byte aligned address,
+                // which the LDS replays at 64 cycles each
+                typedef const volatile __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
+                lds_u16_ptr pm = (lds_u16_ptr)(s.mag + slot);
                 const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
                           p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
                 // 0 / -1 masks of the branch's terms (signed 1-bit field extracts)
@@ -415,132 +458,141 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
             }
             const unsigned long long mask = __ballot(pass);
             if (mask) {
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&s.ncand, (uint32_t)__popcll(mask));
-                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mask);
-                if (pass && at < (uint32_t)kCandCap) {
+                if (pass) {
                     const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
-                    s.cand[at] = slot | (qs << 13) | ((slot - 12u * qs) << 23);
+                    wcand[ncand_w + mask_rank(mask)] = slot | (qs << 13) | ((slot - 12u * qs) << 23);
                 }
+                ncand_w += (uint32_t)__popcll(mask);
             }
+            base += 64;
+            if (base >= npat_w) {
+                in_round = false;
+                round++;
+            }
+            // room for another pass of the gates and more of them to come: not yet
+            if (round < nrounds && ncand_w + 64 <= (uint32_t)kCandPerWave) continue;
         }
-    }
-    lds_barrier();
-    STAMP(4);
-    if (p.debug_stop == 4) {
-        lds_barrier();
-        continue;
-    }
-    if (s.ncand > (uint32_t)kCandCap) {
-        if (tid == 0) defer_tile(p, chunk, tile);
-        lds_barrier();
-        continue;
-    }
+        if (ncand_w == 0) {
+            if (round >= nrounds) break;
+            continue;
+        }
+        wave_lds_fence();
 
-    // ---------------------------------------------------------------- P5 trials
-    // lane = (candidate, try_phase).  Message bit n = 5k + r of trial phase tp sits at
-    // 5x-oversampled position 5*(slot+19) + tp + 12n, i.e. sample
-    // slot + 19 + (tp+12r)/5 + 12k with slicer phase (tp+12r) % 5: field r is 23
-    // consecutive bits of one sign plane; which plane and where comes from s.field.
-    {
-        const uint32_t ntrial = s.ncand * 5u;
-        const uint32_t *tF = s.tab, *tX51 = s.tab + 3 * 256;
-        const char *plane_bytes = (const char *)s.plane;
-        for (uint32_t base = 0; base < ntrial; base += kThreads) {
-            const uint32_t t5 = base + (uint32_t)tid;
-            bool is_hit = false, is_ap = false;
-            uint32_t e_lo = 0, e_hi = 0;
-            if (t5 < ntrial) {
-                const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
-                const uint32_t tpi = t5 - 5u * c;
-                const uint32_t ce = s.cand[c];
-                const uint32_t slot = ce & 0x1FFFu, qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
-                const uint32_t *ft = s.field + tpi * 60u + rs;
-                uint32_t f[5];
+        // ---------------------------------------------------------------- P5 trials
+        // lane = (candidate, try_phase).  Message bit n = 5k + r of trial phase tp sits at
+        // 5x-oversampled position 5*(slot+19) + tp + 12n, i.e. sample
+        // slot + 19 + (tp+12r)/5 + 12k with slicer phase (tp+12r) % 5: field r is 23
+        // consecutive bits of one sign plane; which plane and where comes from s.field.
+        {
+            const uint32_t ntrial = ncand_w * 5u;
+            cand_count += ncand_w;
+            ncand_w = 0;
+            const uint32_t *tF = s.tab, *tX51 = s.tab + 3 * 256;
+            const char *plane_bytes = (const char *)s.plane;
+            for (uint32_t tb = 0; tb < ntrial; tb += 64) {
+                const uint32_t t5 = tb + (uint32_t)lane;
+                bool is_hit = false, is_ap = false;
+                uint32_t e_lo = 0, e_hi = 0;
+                if (t5 < ntrial) {
+                    const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
+                    const uint32_t tpi = t5 - 5u * c;
+                    const uint32_t ce = wcand[c];
+                    const uint32_t cslot = ce & 0x1FFFu, qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
+                    const uint32_t *ft = s.field + tpi * 60u + rs;
+                    uint32_t f[5];
 #pragma unroll
-                for (int r = 0; r < 5; r++) {
-                    const uint32_t fe = ft[r * 12];
-                    const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
-                    const uint32_t *pl = (const uint32_t *)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
-                    f[r] = alignbit(pl[1], pl[0], qq & 31u);
-                }
-                // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
-                const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) |
-                                    ((f[3] & 1u) << 1) | (f[4] & 1u);
-                const bool is_long = df >= 16;
-                // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks at
-                // all 14 bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
-                const bool nonzero = (((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0;
-                const uint32_t mk0 = is_long ? 0x7FFFFFu : 0xFFFu, mk1 = is_long ? 0x7FFFFFu : 0x7FFu,
-                               mk2 = is_long ? 0x3FFFFFu : 0x7FFu;
-                const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
-                // H' = sum_r x^(4-r) * F(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
-                uint32_t hp = 0;
+                    for (int r = 0; r < 5; r++) {
+                        const uint32_t fe = ft[r * 12];
+                        const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
+                        // two dword reads on purpose: the address is only 4-byte aligned, and a
+                        // merged 8-byte read off its alignment is replayed at 64 cycles
+                        typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+                        lds_u32_ptr pl = (lds_u32_ptr)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
+                        const uint32_t lo = pl[0], hi = pl[1];  // volatile: stays two 4-byte reads
+                        f[r] = alignbit(hi, lo, qq & 31u);
+                    }
+                    // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
+                    const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) |
+                                        ((f[3] & 1u) << 1) | (f[4] & 1u);
+                    const bool is_long = df >= 16;
+                    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks
+                    // at all 14 bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
+                    const bool nonzero = (((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0;
+                    const uint32_t mk0 = is_long ? 0x7FFFFFu : 0xFFFu, mk1 = is_long ? 0x7FFFFFu : 0x7FFu,
+                                   mk2 = is_long ? 0x3FFFFFu : 0x7FFu;
+                    const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
+                    // H' = sum_r x^(4-r) * F(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
+                    uint32_t hp = 0;
 #pragma unroll
-                for (int r = 0; r < 5; r++) {
-                    const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
-                    const uint32_t g = *(const uint32_t *)((const char *)tF + (x4 & 0x3FCu)) ^
-                                       *(const uint32_t *)((const char *)tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
-                                       *(const uint32_t *)((const char *)tF + 2048 + ((x4 >> 16) & 0x3FCu));
-                    hp ^= g << (4 - r);
-                }
-                const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
+                    for (int r = 0; r < 5; r++) {
+                        const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
+                        const uint32_t g = *(const uint32_t *)((const char *)tF + (x4 & 0x3FCu)) ^
+                                           *(const uint32_t *)((const char *)tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
+                                           *(const uint32_t *)((const char *)tF + 2048 + ((x4 >> 16) & 0x3FCu));
+                        hp ^= g << (4 - r);
+                    }
+                    const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
 
-                const bool df11 = df == 11, df1718 = df == 17 || df == 18;
-                const bool ap_short = df == 0 || df == 4 || df == 5;
-                const bool ap_long = df == 16 || df == 20 || df == 21 || df >= 24;
-                bool learn = false;  // the host replay will add this address to the filter
-                if (nonzero) {
-                    if (df1718) {                       // mod.rs:91-109: clean iff H == 0
-                        is_hit = h == 0;
-                        learn = is_hit && df == 17;     // DF18 adds addr|1<<25: never matched
-                    } else if (df11) {                  // mod.rs:73-90
-                        const uint32_t crc = tX51[h & 255u] ^ tX51[256 + ((h >> 8) & 255u)] ^ tX51[512 + (h >> 16)];
-                        is_hit = (crc & 0xFFFF80u) == 0;
-                        learn = is_hit && (crc & 0x7Fu) == 0;
-                    } else {
-                        is_ap = ap_short || ap_long;    // mod.rs:56-72, 110-135
+                    const bool df11 = df == 11, df1718 = df == 17 || df == 18;
+                    const bool ap_short = df == 0 || df == 4 || df == 5;
+                    const bool ap_long = df == 16 || df == 20 || df == 21 || df >= 24;
+                    bool learn = false;  // the host replay will add this address to the filter
+                    if (nonzero) {
+                        if (df1718) {                       // mod.rs:91-109: clean iff H == 0
+                            is_hit = h == 0;
+                            learn = is_hit && df == 17;     // DF18 adds addr|1<<25: never matched
+                        } else if (df11) {                  // mod.rs:73-90
+                            const uint32_t crc = tX51[h & 255u] ^ tX51[256 + ((h >> 8) & 255u)] ^ tX51[512 + (h >> 16)];
+                            is_hit = (crc & 0xFFFF80u) == 0;
+                            learn = is_hit && (crc & 0x7Fu) == 0;
+                        } else {
+                            is_ap = ap_short || ap_long;    // mod.rs:56-72, 110-135
+                        }
+                    }
+                    // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
+                    const uint32_t j = (uint32_t)(jbase - kPad) + cslot;
+                    const uint32_t code = tpi + (is_long ? 5u : 0u);
+                    e_lo = h | (code << 24) | (j << 28);
+                    e_hi = (j >> 4) | (chunk << 13);
+                    if (learn) {
+                        uint32_t addr = 0;  // message bits 8..31
+#pragma unroll
+                        for (int n = 8; n < 32; n++) addr |= ((f[n % 5] >> (n / 5)) & 1u) << (31 - n);
+                        bitmap_set(p.bitmap, addr);
                     }
                 }
-                // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
-                const uint32_t j = (uint32_t)(jbase - kPad) + slot;
-                const uint32_t code = tpi + (is_long ? 5u : 0u);
-                e_lo = h | (code << 24) | (j << 28);
-                e_hi = (j >> 4) | (chunk << 13);
-                if (learn) {
-                    uint32_t addr = 0;  // message bits 8..31
-#pragma unroll
-                    for (int n = 8; n < 32; n++) addr |= ((f[n % 5] >> (n / 5)) & 1u) << (31 - n);
-                    bitmap_set(p.bitmap, addr);
+                const uint64_t entry = ((uint64_t)e_hi << 32) | e_lo;
+                // AP entries: straight into this workgroup's own segment, compacted per wave;
+                // s.nap is the workgroup's fill count for this tile
+                const unsigned long long ma = __ballot(is_ap);
+                if (ma) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&s.nap, (uint32_t)__popcll(ma));
+                    at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(ma);
+                    if (is_ap && at < seg_cap) seg[at] = entry;
                 }
-            }
-            const uint64_t entry = ((uint64_t)e_hi << 32) | e_lo;
-            // AP entries: straight into this workgroup's own segment, compacted per wave
-            const unsigned long long ma = __ballot(is_ap);
-            if (ma) {
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&s.nap, (uint32_t)__popcll(ma));
-                at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(ma);
-                if (is_ap && at < seg_cap) seg[at] = entry;
-            }
-            const unsigned long long mh = __ballot(is_hit);
-            if (mh) {  // rare
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
-                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
-                if (is_hit) {
-                    if (at < (uint32_t)kHitCap) {
-                        s.hit[at] = entry;
-                    } else {  // more hits in one tile than the staging holds: one by one
-                        const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
-                        if (gi < p.hits_cap)
-                            p.hits[gi] = entry;
-                        else
-                            atomicOr(&p.ctr->overflow, 1u);
+                const unsigned long long mh = __ballot(is_hit);
+                if (mh) {  // rare
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
+                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
+                    if (is_hit) {
+                        if (at < (uint32_t)kHitCap) {
+                            s.hit[at] = entry;
+                        } else {  // more hits in one tile than the staging holds: one by one
+                            const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
+                            if (gi < p.hits_cap)
+                                p.hits[gi] = entry;
+                            else
+                                atomicOr(&p.ctr->overflow, 1u);
+                        }
                     }
                 }
             }
+            wave_lds_fence();  // wcand is reused by the next passes of the gates
         }
+        if (round >= nrounds) break;
+    }
     }
     lds_barrier();
     STAMP(5);
@@ -552,7 +604,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
     // ---------------------------------------------------------------- tile epilogue
     // The AP fill count of the private segment is a register; it is written back once
     // when the workgroup retires.
-    cand_count += s.ncand;
     ap_count += s.nap;
     if (ap_count > seg_cap) {
         ap_count = seg_cap;
@@ -571,10 +622,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
     lds_barrier();  // counters and lists are reset / reused by the next tile
     STAMP(6);
     }  // tile loop
-    if (tid == 0) {
-        p.ctr->seg_ap[blockIdx.x] = ap_count;
-        p.ctr->seg_cand[blockIdx.x] = cand_count;
-    }
+    // candidate counts were kept per wave (diagnostic): lane 0 of each wave adds its own
+    if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
+    if (tid == 0) p.ctr->seg_ap[blockIdx.x] = ap_count;
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
