@@ -101,7 +101,7 @@ def main():
         of one step (wait, copy-back, ordered replay) overlaps the device scan of the next;
         every step's full work still happens inside the loop."""
         ctx.set_profiling(level)
-        tot = {"ms_scan": 0.0, "ms_dense": 0.0, "ms_match": 0.0, "ms_records": 0.0, "ms_total_device": 0.0}
+        tot = {"ms_scan": 0.0, "ms_match": 0.0, "ms_records": 0.0, "ms_total_device": 0.0}
         frames = 0
 
         def account():
@@ -145,8 +145,7 @@ def main():
 
     # untimed: the same steps once more with an event after every kernel, for the split
     _, tot2 = run_steps(args.warmup, args.steps, 2)
-    dense_ms, match_ms, rec_ms, dev_ms = (tot2["ms_dense"], tot2["ms_match"], tot2["ms_records"],
-                                          tot2["ms_total_device"])
+    match_ms, rec_ms, dev_ms = tot2["ms_match"], tot2["ms_records"], tot2["ms_total_device"]
     ctx.set_profiling(1)
 
     if dist is not None:
@@ -181,7 +180,7 @@ def main():
             "sharding": "independent stream per GPU, no collectives",
             "host_api": "blocking adsb_demod_iq_device per step" if args.sync else
                         "adsb_submit_iq_device / adsb_collect, two passes in flight",
-            "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_scan_dense (deferred tiles) -> k_match -> k_records -> host replay",
+            "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_match -> k_records -> host replay",
             "library": "",
         },
         "roofline": {
@@ -194,12 +193,12 @@ def main():
             "kernel": "k_scan_fast",
             "kernel_avg_ms": round(scan_ms / args.steps, 4),
             "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
-            "other_kernels_avg_ms": {"k_scan_dense": round(dense_ms / args.steps, 4), "k_match": round(match_ms / args.steps, 4),
+            "other_kernels_avg_ms": {"k_match": round(match_ms / args.steps, 4),
                                      "k_records": round(rec_ms / args.steps, 4)},
             "device_chain_avg_ms": round(dev_ms / args.steps, 4),
         },
         "device_stats_last_step": {k: stats[k] for k in
-                                   ("n_candidates", "n_ap_entries", "n_records", "n_messages", "retries", "n_deferred")},
+                                   ("n_candidates", "n_ap_entries", "n_records", "n_messages", "retries")},
     }
     from dump1090_rs_amd import _lib
     result["config"]["library"] = _lib.lib().adsb_version().decode()

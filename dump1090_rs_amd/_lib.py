@@ -39,12 +39,10 @@ class AdsbStats(C.Structure):
         ("n_records", C.c_uint64),
         ("n_messages", C.c_uint64),
         ("ms_scan", C.c_float),
-        ("ms_dense", C.c_float),
         ("ms_match", C.c_float),
         ("ms_records", C.c_float),
         ("ms_total_device", C.c_float),
         ("retries", C.c_uint32),
-        ("n_deferred", C.c_uint32),
         ("reserved", C.c_uint32),
     ]
 

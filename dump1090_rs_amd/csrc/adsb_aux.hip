@@ -54,30 +54,43 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     __shared__ uint32_t stab[6 * 256];  // X51 and X107
     for (int i = threadIdx.x; i < 6 * 256; i += blockDim.x) stab[i] = p.tables[kTabX51 * 256 + i];
     __syncthreads();
-    // blocks 0..kApSegments-1 take one segment of the fast scan's list each; the blocks
-    // beyond stride over the dap list of the simple / dense kernels
-    const bool seg_block = blockIdx.x < (uint32_t)kApSegments;
     const uint32_t seg_cap = p.ap_cap / kApSegments;
-    const uint32_t n = seg_block ? min(p.ctr->seg_ap[blockIdx.x], seg_cap) : min(p.ctr->n_dap, p.dap_cap);
-    const uint64_t *ap = seg_block ? p.ap + (uint64_t)blockIdx.x * seg_cap : p.dap;
-    const uint32_t stride = seg_block ? blockDim.x : (gridDim.x - kApSegments) * blockDim.x;
-    for (uint32_t i = (seg_block ? 0u : (blockIdx.x - kApSegments) * blockDim.x) + threadIdx.x;; i += stride) {
-        // whole waves stay in the loop together so wave_append's ballot is uniform
-        const uint32_t wave_first = i - (threadIdx.x & 63);
-        if (wave_first >= n) break;
-        bool has = false;
-        uint64_t e = 0;
-        if (i < n) {
-            e = ap[i];
-            const uint32_t code = entry_code(e);
-            uint32_t c = entry_value(e);
-            if (code < 5)
-                c = gf_apply(stab, c);
-            else if (code < 10)
-                c = gf_apply(stab + 3 * 256, c);
-            has = (p.bitmap[c >> 5] >> (c & 31)) & 1u;
+    // work units: the kApSegments segments of the fast scan's list, then the dap list
+    for (uint32_t sg = blockIdx.x; sg <= (uint32_t)kApSegments; sg += gridDim.x) {
+        const bool is_dap = sg == (uint32_t)kApSegments;
+        const uint32_t n = is_dap ? min(p.ctr->n_dap, p.dap_cap) : min(p.ctr->seg_ap[sg], seg_cap);
+        const uint64_t *ap = is_dap ? p.dap : p.ap + (uint64_t)sg * seg_cap;
+        // four entries per thread per trip: their list loads, then their bitmap loads, are
+        // in flight together (the chain entry -> residual -> bitmap word is all latency)
+        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+            uint64_t e[4];
+            uint32_t w[4], c[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + k * blockDim.x;
+                e[k] = i < n ? ap[i] : ~0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t code = entry_code(e[k]);
+                c[k] = entry_value(e[k]);
+                if (code < 5)
+                    c[k] = gf_apply(stab, c[k]);
+                else if (code < 10)
+                    c[k] = gf_apply(stab + 3 * 256, c[k]);
+                w[k] = p.bitmap[c[k] >> 5];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (e[k] != ~0ull && ((w[k] >> (c[k] & 31)) & 1u)) {  // rare: one atomic each
+                    const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
+                    if (idx < p.hits_cap)
+                        p.hits[idx] = e[k];
+                    else
+                        atomicOr(&p.ctr->overflow, 1u);
+                }
+            }
         }
-        wave_append(has, e, p.hits, p.hits_cap, &p.ctr->n_hits, &p.ctr->overflow, 1u);
     }
 }
 
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             Summary sm;
             sm.n_hits = p.ctr->n_hits;
             sm.overflow = p.ctr->overflow;
-            sm.n_deferred = p.ctr->n_deferred;
+            sm.reserved0 = 0;
             sm.n_dap = p.ctr->n_dap;
             sm.n_ap_total = ap + p.ctr->n_dap;
             sm.n_cand_total = cand + p.ctr->n_cand_simple;
@@ -230,9 +243,9 @@ int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
 
 int launch_match(const ScanParams &p, void *stream)
 {
-    // one block per segment of the fast scan's AP list + 64 blocks for the dap list; the
-    // counts live on the device
-    const uint32_t blocks = kApSegments + 64;
+    // 512 blocks stride over the segments of the fast scan's AP list and the dap list; the
+    // fill counts live on the device
+    const uint32_t blocks = 512;
     hipLaunchKernelGGL(k_match, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }

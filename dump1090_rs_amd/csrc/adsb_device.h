@@ -9,8 +9,6 @@
 //             * self-validating trials (clean DF11 / DF17 / DF18)  -> hit list,
 //               and their address is OR-ed into the 2^24-bit address bitmap
 //             * address/parity trials (DF 0,4,5,16,20,21,24..31)   -> AP list
-//           (tiles too dense for the fast kernel's LDS lists -> deferred-tile list)
-//   dense   deferred tiles through the simple kernel (normally none)
 //   match   AP list x bitmap -> hit list      (bitmap is now complete for the call)
 //   records hit list -> {chunk, j, try_phase, 14 message bytes, 33-sample power}
 //
@@ -61,17 +59,17 @@ static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 // The AP list of the fast scan is split into kApSegments equal segments; persistent
 // workgroup b owns segment b outright, so appending needs no atomic at all (a returning
 // global atomic costs a workgroup 1-2 us per tile, and one hot counter saturates near
-// 90 atomics/us on this chip).  The simple / dense kernels append to a second list,
-// `dap`, through one shared counter: they are the slow path anyway.
+// 90 atomics/us on this chip).  The simple kernel appends to a second list,
+// `dap`, through one shared counter: it is the slow path anyway.
 constexpr int kApSegments = 1024;
 
 // Device counters block (one per context).
 struct Counters {
     uint32_t n_hits;       // entries in the hit list
-    uint32_t overflow;     // bit0: hit list, bit1: an AP segment, bit2: deferred list, bit3: dap list
-    uint32_t n_deferred;   // tiles handed to the dense kernel
+    uint32_t overflow;     // bit0: hit list, bit1: an AP segment, bit3: dap list
+    uint32_t reserved0;
     uint32_t n_dap;        // entries in the dap list
-    uint32_t n_cand_simple;  // candidates seen by the simple / dense kernels (diagnostic)
+    uint32_t n_cand_simple;  // candidates seen by the simple kernel (diagnostic)
     uint32_t pad[3];
     uint32_t seg_ap[kApSegments];    // entries in each AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
@@ -80,7 +78,7 @@ struct Counters {
 // What the host needs after a pass, gathered by the records kernel (the last one to run)
 // so that one small copy brings it back.
 struct Summary {
-    uint32_t n_hits, overflow, n_deferred, n_dap;
+    uint32_t n_hits, overflow, reserved0, n_dap;
     uint32_t n_ap_total;    // all AP entries (fast segments + dap)
     uint32_t n_cand_total;  // all candidates
     uint32_t pad[2];
@@ -100,10 +98,8 @@ struct ScanParams {
     uint32_t hits_cap;
     uint64_t *ap;           // kApSegments segments of ap_cap / kApSegments entries
     uint32_t ap_cap;        // a multiple of kApSegments
-    uint64_t *dap;          // AP entries of the simple / dense kernels
+    uint64_t *dap;          // AP entries of the simple kernel
     uint32_t dap_cap;
-    uint32_t *deferred;     // (chunk << 8 | fast-tile index) of tiles the fast kernel gave up on
-    uint32_t deferred_cap;
     const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
     Summary *summary;
@@ -118,7 +114,6 @@ int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
 int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream);
 int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
-int launch_dense(const ScanParams &p, void *stream);
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);
 int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream);

@@ -56,9 +56,8 @@ struct adsb_ctx {
     Counters *d_ctr = nullptr;
     uint64_t *d_hits = nullptr, *d_ap = nullptr, *d_dap = nullptr;
     TrialRecord *d_rec = nullptr;
-    uint32_t *d_deferred = nullptr;
     uint32_t *d_tables = nullptr;
-    uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0, deferred_cap = 0;
+    uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0;
     Summary *d_sum = nullptr;
 
     Slot slot[kSlots];
@@ -143,8 +142,6 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.ap_cap = c->ap_cap;
     p.dap = c->d_dap;
     p.dap_cap = c->dap_cap;
-    p.deferred = c->d_deferred;
-    p.deferred_cap = c->deferred_cap;
     p.tables = c->d_tables;
     p.ctr = c->d_ctr;
     p.summary = c->d_sum;
@@ -166,8 +163,6 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (prof) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
     if (prof) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
-    if (!from_mag)  // tiles the fast scan deferred (normally none; the kernel then exits at once)
-        if (int e = launch_dense(p, c->stream)) return fail(c, (hipError_t)e, "launch_dense");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], c->stream));
     if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], c->stream));
@@ -202,9 +197,7 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
         st.ms_scan += ms;
         if (sl.profiled > 1) {  // per-kernel split of the tail (events cost a few us each)
-            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
-            st.ms_dense += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[3]));
             st.ms_match += ms;
             HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]));
             st.ms_records += ms;
@@ -214,7 +207,6 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     }
     st.n_candidates += sl.h_sum->n_cand_total;
     st.n_ap_entries += sl.h_sum->n_ap_total;
-    st.n_deferred += sl.h_sum->n_deferred;
     st.n_records += n;
     replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out);
     return 0;
@@ -305,12 +297,10 @@ int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<
         total.n_ap_entries += c->stats.n_ap_entries;
         total.n_records += c->stats.n_records;
         total.ms_scan += c->stats.ms_scan;
-        total.ms_dense += c->stats.ms_dense;
         total.ms_match += c->stats.ms_match;
         total.ms_records += c->stats.ms_records;
         total.ms_total_device += c->stats.ms_total_device;
         total.retries += c->stats.retries;
-        total.n_deferred += c->stats.n_deferred;
     }
     total.n_samples = n_samples;
     c->stats = total;
@@ -363,13 +353,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     // Fast-scan AP list: kApSegments private segments, sized for ~5x the rate pure noise
     // produces (2.3 % of samples become address/parity entries), never less than one
     // tile's staging buffer so that a single-chunk pass always fits.  Denser input falls
-    // back to per-chunk passes.  dap (simple / dense kernels) holds a whole chunk's worst
+    // back to per-chunk passes.  dap (simple kernel) holds a whole chunk's worst
     // case: every j sliced, five trials each.
     uint64_t seg = std::max<uint64_t>(2048, (max_chunks * (uint64_t)kChunkSamples / 8 + kApSegments - 1) / kApSegments);
     c->ap_cap = (uint32_t)std::min<uint64_t>(seg * kApSegments, 0xFFFFFC00u);
     c->dap_cap = kWorstPerChunk;
     c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
-    c->deferred_cap = (uint32_t)std::min<uint64_t>(max_chunks * 32, 1u << 24);
 
     int rc = ADSB_OK;
     auto body = [&]() -> int {
@@ -383,7 +372,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_rec, (size_t)c->hits_cap * sizeof(TrialRecord)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_deferred, (size_t)c->deferred_cap * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
             std::vector<uint32_t> tab = build_gf_tables();
@@ -439,7 +427,6 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_ap) (void)hipFree(c->d_ap);
     if (c->d_dap) (void)hipFree(c->d_dap);
     if (c->d_rec) (void)hipFree(c->d_rec);
-    if (c->d_deferred) (void)hipFree(c->d_deferred);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_timeline) {
         // profiling aid: dump the stamps of the last scan on the way out
@@ -586,8 +573,6 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
         total.n_ap_entries += c->stats.n_ap_entries;
         total.n_records += c->stats.n_records;
         total.ms_scan += c->stats.ms_scan;
-        total.ms_dense += c->stats.ms_dense;
-        total.n_deferred += c->stats.n_deferred;
         total.ms_match += c->stats.ms_match;
         total.ms_records += c->stats.ms_records;
         total.ms_total_device += c->stats.ms_total_device;

@@ -34,9 +34,9 @@
 // to the instruction: 24-bit multiplies with magic constants instead of divisions,
 // shifts and masks instead of bit-field extracts, u16 LDS reads instead of unpacking.
 //
-// A tile whose LDS lists would overflow (far denser than any real signal) is handed,
-// untouched, to the simple kernel through the deferred list, so the fast path has fixed
-// capacity and the result stays exact.
+// Nothing in the kernel has a capacity that input density could exceed: each wave keeps
+// its matches and candidates in its own small LDS regions and drains them in rounds
+// (P3..P5 below), so exactness never depends on how dense the signal is.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

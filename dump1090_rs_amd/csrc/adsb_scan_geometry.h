@@ -1,5 +1,5 @@
 // adsb_scan_geometry.h -- tile geometry of the fast scan kernel (adsb_scan_fast.hip),
-// shared with the dense fallback, which re-does deferred fast tiles.
+// shared with the host, which builds the field-addressing table for it.
 #pragma once
 #include "adsb_device.h"
 
@@ -13,7 +13,6 @@ constexpr int kTilesPerChunk = (kChunkSamples + kTile - 1) / kTile;  // 17
 constexpr int kPad = 2;   // 326 + 2 = 4 * 82: LDS slot 0 sits on a 16-byte IQ boundary
 constexpr int kSlots = kTile + kPad + kReach;  // 8004 magnitudes a tile touches
 static_assert(kTile % 4 == 0 && (kLead + kPad) % 4 == 0, "aligned dwordx4 IQ loads");
-static_assert(kTilesPerChunk < 256, "deferred entries keep the tile index in 8 bits");
 
 // sign planes: bit k of plane (kind, res) = decision at slot 12k + res
 constexpr int kPlaneBits = (kSlots + 11) / 12;         // 667 per residue

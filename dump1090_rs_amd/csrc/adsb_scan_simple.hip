@@ -4,11 +4,9 @@
 // then every j through the gates (src/demod_2400.rs:121-146) exactly as the reference
 // walks them, then every trial phase sliced bit by bit (:158-182) and scored as far as
 // the device goes (DF class + CRC residual, src/mode_s/mod.rs:41-135).  It is slow
-// (every thread walks 112 bits serially) and has no capacity limits, which is why it
-// serves (a) adsb_demodulate2400, whose input is a caller-supplied MagnitudeBuffer, and
-// (b) tiles the fast kernel defers because they overflow its LDS lists.
+// (every thread walks 112 bits serially) and serves adsb_demodulate2400, whose input is
+// a caller-supplied MagnitudeBuffer (one chunk; throughput is irrelevant there).
 #include "adsb_dev_common.h"
-#include "adsb_scan_geometry.h"
 
 namespace adsb {
 
@@ -125,28 +123,6 @@ __global__ __launch_bounds__(256) void k_scan_simple(ScanParams p)
                                &sncand);
 }
 
-// deferred tiles of the fast kernel: two blocks per deferred tile (half a fast tile each)
-__global__ __launch_bounds__(256) void k_scan_dense(ScanParams p)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t smag[kSlots];
-    __shared__ uint32_t scrc[256];
-    __shared__ uint16_t scand[kTile];
-    __shared__ uint32_t sncand;
-    static_assert(fastgeo::kTile % 8 == 0 && fastgeo::kTile / 2 <= kTile, "half a fast tile per block");
-
-    const uint32_t n = min(p.ctr->n_deferred, p.deferred_cap);
-    for (uint32_t item = blockIdx.x; item < 2 * n; item += gridDim.x) {
-        const uint32_t e = p.deferred[item >> 1];
-        const uint32_t chunk = e >> 8;
-        const int len = chunk_len(p.n_samples, chunk);
-        const int jbase = (int)(e & 0xFFu) * fastgeo::kTile + (int)(item & 1u) * (fastgeo::kTile / 2);
-        const int jend = min(len, (int)(e & 0xFFu) * fastgeo::kTile + (int)((item & 1u) + 1) * (fastgeo::kTile / 2));
-        if (jbase < jend)
-            scan_simple_tile<false>(p, chunk, jbase, jend - jbase, len, smag, scrc, scand, &sncand);
-        __syncthreads();
-    }
-}
-
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 }  // namespace
@@ -159,14 +135,6 @@ int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream)
         hipLaunchKernelGGL(k_scan_simple<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_scan_simple<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    return hip_ok(hipGetLastError());
-}
-
-int launch_dense(const ScanParams &p, void *stream)
-{
-    // the deferred count lives on the device; a small fixed grid strides over it and
-    // exits at once when it is zero (the normal case)
-    hipLaunchKernelGGL(k_scan_dense, dim3(64), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

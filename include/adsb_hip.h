@@ -82,12 +82,10 @@ typedef struct {
     uint64_t n_records;     /* trial records replayed on the host */
     uint64_t n_messages;
     float ms_scan;          /* scan kernel (IQ -> candidates -> trials), HIP events */
-    float ms_dense;         /* dense-tile fallback kernel (normally finds nothing to do) */
     float ms_match;         /* address/parity match kernel */
     float ms_records;       /* record builder kernel */
     float ms_total_device;  /* first launch -> last kernel end */
     uint32_t retries;       /* device-list overflow fallbacks taken */
-    uint32_t n_deferred;    /* tiles the fast scan handed to the dense fallback */
     uint32_t reserved;
 } adsb_stats;
 
@@ -101,7 +99,7 @@ void adsb_destroy(adsb_ctx *ctx);
  * context's own.  Pass NULL to go back to the private stream. */
 int adsb_set_stream(adsb_ctx *ctx, void *hip_stream);
 /* HIP-event timing of the kernels: 0 = off, 1 = ms_scan only (default; two events),
- * 2 = also ms_dense / ms_match / ms_records / ms_total_device (an event costs the
+ * 2 = also ms_match / ms_records / ms_total_device (an event costs the
  * stream several microseconds, so level 2 slows a call down noticeably). */
 int adsb_set_profiling(adsb_ctx *ctx, int level);
 

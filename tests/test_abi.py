@@ -29,7 +29,7 @@ def test_struct_layouts_match_header(hip_lib):
     assert C.sizeof(AdsbMsg) == 40
     assert AdsbMsg.len.offset == 14 and AdsbMsg.score.offset == 16 and AdsbMsg.j.offset == 20
     assert AdsbMsg.chunk.offset == 24 and AdsbMsg.signal_level.offset == 32
-    assert C.sizeof(AdsbStats) == 6 * 8 + 5 * 4 + 3 * 4
+    assert C.sizeof(AdsbStats) == 6 * 8 + 4 * 4 + 2 * 4
 
 
 def test_no_cpu_backend(hip_lib):
