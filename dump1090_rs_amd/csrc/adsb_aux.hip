@@ -55,14 +55,17 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     for (int i = threadIdx.x; i < 6 * 256; i += blockDim.x) stab[i] = p.tables[kTabX51 * 256 + i];
     __syncthreads();
     const uint32_t seg_cap = p.ap_cap / kApSegments;
-    // work units: the kApSegments segments of the fast scan's list, then the dap list
-    for (uint32_t sg = blockIdx.x; sg <= (uint32_t)kApSegments; sg += gridDim.x) {
+    // work units: the kApSegments segments of the fast scan's list, then the dap list; two
+    // blocks share a unit (the grid is 2 x units) so that the usual ~1500 entries of a
+    // segment are a single trip
+    {
+        const uint32_t sg = blockIdx.x >> 1, half = blockIdx.x & 1u;
         const bool is_dap = sg == (uint32_t)kApSegments;
         const uint32_t n = is_dap ? min(p.ctr->n_dap, p.dap_cap) : min(p.ctr->seg_ap[sg], seg_cap);
         const uint64_t *ap = is_dap ? p.dap : p.ap + (uint64_t)sg * seg_cap;
         // four entries per thread per trip: their list loads, then their bitmap loads, are
         // in flight together (the chain entry -> residual -> bitmap word is all latency)
-        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        for (uint32_t i0 = half * 4 * blockDim.x + threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
             uint64_t e[4];
             uint32_t w[4], c[4];
 #pragma unroll
@@ -243,9 +246,9 @@ int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
 
 int launch_match(const ScanParams &p, void *stream)
 {
-    // 512 blocks stride over the segments of the fast scan's AP list and the dap list; the
-    // fill counts live on the device
-    const uint32_t blocks = 512;
+    // two blocks per segment of the fast scan's AP list and for the dap list; the fill
+    // counts live on the device
+    const uint32_t blocks = 2 * (kApSegments + 1);
     hipLaunchKernelGGL(k_match, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }

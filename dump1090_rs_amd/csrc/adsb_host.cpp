@@ -29,8 +29,10 @@ struct Slot {
     const void *src = nullptr;
     uint64_t n_samples = 0;
     uint32_t n_chunks = 0;
-    Summary *h_sum = nullptr;      // pinned
-    TrialRecord *h_rec = nullptr;  // pinned, hits_cap entries
+    // pinned, mapped host memory the records kernel writes straight into (no copy commands
+    // on the stream): *_dev are the device-side addresses of the same allocations
+    Summary *h_sum = nullptr, *h_sum_dev = nullptr;
+    TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;  // hits_cap entries
     hipEvent_t done = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int profiled = 0;  // profiling level the pass was enqueued with
@@ -55,10 +57,8 @@ struct adsb_ctx {
     uint32_t *d_bitmap = nullptr;
     Counters *d_ctr = nullptr;
     uint64_t *d_hits = nullptr, *d_ap = nullptr, *d_dap = nullptr;
-    TrialRecord *d_rec = nullptr;
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0;
-    Summary *d_sum = nullptr;
 
     Slot slot[kSlots];
     uint64_t submitted = 0, collected = 0;
@@ -73,7 +73,6 @@ namespace {
 
 constexpr size_t kBitmapBytes = (1u << 24) / 8;
 constexpr uint32_t kWorstPerChunk = 5u * kChunkSamples;  // every j sliced, 5 trials each
-constexpr size_t kInlineRecords = 1024;  // records fetched together with the summary
 
 int fail(adsb_ctx *c, hipError_t e, const char *what)
 {
@@ -144,7 +143,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.dap_cap = c->dap_cap;
     p.tables = c->d_tables;
     p.ctr = c->d_ctr;
-    p.summary = c->d_sum;
+    p.summary = sl.h_sum_dev;
     p.stagger_ticks = c->stagger_ticks;
     p.debug_stop = c->debug_stop;
     p.timeline = c->d_timeline;
@@ -166,13 +165,11 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], c->stream));
     if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], c->stream));
-    if (int e = launch_records(p, from_mag, c->d_rec, c->stream))
+    // the records kernel writes the summary and the records into the slot's mapped host
+    // memory; `done` (system-scope release) makes them visible to the host
+    if (int e = launch_records(p, from_mag, sl.h_rec_dev, c->stream))
         return fail(c, (hipError_t)e, "launch_records");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], c->stream));
-    // one round trip: the summary and the first kInlineRecords records come back together
-    HIP_TRY(c, hipMemcpyAsync(sl.h_sum, c->d_sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(sl.h_rec, c->d_rec, kInlineRecords * sizeof(TrialRecord),
-                              hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(sl.done, c->stream));
     return ADSB_OK;
 }
@@ -184,14 +181,6 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     HIP_TRY(c, hipEventSynchronize(sl.done));
     if (sl.h_sum->overflow) return 1;
     const size_t n = sl.h_sum->n_hits;
-    if (n > kInlineRecords) {
-        // more records than came back with the summary; the device copy is still intact
-        // unless a later pass has run, so a pipelined caller keeps passes below this size
-        HIP_TRY(c, hipMemcpyAsync(sl.h_rec + kInlineRecords, c->d_rec + kInlineRecords,
-                                  (n - kInlineRecords) * sizeof(TrialRecord), hipMemcpyDeviceToHost,
-                                  c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
     if (sl.profiled) {
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
@@ -371,7 +360,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_rec, (size_t)c->hits_cap * sizeof(TrialRecord)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
             std::vector<uint32_t> tab = build_gf_tables();
@@ -381,11 +369,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
                                  hipMemcpyHostToDevice));
         }
-        HIP_TRY(c, hipMalloc((void **)&c->d_sum, sizeof(Summary)));
         for (Slot &sl : c->slot) {
-            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocDefault));
+            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocMapped));
             HIP_TRY(c, hipHostMalloc((void **)&sl.h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
-                                     hipHostMallocDefault));
+                                     hipHostMallocMapped));
+            HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_sum_dev, sl.h_sum, 0));
+            HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_rec_dev, sl.h_rec, 0));
             // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
             for (auto &e : sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
             HIP_TRY(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -426,7 +415,6 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_ap) (void)hipFree(c->d_ap);
     if (c->d_dap) (void)hipFree(c->d_dap);
-    if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_timeline) {
         // profiling aid: dump the stamps of the last scan on the way out
@@ -443,7 +431,6 @@ void adsb_destroy(adsb_ctx *c)
                 }
         (void)hipFree(c->d_timeline);
     }
-    if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
