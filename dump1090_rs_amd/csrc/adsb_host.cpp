@@ -648,6 +648,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.2 gfx950 scan=v1-planes"; }
+const char *adsb_version(void) { return "adsb_hip 0.3 gfx950 scan=v2-wave-private"; }
 
 }  // extern "C"
