@@ -42,9 +42,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["sparse", "dense"], default="sparse",
+    ap.add_argument("--workload", choices=["sparse", "dense", "stream"], default="sparse",
                     help="sparse: 64 DF17 bursts per 256 MiB (BASELINE config 2); "
-                         "dense: 5000 bursts (config 5)")
+                         "dense: 5000 bursts (config 5); stream: host-resident IQ through the "
+                         "pinned double-buffered ring, H2D inside the timed region (config 3)")
     ap.add_argument("--chunks", type=int, default=512, help="131072-sample buffers per step")
     ap.add_argument("--buffers", type=int, default=3, help="distinct IQ buffers rotated over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,6 +79,9 @@ def main():
 
     from dump1090_rs_amd import Context, synth
     from dump1090_rs_amd._lib import AdsbMsg
+
+    if args.workload == "stream":
+        return stream_bench(args, torch, dist, rank, world, local_rank)
 
     n = args.chunks * CHUNK
     n_bursts = 64 if args.workload == "sparse" else 5000
@@ -250,6 +254,84 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and result.get("parity_checked") is False:
         sys.exit(3)
+
+
+def stream_bench(args, torch, dist, rank, world, local_rank):
+    """BASELINE config 3: sustained rate with the IQ starting in host memory.  A step = one
+    ring slot of --chunks buffers (default here 64 = 32 MiB): adsb_ring_submit starts its
+    pinned H2D copy on the copy stream and the pass behind it; the other slot's pass runs
+    meanwhile.  No icao_flush between steps (the live loop of main.rs never flushes).  The
+    ring buffers are filled once, outside the timed region (an SDR driver would DMA into them)."""
+    from dump1090_rs_amd import Context, synth
+    from dump1090_rs_amd._lib import AdsbMsg
+
+    chunks = args.chunks if args.chunks != 512 else 64
+    n = chunks * CHUNK
+    ctx = Context(device=local_rank, max_chunks=chunks)
+    ctx.ring_create(n)
+    cap = 1 << 18
+    out = (AdsbMsg * cap)()
+    ctx.icao_flush()
+    for k in range(2):  # fill both pinned slots (and warm up)
+        buf = ctx.ring_acquire()
+        buf[:] = synth.make_iq(n, n_bursts=max(1, 64 * chunks // 512), seed=synth.SEED_DEFAULT + 7 * rank + k)
+        ctx.ring_submit(n)
+        ctx.collect_raw(out, cap)
+    for _ in range(args.warmup):
+        ctx.ring_acquire()
+        ctx.ring_submit(n)
+        ctx.collect_raw(out, cap)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_profiling(1)
+    frames, scan_ms = 0, 0.0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ctx.ring_acquire()
+        ctx.ring_submit(n)
+        if i > 0:
+            frames += ctx.collect_raw(out, cap)
+            scan_ms += ctx.stats_raw().ms_scan
+    frames += ctx.collect_raw(out, cap)
+    scan_ms += ctx.stats_raw().ms_scan
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        from dump1090_rs_amd import sharding
+        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device=torch.device("cuda", local_rank))
+    from dump1090_rs_amd import _lib
+    msps = n * args.steps * world / elapsed / 1e6
+    scan_avg_s = scan_ms / args.steps / 1e3
+    achieved = BYTES_PER_SAMPLE * n / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+    result = {
+        "metric": "IQ Msamples/s demodulated", "value": round(msps, 1), "unit": "Msamples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i16 IQ -> f32 magnitude (exact) -> u16/i32 integer", "data": "synthetic",
+        "frames_per_s": round(frames / elapsed, 1),
+        "config": {"workload": f"streaming ring: {chunks} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB per slot, "
+                               "host-resident IQ, pinned double-buffered hipMemcpyAsync inside the timed region "
+                               "(BASELINE config 3)",
+                   "h2d_GBps": round(BYTES_PER_SAMPLE * n * args.steps / elapsed / 1e9, 2),
+                   "library": _lib.lib().adsb_version().decode()},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_scan_fast",
+                     "kernel_avg_ms": round(scan_ms / args.steps, 4),
+                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+                     "note": "PCIe-fed: the scan kernel idles between transfers; value is the sustained end-to-end rate"},
+    }
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def _cpu_model() -> str:

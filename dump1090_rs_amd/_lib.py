@@ -88,6 +88,9 @@ def lib() -> C.CDLL:
     L.adsb_submit_iq_device.argtypes = [vp, vp, sz]
     L.adsb_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_pending.argtypes = [vp]
+    L.adsb_ring_create.argtypes = [vp, sz]
+    L.adsb_ring_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.adsb_ring_submit.argtypes = [vp, sz]
     L.adsb_read_test_data.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
     L.adsb_get_stats.argtypes = [vp, C.POINTER(AdsbStats)]
     L.adsb_replay_records.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
@@ -100,7 +103,8 @@ def lib() -> C.CDLL:
     for name in ("adsb_create", "adsb_set_stream", "adsb_set_profiling", "adsb_icao_flush",
                  "adsb_to_mag", "adsb_demodulate2400", "adsb_demod_iq", "adsb_demod_iq_device",
                  "adsb_read_test_data", "adsb_get_stats", "adsb_replay_records",
-                 "adsb_selftest_mag_digest", "adsb_submit_iq_device", "adsb_collect", "adsb_pending"):
+                 "adsb_selftest_mag_digest", "adsb_submit_iq_device", "adsb_collect", "adsb_pending",
+                 "adsb_ring_create", "adsb_ring_acquire", "adsb_ring_submit"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -174,6 +174,20 @@ class Context:
     def collect(self, cap: int = 1 << 16) -> List[ModeSMessage]:
         return self._collect(lambda out, c, n: self._L.adsb_collect(self._h, out, c, n), "adsb_collect", cap)
 
+    # -- streaming ring: pinned host buffers, H2D overlapped with the other slot's pass
+    def ring_create(self, samples_per_slot: int) -> None:
+        self._check(self._L.adsb_ring_create(self._h, samples_per_slot), "adsb_ring_create")
+
+    def ring_acquire(self) -> np.ndarray:
+        """The pinned (capacity, 2) int16 [re, im] buffer of the next submission."""
+        ptr, cap = C.c_void_p(), C.c_size_t()
+        self._check(self._L.adsb_ring_acquire(self._h, C.byref(ptr), C.byref(cap)), "adsb_ring_acquire")
+        buf = (C.c_int16 * (2 * cap.value)).from_address(ptr.value)
+        return np.ctypeslib.as_array(buf).reshape(-1, 2)
+
+    def ring_submit(self, n_samples: int) -> None:
+        self._check(self._L.adsb_ring_submit(self._h, n_samples), "adsb_ring_submit")
+
     def pending(self) -> int:
         return int(self._L.adsb_pending(self._h))
 

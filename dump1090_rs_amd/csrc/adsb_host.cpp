@@ -63,6 +63,17 @@ struct adsb_ctx {
     Slot slot[kSlots];
     uint64_t submitted = 0, collected = 0;
 
+    // streaming ring (adsb_ring_*): per slot a pinned host buffer the caller fills and a
+    // device staging buffer; the H2D copy of one slot runs on its own stream while the
+    // other slot's pass computes
+    struct RingSlot {
+        int16_t *h_iq = nullptr;
+        void *d_iq = nullptr;
+        hipEvent_t copied = nullptr;
+    } ring[kSlots];
+    size_t ring_samples = 0;
+    hipStream_t copy_stream = nullptr;
+
     IcaoFilter filter;
     Crc24 crc;
     adsb_stats stats{};
@@ -416,6 +427,12 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_ap) (void)hipFree(c->d_ap);
     if (c->d_dap) (void)hipFree(c->d_dap);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    for (auto &r : c->ring) {
+        if (r.copied) (void)hipEventDestroy(r.copied);
+        if (r.h_iq) (void)hipHostFree(r.h_iq);
+        if (r.d_iq) (void)hipFree(r.d_iq);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->d_timeline) {
         // profiling aid: dump the stamps of the last scan on the way out
         unsigned long long tl[512];
@@ -532,6 +549,44 @@ int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
 }
 
 int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->collected) : 0; }
+
+int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
+{
+    if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
+    if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (auto &r : c->ring) {
+        HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
+        HIP_TRY(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
+    }
+    c->ring_samples = samples_per_slot;
+    return ADSB_OK;
+}
+
+int adsb_ring_acquire(adsb_ctx *c, int16_t **host_iq, size_t *capacity_samples)
+{
+    if (!c || !host_iq || !c->ring_samples) return ADSB_ERR_INVALID;
+    if (c->slot[c->submitted % kSlots].busy) return ADSB_ERR_BUSY;  // collect the oldest pass first
+    *host_iq = c->ring[c->submitted % kSlots].h_iq;
+    if (capacity_samples) *capacity_samples = c->ring_samples;
+    return ADSB_OK;
+}
+
+int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
+{
+    if (!c || !c->ring_samples || n_samples == 0 || n_samples > c->ring_samples) return ADSB_ERR_INVALID;
+    if (c->slot[c->submitted % kSlots].busy) return ADSB_ERR_BUSY;
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto &r = c->ring[c->submitted % kSlots];
+    // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's
+    // transfer overlaps the other slot's kernels
+    HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(r.copied, c->copy_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, r.copied, 0));
+    return submit(c, r.d_iq, false, n_samples);
+}
 
 int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *out, size_t cap,
                   size_t *n_out)

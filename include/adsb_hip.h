@@ -142,6 +142,18 @@ int adsb_submit_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_s
 int adsb_collect(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 int adsb_pending(const adsb_ctx *ctx);
 
+/* Streaming ring for a host that produces IQ (an SDR read loop, dump1090_rs/src/main.rs:
+ * 154-167): two pinned host buffers of `samples_per_slot` samples with a device staging
+ * buffer each.  Fill the buffer adsb_ring_acquire hands out (e.g. read the SDR straight
+ * into it), adsb_ring_submit(n) starts its host-to-device copy on a copy stream and the
+ * pass behind it, adsb_collect returns the oldest pass's messages.  While one slot's pass
+ * runs, the other slot's transfer is in flight.  samples_per_slot may not exceed the
+ * context's max_chunks buffers; adsb_ring_acquire returns ADSB_ERR_BUSY until the pass
+ * that last used the slot has been collected. */
+int adsb_ring_create(adsb_ctx *ctx, size_t samples_per_slot);
+int adsb_ring_acquire(adsb_ctx *ctx, int16_t **host_iq_re_im, size_t *capacity_samples);
+int adsb_ring_submit(adsb_ctx *ctx, size_t n_samples);
+
 /* src/utils.rs:23-40 read_test_data: file pairs are [im][re] little-endian;
  * writes in-memory {re, im}.  Returns samples read via *n_out. */
 int adsb_read_test_data(const char *path, int16_t *iq_re_im, size_t max_samples, size_t *n_out);

@@ -323,3 +323,30 @@ def test_submit_collect_matches_blocking_calls_and_orders_flushes(ctx, oracle_mo
         assert_same(g, w)
     with pytest.raises(AdsbError):
         ctx.collect()                                         # nothing pending
+
+
+def test_streaming_ring_pinned_double_buffering(hip_lib, oracle_mod):
+    """BASELINE config 3: the host fills pinned ring buffers, H2D copies overlap passes;
+    frames identical to one oracle stream over the same bytes."""
+    from dump1090_rs_amd import Context
+    per_slot, n_batches = 4 * 131072, 5
+    iq = synth.make_iq(per_slot * n_batches - 7000, n_bursts=60, seed=8088)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    got = []
+    with Context(0, 4) as c:
+        c.ring_create(per_slot)
+        c.icao_flush()
+        for b in range(n_batches):
+            if c.pending() == 2:
+                got += [(m.chunk + 4 * (b - 2), m) for m in c.collect()]
+            part = iq[b * per_slot:(b + 1) * per_slot]
+            buf = c.ring_acquire()
+            assert buf.shape == (per_slot, 2)
+            buf[: len(part)] = part
+            c.ring_submit(len(part))
+        k = n_batches - c.pending()
+        while c.pending():
+            got += [(m.chunk + 4 * k, m) for m in c.collect()]
+            k += 1
+    assert [(ch, m.j, m.try_phase, m.score, m.msg, m.signal_level) for ch, m in got] == \
+        [(w["chunk"], w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"]) for w in want]
