@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--chunks", type=int, default=512, help="131072-sample buffers per step")
     ap.add_argument("--buffers", type=int, default=3, help="distinct IQ buffers rotated over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-profiling", type=int, default=1,
+                    help="HIP-event level inside the timed region (1 = scan kernel stamped by its "
+                         "own launch; 0 = none, then roofline numbers come from the untimed repeat)")
     ap.add_argument("--sync", action="store_true",
                     help="one blocking adsb_demod_iq_device call per step instead of the two-deep "
                          "submit/collect pipeline")
@@ -141,7 +144,7 @@ def main():
     # by the library on the stream the kernels run on.
     fence()
     t0 = time.perf_counter()
-    frames, tot = run_steps(args.warmup, args.steps, 1)
+    frames, tot = run_steps(args.warmup, args.steps, args.timed_profiling)
     fence()
     elapsed = time.perf_counter() - t0
     scan_ms = tot["ms_scan"]
@@ -149,6 +152,8 @@ def main():
 
     # untimed: the same steps once more with an event after every kernel, for the split
     _, tot2 = run_steps(args.warmup, args.steps, 2)
+    if args.timed_profiling == 0:
+        scan_ms = tot2["ms_scan"]
     match_ms, rec_ms, dev_ms = tot2["ms_match"], tot2["ms_records"], tot2["ms_total_device"]
     ctx.set_profiling(1)
 

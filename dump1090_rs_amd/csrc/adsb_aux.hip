@@ -51,9 +51,9 @@ __device__ __forceinline__ uint32_t gf_apply(const uint32_t *tab3, uint32_t h)
 
 __global__ __launch_bounds__(256) void k_match(ScanParams p)
 {
-    __shared__ uint32_t stab[6 * 256];  // X51 and X107
-    for (int i = threadIdx.x; i < 6 * 256; i += blockDim.x) stab[i] = p.tables[kTabX51 * 256 + i];
-    __syncthreads();
+    // the x^51 / x^107 multiplier tables (6 KB) are read through the vector cache: staging
+    // them in LDS first costs every block a global round trip before it can start
+    const uint32_t *stab = p.tables + kTabX51 * 256;
     const uint32_t seg_cap = p.ap_cap / kApSegments;
     // work units: the kApSegments segments of the fast scan's list, then the dap list; two
     // blocks share a unit (the grid is 2 x units) so that the usual ~1500 entries of a
@@ -103,6 +103,17 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
 // kept in HBM), the 112 bits of the trial phase are sliced (demod_2400.rs:158-182)
 // and the 33-sample power summed (:191-196).
 // ---------------------------------------------------------------------------
+// Stores into mapped host memory: system scope, i.e. written through the caches, so they
+// are in host memory when the kernel has drained -- no cache flush needed afterwards.
+__device__ __forceinline__ void host_store64(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void host_store32(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool FROM_MAG>
 struct WindowReader {
     const void *src;
@@ -130,28 +141,15 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 {
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {  // one wave totals the counters for the host
-        uint32_t ap = 0, cand = 0;
-        for (int i = lane; i < kApSegments; i += 64) {
-            ap += p.ctr->seg_ap[i];
-            cand += p.ctr->seg_cand[i];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            ap += __shfl_down(ap, off);
-            cand += __shfl_down(cand, off);
-        }
-        if (lane == 0) {
-            Summary sm;
-            sm.n_hits = p.ctr->n_hits;
-            sm.overflow = p.ctr->overflow;
-            sm.reserved0 = 0;
-            sm.n_dap = p.ctr->n_dap;
-            sm.n_ap_total = ap + p.ctr->n_dap;
-            sm.n_cand_total = cand + p.ctr->n_cand_simple;
-            sm.pad[0] = sm.pad[1] = 0;
-            *p.summary = sm;
-        }
+    // housekeeping for the NEXT pass, so that it needs no reset launch of its own: zero the
+    // other counters block and, after an icao_flush switched bitmaps, clear the spare one
+    // (address 0 always tests true, src/icao_filter.rs:71-80: bit 0 starts set)
+    {
+        const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+        for (uint32_t i = gi; i < sizeof(Counters) / 4; i += gn) ((uint32_t *)p.next_ctr)[i] = 0;
+        if (p.clean_bitmap)
+            for (uint32_t v = gi; v < (1u << 24) / 8 / 16; v += gn)
+                ((uint4 *)p.clean_bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
     }
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -192,7 +190,32 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 #pragma unroll
             for (int b = 0; b < 6; b++) r.msg[8 + b] = (uint8_t)(half[1] >> (56 - 8 * b));
             r.pad = 0;
-            rec[i] = r;
+            const unsigned long long *src = (const unsigned long long *)&r;
+            unsigned long long *dst = (unsigned long long *)&rec[i];
+#pragma unroll
+            for (int k = 0; k < 4; k++) host_store64(dst + k, src[k]);
+        }
+    }
+    // The summary for the host (block 0, one wave).  Like the records it goes straight into
+    // mapped host memory with write-through stores, so that the completion event behind
+    // this kernel needs no system-scope cache flush to make it visible.
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        uint32_t ap = 0, cand = 0;
+        for (int i = lane; i < kApSegments; i += 64) {
+            ap += p.ctr->seg_ap[i];
+            cand += p.ctr->seg_cand[i];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ap += __shfl_down(ap, off);
+            cand += __shfl_down(cand, off);
+        }
+        if (lane == 0) {
+            uint32_t *sm = (uint32_t *)p.summary;
+            const uint32_t vals[8] = {p.ctr->n_hits, p.ctr->overflow, 0u, p.ctr->n_dap,
+                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, 0u, p.seq};
+#pragma unroll
+            for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
         }
     }
 }

@@ -70,7 +70,8 @@ struct Counters {
     uint32_t reserved0;
     uint32_t n_dap;        // entries in the dap list
     uint32_t n_cand_simple;  // candidates seen by the simple kernel (diagnostic)
-    uint32_t pad[3];
+    uint32_t blocks_done;    // records kernel: blocks that have finished (last one publishes)
+    uint32_t pad[2];
     uint32_t seg_ap[kApSegments];    // entries in each AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
 };
@@ -81,7 +82,8 @@ struct Summary {
     uint32_t n_hits, overflow, reserved0, n_dap;
     uint32_t n_ap_total;    // all AP entries (fast segments + dap)
     uint32_t n_cand_total;  // all candidates
-    uint32_t pad[2];
+    uint32_t pad;
+    uint32_t seq;           // the pass's sequence number (never 0): lets the host check it reads its own pass
 };
 
 // GF(2) tables, 256 u32 each (adsb_tables.h): F0 F1 F2 | X51_0..2 | X107_0..2
@@ -102,7 +104,11 @@ struct ScanParams {
     uint32_t dap_cap;
     const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
-    Summary *summary;
+    Counters *next_ctr;     // the other counters block: zeroed by the records kernel for the next pass
+    uint32_t *clean_bitmap; // the spare bitmap to clear in the records kernel after an icao_flush, or null
+    Summary *summary;       // in mapped host memory
+    uint32_t seq;           // this pass's sequence number
+    void *ev_start, *ev_stop;  // HIP events stamped by the scan launch itself (or null)
     uint32_t stagger_ticks; // fast scan: start offset between the workgroups of a CU (clock64 ticks)
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
@@ -110,7 +116,8 @@ struct ScanParams {
 
 // launches; all asynchronous on `stream`, return a hipError_t as int
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
-// zero the counters block and, when `bitmap` is non-null, clear the address bitmap (bit 0 stays set)
+// zero a counters block and, when `bitmap` is non-null, clear an address bitmap (bit 0 stays
+// set); only needed once per context: afterwards every pass cleans up for the next one
 int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream);
 int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path

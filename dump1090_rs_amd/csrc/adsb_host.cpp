@@ -33,7 +33,8 @@ struct Slot {
     // on the stream): *_dev are the device-side addresses of the same allocations
     Summary *h_sum = nullptr, *h_sum_dev = nullptr;
     TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;  // hits_cap entries
-    hipEvent_t done = nullptr;
+    uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
+    hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int profiled = 0;  // profiling level the pass was enqueued with
 };
@@ -45,7 +46,7 @@ struct adsb_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int profiling = 1;  // 0: no events, 1: around the scan kernel, 2: around every kernel
-    bool flush_pending = true;  // consumed by the next pass: its reset kernel clears the bitmap
+    bool flush_pending = true;  // consumed by the next pass: it switches to the clean spare bitmap
     uint32_t stagger_ticks = 0;
     int debug_stop = 0;  // ADSB_DEBUG_STOP: profiling aid, breaks results when non-zero
     unsigned long long *d_timeline = nullptr;  // ADSB_TIMELINE=1: 8 blocks x 8 tiles x 8 stamps
@@ -54,14 +55,21 @@ struct adsb_ctx {
     void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
     size_t stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
-    uint32_t *d_bitmap = nullptr;
-    Counters *d_ctr = nullptr;
+    // Two address bitmaps and two counters blocks: every pass's records kernel zeroes the
+    // counters of the next pass and re-cleans the bitmap an icao_flush retired, so a pass is
+    // scan -> match -> records with no reset launch in front.
+    uint32_t *d_bitmap[2] = {nullptr, nullptr};
+    int cur_bitmap = 0;          // the one in use
+    bool spare_dirty = false;    // the other one still holds pre-flush addresses
+    Counters *d_ctr[2] = {nullptr, nullptr};
+    int cur_ctr = 0;
     uint64_t *d_hits = nullptr, *d_ap = nullptr, *d_dap = nullptr;
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0;
 
     Slot slot[kSlots];
     uint64_t submitted = 0, collected = 0;
+    uint32_t next_seq = 1;
 
     // streaming ring (adsb_ring_*): per slot a pinned host buffer the caller fills and a
     // device staging buffer; the H2D copy of one slot runs on its own stream while the
@@ -145,7 +153,13 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.src = d_src;
     p.n_samples = n_samples;
     p.n_chunks = n_chunks;
-    p.bitmap = c->d_bitmap;
+    if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the clean spare
+        c->cur_bitmap ^= 1;
+        c->spare_dirty = true;
+    }
+    p.bitmap = c->d_bitmap[c->cur_bitmap];
+    p.clean_bitmap = c->spare_dirty ? c->d_bitmap[c->cur_bitmap ^ 1] : nullptr;
+    c->spare_dirty = false;
     p.hits = c->d_hits;
     p.hits_cap = c->hits_cap;
     p.ap = c->d_ap;
@@ -153,7 +167,9 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.dap = c->d_dap;
     p.dap_cap = c->dap_cap;
     p.tables = c->d_tables;
-    p.ctr = c->d_ctr;
+    p.ctr = c->d_ctr[c->cur_ctr];
+    p.next_ctr = c->d_ctr[c->cur_ctr ^ 1];
+    c->cur_ctr ^= 1;
     p.summary = sl.h_sum_dev;
     p.stagger_ticks = c->stagger_ticks;
     p.debug_stop = c->debug_stop;
@@ -166,18 +182,26 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.flush_before = c->flush_pending;
     sl.profiled = c->profiling;
     const int prof = sl.profiled;
+    sl.seq = c->next_seq++;
+    if (c->next_seq == 0) c->next_seq = 1;
+    sl.h_sum->seq = 0;  // the records kernel overwrites it, last, with sl.seq
+    p.seq = sl.seq;
+    // level 1: the scan launch stamps its own begin/end (no extra packets on the stream);
+    // level 2: classic event records between all kernels
+    static const bool ext_events = !std::getenv("ADSB_NO_EXT_EVENTS");
+    p.ev_start = ext_events && prof == 1 && !from_mag ? sl.ev[0] : nullptr;
+    p.ev_stop = ext_events && prof == 1 && !from_mag ? sl.ev[1] : nullptr;
 
-    if (int e = launch_reset(c->d_ctr, c->flush_pending ? c->d_bitmap : nullptr, c->stream))
-        return fail(c, (hipError_t)e, "launch_reset");
     c->flush_pending = false;
-    if (prof) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
+    const bool classic = prof > 1 || (prof == 1 && (from_mag || !ext_events));
+    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
-    if (prof) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
+    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], c->stream));
     if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], c->stream));
-    // the records kernel writes the summary and the records into the slot's mapped host
-    // memory; `done` (system-scope release) makes them visible to the host
+    // the records kernel writes the records and the summary into the slot's mapped host
+    // memory with write-through stores; `done` only has to say the kernel has drained
     if (int e = launch_records(p, from_mag, sl.h_rec_dev, c->stream))
         return fail(c, (hipError_t)e, "launch_records");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], c->stream));
@@ -190,6 +214,10 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
 int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out)
 {
     HIP_TRY(c, hipEventSynchronize(sl.done));
+    if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
+        c->last_error = "pass completed without publishing its summary";
+        return ADSB_ERR_HIP;
+    }
     if (sl.h_sum->overflow) return 1;
     const size_t n = sl.h_sum->n_hits;
     if (sl.profiled) {
@@ -366,8 +394,10 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, kBitmapBytes));
-        HIP_TRY(c, hipMalloc((void **)&c->d_ctr, sizeof(Counters)));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_bitmap[k], kBitmapBytes));
+            HIP_TRY(c, hipMalloc((void **)&c->d_ctr[k], sizeof(Counters)));
+        }
         HIP_TRY(c, hipMalloc((void **)&c->d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
@@ -388,13 +418,19 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_rec_dev, sl.h_rec, 0));
             // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
             for (auto &e : sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
-            HIP_TRY(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&sl.done, std::getenv("ADSB_DONE_FENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
         }
         if (std::getenv("ADSB_TIMELINE")) {
             HIP_TRY(c, hipMalloc((void **)&c->d_timeline, 512 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemset(c->d_timeline, 0, 512 * sizeof(unsigned long long)));
         }
-        c->flush_pending = true;
+        // both bitmaps clean and both counter blocks zero to start with; from then on each
+        // pass cleans up for the next (the first pass needs no flush of its own)
+        for (int k = 0; k < 2; k++)
+            if (int e = launch_reset(c->d_ctr[k], c->d_bitmap[k], c->stream))
+                return fail(c, (hipError_t)e, "launch_reset");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->flush_pending = false;
         return (int)ADSB_OK;
     };
     rc = body();
@@ -421,8 +457,10 @@ void adsb_destroy(adsb_ctx *c)
     }
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_mag) (void)hipFree(c->d_mag);
-    if (c->d_bitmap) (void)hipFree(c->d_bitmap);
-    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    for (int k = 0; k < 2; k++) {
+        if (c->d_bitmap[k]) (void)hipFree(c->d_bitmap[k]);
+        if (c->d_ctr[k]) (void)hipFree(c->d_ctr[k]);
+    }
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_ap) (void)hipFree(c->d_ap);
     if (c->d_dap) (void)hipFree(c->d_dap);
@@ -647,14 +685,19 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
                              uint64_t *xor_out)
 {
     if (!c || !sum_out || !xor_out) return ADSB_ERR_INVALID;
+    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipSetDevice(c->device));
     // the counters block doubles as the 16-byte result area
     static_assert(sizeof(Counters) >= 16, "digest result fits the counters block");
-    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
-    if (int e = launch_mag_digest(first_bits, count, (unsigned long long *)c->d_ctr, c->stream))
+    // the counters block the next pass will use doubles as the 16-byte result area; it is
+    // zeroed again afterwards
+    Counters *scratch = c->d_ctr[c->cur_ctr];
+    HIP_TRY(c, hipMemsetAsync(scratch, 0, sizeof(Counters), c->stream));
+    if (int e = launch_mag_digest(first_bits, count, (unsigned long long *)scratch, c->stream))
         return fail(c, (hipError_t)e, "launch_mag_digest");
     uint64_t res[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(res, c->d_ctr, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(res, scratch, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(scratch, 0, sizeof(Counters), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *sum_out = res[0];
     *xor_out = res[1];

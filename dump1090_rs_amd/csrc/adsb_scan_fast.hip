@@ -41,6 +41,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "adsb_dev_common.h"
 #include "adsb_scan_geometry.h"
 
@@ -655,7 +657,13 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
     }
     const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
-    hipLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    // With events, the launch itself carries them (hipExtLaunchKernelGGL): the dispatch
+    // packet's own begin/end timestamps, no barrier packets in the stream around it.
+    if (p.ev_start && p.ev_stop)
+        hipExtLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                              (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
+    else
+        hipLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 
