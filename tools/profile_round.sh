@@ -3,6 +3,6 @@
 # counters, final bench line.  usage: tools_profile_round.sh <tag>
 R=$GRAFT_REPO_ROOT; T=$1; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$T -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_${T}_bench.log 2>&1
-cd $R; ./tools_traffic.sh traffic_$T > gpurun_out/traffic_$T.json 2>/dev/null
+cd $R; ./tools/traffic.sh traffic_$T > gpurun_out/traffic_$T.json 2>/dev/null
 timeout 300 python bench.py > gpurun_out/bench_$T.json 2> gpurun_out/bench_$T.err
 tail -1 gpurun_out/traffic_$T.json; tail -1 gpurun_out/bench_$T.json | cut -c1-400
