@@ -67,10 +67,6 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
             if (OP == 45) asm volatile("v_pk_mad_i16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 46) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 47) asm volatile("v_mad_u32_u16 %0, %0, %1, %1 op_sel:[1,0,0,0]" : "+v"(a[i]) : "v"(b));
-            if (OP == 48) asm volatile("v_dot2_i32_i16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
-            if (OP == 49) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
-            if (OP == 50) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
-            if (OP == 51) asm volatile("s_and_b64 s[10:11], s[10:11], s[12:13]" ::: "s10","s11");
         }
     }
     uint32_t r = 0;
@@ -146,9 +142,5 @@ int main()
     run<45>("v_pk_mad_i16", d);
     run<46>("v_pk_max_i16", d);
     run<47>("v_mad_u32_u16", d);
-    run<48>("v_dot2_i32_i16", d);
-    run<49>("v_mul_lo_u32", d);
-    run<50>("v_bcnt_u32_b32", d);
-    run<51>("s_and_b64", d);
     return 0;
 }
