@@ -141,15 +141,14 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 {
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
     const int lane = threadIdx.x & 63;
-    // housekeeping for the NEXT pass, so that it needs no reset launch of its own: zero the
-    // other counters block and, after an icao_flush switched bitmaps, clear the spare one
-    // (address 0 always tests true, src/icao_filter.rs:71-80: bit 0 starts set)
-    {
+    // Housekeeping so that no pass needs a reset launch: after an icao_flush retired a
+    // bitmap, clear it here (address 0 always tests true, src/icao_filter.rs:71-80: bit 0
+    // starts set); it comes back into use two flushes later.  This pass's own counters are
+    // zeroed at the very end, by the last block to finish.
+    if (p.clean_bitmap) {
         const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
-        for (uint32_t i = gi; i < sizeof(Counters) / 4; i += gn) ((uint32_t *)p.next_ctr)[i] = 0;
-        if (p.clean_bitmap)
-            for (uint32_t v = gi; v < (1u << 24) / 8 / 16; v += gn)
-                ((uint4 *)p.clean_bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
+        for (uint32_t v = gi; v < (1u << 24) / 8 / 16; v += gn)
+            ((uint4 *)p.clean_bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
     }
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -196,10 +195,16 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             for (int k = 0; k < 4; k++) host_store64(dst + k, src[k]);
         }
     }
-    // The summary for the host (block 0, one wave).  Like the records it goes straight into
-    // mapped host memory with write-through stores, so that the completion event behind
-    // this kernel needs no system-scope cache flush to make it visible.
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    // The last block to finish totals the counters into the summary for the host -- like the
+    // records it goes straight into mapped host memory with write-through stores, so the
+    // completion event behind this kernel needs no system-scope cache flush -- and then
+    // zeroes this pass's counters block, which the same slot's next pass starts from.
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&p.ctr->blocks_done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x < 64) {
         uint32_t ap = 0, cand = 0;
         for (int i = lane; i < kApSegments; i += 64) {
             ap += p.ctr->seg_ap[i];
@@ -218,6 +223,8 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
         }
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) ((uint32_t *)p.ctr)[i] = 0;
 }
 
 // ---------------------------------------------------------------------------

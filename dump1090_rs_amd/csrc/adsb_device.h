@@ -104,8 +104,7 @@ struct ScanParams {
     uint32_t dap_cap;
     const uint32_t *tables; // kTabCount x 256
     Counters *ctr;
-    Counters *next_ctr;     // the other counters block: zeroed by the records kernel for the next pass
-    uint32_t *clean_bitmap; // the spare bitmap to clear in the records kernel after an icao_flush, or null
+    uint32_t *clean_bitmap; // a retired bitmap for the records kernel to clear (after an icao_flush), or null
     Summary *summary;       // in mapped host memory
     uint32_t seq;           // this pass's sequence number
     void *ev_start, *ev_stop;  // HIP events stamped by the scan launch itself (or null)

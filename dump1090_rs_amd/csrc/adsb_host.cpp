@@ -33,6 +33,12 @@ struct Slot {
     // on the stream): *_dev are the device-side addresses of the same allocations
     Summary *h_sum = nullptr, *h_sum_dev = nullptr;
     TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;  // hits_cap entries
+    // device side of the slot: its own counters, AP list and hit list, so that the match /
+    // records tail of this pass (tail stream) can run while the next pass's scan (scan
+    // stream) fills the other slot's
+    Counters *d_ctr = nullptr;
+    uint64_t *d_ap = nullptr, *d_hits = nullptr;
+    hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
     uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -55,15 +61,14 @@ struct adsb_ctx {
     void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
     size_t stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
-    // Two address bitmaps and two counters blocks: every pass's records kernel zeroes the
-    // counters of the next pass and re-cleans the bitmap an icao_flush retired, so a pass is
-    // scan -> match -> records with no reset launch in front.
-    uint32_t *d_bitmap[2] = {nullptr, nullptr};
-    int cur_bitmap = 0;          // the one in use
-    bool spare_dirty = false;    // the other one still holds pre-flush addresses
-    Counters *d_ctr[2] = {nullptr, nullptr};
-    int cur_ctr = 0;
-    uint64_t *d_hits = nullptr, *d_ap = nullptr, *d_dap = nullptr;
+    // Three address bitmaps in rotation: icao_flush moves on to the next (clean) one, the
+    // retired one is cleared by that pass's records kernel and comes back into use two
+    // flushes later -- by then the pass that cleared it has long been collected, so neither
+    // a reset launch nor a cross-stream wait is ever needed.
+    uint32_t *d_bitmap[3] = {nullptr, nullptr, nullptr};
+    int cur_bitmap = 0;
+    hipStream_t tail_stream = nullptr;  // match + records of pass i run here, beside scan i+1
+    uint64_t *d_dap = nullptr;
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0;
 
@@ -153,23 +158,20 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.src = d_src;
     p.n_samples = n_samples;
     p.n_chunks = n_chunks;
-    if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the clean spare
-        c->cur_bitmap ^= 1;
-        c->spare_dirty = true;
+    p.clean_bitmap = nullptr;
+    if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the next clean one
+        p.clean_bitmap = c->d_bitmap[c->cur_bitmap];
+        c->cur_bitmap = (c->cur_bitmap + 1) % 3;
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
-    p.clean_bitmap = c->spare_dirty ? c->d_bitmap[c->cur_bitmap ^ 1] : nullptr;
-    c->spare_dirty = false;
-    p.hits = c->d_hits;
+    p.hits = sl.d_hits;
     p.hits_cap = c->hits_cap;
-    p.ap = c->d_ap;
+    p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
     p.dap = c->d_dap;
     p.dap_cap = c->dap_cap;
     p.tables = c->d_tables;
-    p.ctr = c->d_ctr[c->cur_ctr];
-    p.next_ctr = c->d_ctr[c->cur_ctr ^ 1];
-    c->cur_ctr ^= 1;
+    p.ctr = sl.d_ctr;
     p.summary = sl.h_sum_dev;
     p.stagger_ticks = c->stagger_ticks;
     p.debug_stop = c->debug_stop;
@@ -197,15 +199,20 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
-    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], c->stream));
-    if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
-    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], c->stream));
+    // the tail runs on its own stream behind the scan: the next pass's scan does not wait
+    // for it (it works on the other slot's lists and counters)
+    HIP_TRY(c, hipEventRecord(sl.scanned, c->stream));
+    hipStream_t ts = c->tail_stream;
+    HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
+    if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
     // the records kernel writes the records and the summary into the slot's mapped host
     // memory with write-through stores; `done` only has to say the kernel has drained
-    if (int e = launch_records(p, from_mag, sl.h_rec_dev, c->stream))
+    if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
         return fail(c, (hipError_t)e, "launch_records");
-    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], c->stream));
-    HIP_TRY(c, hipEventRecord(sl.done, c->stream));
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
+    HIP_TRY(c, hipEventRecord(sl.done, ts));
     return ADSB_OK;
 }
 
@@ -225,7 +232,7 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
         st.ms_scan += ms;
         if (sl.profiled > 1) {  // per-kernel split of the tail (events cost a few us each)
-            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[3]));
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
             st.ms_match += ms;
             HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]));
             st.ms_records += ms;
@@ -255,6 +262,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     if (rc > 0 && !sl.from_mag && sl.n_chunks > 1) {
         st.retries++;
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // later passes have their results on the host
+        HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
         const bool keep_flush = c->flush_pending;
         c->flush_pending = false;
         Slot tmp = sl;  // same host buffers and events, one chunk at a time
@@ -394,12 +402,14 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
-        for (int k = 0; k < 2; k++) {
-            HIP_TRY(c, hipMalloc((void **)&c->d_bitmap[k], kBitmapBytes));
-            HIP_TRY(c, hipMalloc((void **)&c->d_ctr[k], sizeof(Counters)));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
+        for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapBytes));
+        for (Slot &sl : c->slot) {
+            HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipEventCreateWithFlags(&sl.scanned, hipEventDisableTiming | hipEventDisableSystemFence));
         }
-        HIP_TRY(c, hipMalloc((void **)&c->d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
@@ -426,8 +436,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         // both bitmaps clean and both counter blocks zero to start with; from then on each
         // pass cleans up for the next (the first pass needs no flush of its own)
-        for (int k = 0; k < 2; k++)
-            if (int e = launch_reset(c->d_ctr[k], c->d_bitmap[k], c->stream))
+        for (int k = 0; k < 3; k++)
+            if (int e = launch_reset(c->slot[k % kSlots].d_ctr, c->d_bitmap[k], c->stream))
                 return fail(c, (hipError_t)e, "launch_reset");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->flush_pending = false;
@@ -452,17 +462,21 @@ void adsb_destroy(adsb_ctx *c)
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.scanned) (void)hipEventDestroy(sl.scanned);
+        if (sl.d_ctr) (void)hipFree(sl.d_ctr);
+        if (sl.d_hits) (void)hipFree(sl.d_hits);
+        if (sl.d_ap) (void)hipFree(sl.d_ap);
         if (sl.h_sum) (void)hipHostFree(sl.h_sum);
         if (sl.h_rec) (void)hipHostFree(sl.h_rec);
     }
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_mag) (void)hipFree(c->d_mag);
-    for (int k = 0; k < 2; k++) {
-        if (c->d_bitmap[k]) (void)hipFree(c->d_bitmap[k]);
-        if (c->d_ctr[k]) (void)hipFree(c->d_ctr[k]);
+    for (auto &b : c->d_bitmap)
+        if (b) (void)hipFree(b);
+    if (c->tail_stream) {
+        (void)hipStreamSynchronize(c->tail_stream);
+        (void)hipStreamDestroy(c->tail_stream);
     }
-    if (c->d_hits) (void)hipFree(c->d_hits);
-    if (c->d_ap) (void)hipFree(c->d_ap);
     if (c->d_dap) (void)hipFree(c->d_dap);
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &r : c->ring) {
@@ -691,7 +705,7 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
     static_assert(sizeof(Counters) >= 16, "digest result fits the counters block");
     // the counters block the next pass will use doubles as the 16-byte result area; it is
     // zeroed again afterwards
-    Counters *scratch = c->d_ctr[c->cur_ctr];
+    Counters *scratch = c->slot[c->submitted % kSlots].d_ctr;
     HIP_TRY(c, hipMemsetAsync(scratch, 0, sizeof(Counters), c->stream));
     if (int e = launch_mag_digest(first_bits, count, (unsigned long long *)scratch, c->stream))
         return fail(c, (hipError_t)e, "launch_mag_digest");
