@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void k_reset(Counters *ctr, uint32_t *bitmap)
 // the filter when it is scored (mode_s/mod.rs:71,115,130); the bitmap now holds
 // every address the filter can contain at any point of this call (plus 0, which
 // icao_filter_test always accepts, icao_filter.rs:71-80).  Entries from the fast
-// scan carry the syndrome H; the residual is x^51*H or x^107*H (adsb_tables.h).
+// scan carry H' = x^51*H: the residual itself for 56-bit trials, x^56*H' for 112-bit
+// ones (adsb_tables.h).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t gf_apply(const uint32_t *tab3, uint32_t h)
 {
@@ -51,9 +52,9 @@ __device__ __forceinline__ uint32_t gf_apply(const uint32_t *tab3, uint32_t h)
 
 __global__ __launch_bounds__(256) void k_match(ScanParams p)
 {
-    // the x^51 / x^107 multiplier tables (6 KB) are read through the vector cache: staging
-    // them in LDS first costs every block a global round trip before it can start
-    const uint32_t *stab = p.tables + kTabX51 * 256;
+    // the x^56 multiplier table (3 KB) is read through the vector cache: staging it in LDS
+    // first costs every block a global round trip before it can start
+    const uint32_t *stab = p.tables + kTabX56 * 256;
     const uint32_t seg_cap = p.ap_cap / kApSegments;
     // work units: the kApSegments segments of the fast scan's list, then the dap list; two
     // blocks share a unit (the grid is 2 x units) so that the usual ~1500 entries of a
@@ -77,10 +78,7 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
             for (int k = 0; k < 4; k++) {
                 const uint32_t code = entry_code(e[k]);
                 c[k] = entry_value(e[k]);
-                if (code < 5)
-                    c[k] = gf_apply(stab, c[k]);
-                else if (code < 10)
-                    c[k] = gf_apply(stab + 3 * 256, c[k]);
+                if (code >= 5 && code < 10) c[k] = gf_apply(stab, c[k]);
                 w[k] = p.bitmap[c[k] >> 5];
             }
 #pragma unroll

@@ -27,12 +27,12 @@ constexpr int kMagDataLen = kLead + kChunkSamples;
 constexpr int kReach = 290;            // furthest sample a preamble at j touches: j+290
 
 // 64-bit list entry: value24 | code<<24 | j<<28 | chunk<<45
-//   code 0..4   short message (56 bits), try_phase = 4 + code, value = H (see below)
-//   code 5..9   long message (112 bits), try_phase = 4 + code - 5, value = H
+//   code 0..4   short message (56 bits), try_phase = 4 + code, value = H' (see below)
+//   code 5..9   long message (112 bits), try_phase = 4 + code - 5, value = H'
 //   code 10..14 try_phase = 4 + code - 10, value = the CRC residual itself
-// H is the CRC syndrome before its final constant multiplier: residual =
-// x^51 * H (short) or x^107 * H (long) in GF(2)[x]/(0x1FFF409) -- the match kernel
-// applies the multiplier (adsb_tables.h explains the factorisation).
+// H' = x^51 * H is the CRC syndrome of the fast scan: the residual itself for a 56-bit
+// message, and the residual is x^56 * H' in GF(2)[x]/(0x1FFF409) for a 112-bit one -- the
+// match kernel applies that multiplier (adsb_tables.h explains the factorisation).
 __host__ __device__ inline uint64_t pack_entry(uint32_t value, uint32_t code, uint32_t j,
                                                uint64_t chunk)
 {
@@ -86,8 +86,8 @@ struct Summary {
     uint32_t seq;           // the pass's sequence number (never 0): lets the host check it reads its own pass
 };
 
-// GF(2) tables, 256 u32 each (adsb_tables.h): F0 F1 F2 | X51_0..2 | X107_0..2
-constexpr int kTabF = 0, kTabX51 = 3, kTabX107 = 6, kTabCount = 9;
+// GF(2) tables, 256 u32 each (adsb_tables.h): F'0 F'1 F'2 | X56_0..2
+constexpr int kTabF = 0, kTabX56 = 3, kTabCount = 6;
 // after them in the same buffer: R16 (16 u32, adsb_tables.h) and the field table (300 u32)
 constexpr int kTabR16Off = kTabCount * 256, kTabFieldOff = kTabR16Off + 16, kTabWords = kTabFieldOff + 300;
 

@@ -47,6 +47,8 @@ struct Slot {
 
 constexpr int kSlots = 2;  // ADSB_MAX_IN_FLIGHT
 
+constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup
+
 struct adsb_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
@@ -431,8 +433,9 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipEventCreateWithFlags(&sl.done, std::getenv("ADSB_DONE_FENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
         }
         if (std::getenv("ADSB_TIMELINE")) {
-            HIP_TRY(c, hipMalloc((void **)&c->d_timeline, 512 * sizeof(unsigned long long)));
-            HIP_TRY(c, hipMemset(c->d_timeline, 0, 512 * sizeof(unsigned long long)));
+            // 1: stamps of 8 blocks x 8 tiles; 2 (with ADSB_DEBUG_STOP=100): per-wave phase totals
+            HIP_TRY(c, hipMalloc((void **)&c->d_timeline, kTimelineWords * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemset(c->d_timeline, 0, kTimelineWords * sizeof(unsigned long long)));
         }
         // both bitmaps clean and both counter blocks zero to start with; from then on each
         // pass cleans up for the next (the first pass needs no flush of its own)
@@ -485,7 +488,28 @@ void adsb_destroy(adsb_ctx *c)
         if (r.d_iq) (void)hipFree(r.d_iq);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->d_timeline) {
+    if (c->d_timeline && c->debug_stop == 100) {
+        // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves
+        std::vector<unsigned long long> tl(kTimelineWords);
+        if (hipMemcpy(tl.data(), c->d_timeline, kTimelineWords * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[8] = {0};
+            int nw = 0;
+            for (size_t w = 0; w < kTimelineWords / 8; w++) {
+                double tot = 0;
+                for (int k = 0; k < 8; k++) tot += (double)tl[w * 8 + k];
+                if (tot == 0) continue;
+                nw++;
+                for (int k = 0; k < 8; k++) sum[k] += (double)tl[w * 8 + k];
+            }
+            double all = 0;
+            for (double v : sum) all += v;
+            static const char *name[8] = {"P1", "wait B1", "P2", "wait B2", "P3-5", "wait B3", "epilogue", "wait B4"};
+            std::fprintf(stderr, "phase accounting over %d waves (clock64 ticks per wave, share):\n", nw);
+            for (int k = 0; k < 8; k++)
+                std::fprintf(stderr, "  %-9s %10.0f  %5.1f %%\n", name[k], sum[k] / (nw ? nw : 1), 100.0 * sum[k] / (all ? all : 1));
+        }
+        (void)hipFree(c->d_timeline);
+    } else if (c->d_timeline) {
         // profiling aid: dump the stamps of the last scan on the way out
         unsigned long long tl[512];
         if (hipMemcpy(tl, c->d_timeline, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess)
@@ -760,6 +784,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.3 gfx950 scan=v2-wave-private"; }
+const char *adsb_version(void) { return "adsb_hip 0.4 gfx950 scan=v3-dual-slot"; }
 
 }  // extern "C"

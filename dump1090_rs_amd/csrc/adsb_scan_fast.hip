@@ -69,9 +69,27 @@ static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
 constexpr int kWaves = kThreads / 64;
 constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
 constexpr int kRoundBits = 4;                 // plane bits per round when they do not fit: 64 x 4 <= 256
-constexpr int kCandPerWave = 128;             // a wave's candidates waiting for the trial stage
-static_assert(64 * kRoundBits <= kPatPerWave && kCandPerWave >= 128, "wave-private regions");
+#ifndef ADSB_GATE_SLOTS
+#define ADSB_GATE_SLOTS 1
+#endif
+#ifndef ADSB_TRIAL_SLOTS
+#define ADSB_TRIAL_SLOTS 1
+#endif
+constexpr int kGateSlots = ADSB_GATE_SLOTS;   // pattern matches one lane gates per pass
+constexpr int kTrialSlots = ADSB_TRIAL_SLOTS; // trials one lane evaluates per pass
+constexpr int kCandPerWave = 64 + 64 * kGateSlots;  // a wave's candidates waiting for the trial stage
+static_assert(64 * kRoundBits <= kPatPerWave, "wave-private regions");
 constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
+
+// LDS accesses wider than their address is aligned are legal on gfx950 but replayed at 64
+// cycles (SQ_LDS_UNALIGNED_STALL); with unaligned-access-mode on (the default) the
+// compiler merges neighbouring u16 / u32 LDS reads into exactly those.  The scan kernel is
+// compiled with the mode off: merges only happen where alignment is known.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ADSB_NO_UNALIGNED __attribute__((target("no-unaligned-access-mode")))
+#else
+#define ADSB_NO_UNALIGNED
+#endif
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
 // would wait for the next tile's IQ prefetch at every phase boundary; here only LDS
@@ -135,7 +153,7 @@ constexpr uint32_t kBranchTerms[5] = {0x133u, 0x371u, 0x055u, 0x3D4u, 0x2CCu};
 struct alignas(16) FastLds {
     uint16_t mag[kAllocSlots];         // P1..P4
     uint32_t plane[kPlanes * kPlaneDw];
-    uint32_t tab[6 * 256];             // F0 F1 F2 X51_0 X51_1 X51_2
+    uint32_t tab[3 * 256];             // F'0 F'1 F'2 (adsb_tables.h)
     uint32_t r16[16];                  // x^24..x^27 reduction
     uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
     uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch terms << 13
@@ -143,6 +161,129 @@ struct alignas(16) FastLds {
     uint64_t hit[kHitCap];
     uint32_t nap, nhit, hit_base;
 };
+
+// P4, one pattern match: high / base_signal / base_noise of the branch that matched first
+// (demod_2400.rs:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
+// Branch-free; returns 1 when the position goes on to be sliced.
+__device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
+{
+    // one u16 LDS read per magnitude (no unpacking on the VALU).  The kernel is compiled
+    // without unaligned-access-mode (ADSB_NO_UNALIGNED below), or these would be merged into
+    // 8/16-byte reads at a 2-byte aligned address, which the LDS replays at 64 cycles each.
+    const uint16_t *pm = mag + (ent & 0x1FFFu);
+    const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
+              p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
+    const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
+    // 0 / -1 masks of the branch's terms (signed 1-bit field extracts)
+#define TERM(bit) __builtin_amdgcn_sbfe((int)ent, 13 + (bit), 1)
+    const int s39 = p3 + p9, s410 = p4 + p10;
+    const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
+    const int sig = (p1 & TERM(4)) + (s39 & TERM(5)) + (p12 & TERM(6)) + (s410 & TERM(7));
+    const int noise = p6 + p7 + (p5 & TERM(8)) + (p8 & TERM(9));
+#undef TERM
+    const int loud = max(max(max(p5, p6), max(p7, p8)), max(max(q14, q15), max(max(q16, q17), q18)));
+    return (uint32_t)(2 * sig >= 3 * noise) & (uint32_t)(loud < high);  // :129, :135-146
+}
+
+// candidate entry: slot | slot/12 << 13 | slot%12 << 23
+__device__ __forceinline__ uint32_t cand_entry(uint32_t slot)
+{
+    const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
+    return slot | (qs << 13) | ((slot - 12u * qs) << 23);
+}
+
+// P5, one trial.  Message bit n = 5k + r of trial phase tp sits at 5x-oversampled position
+// 5*(slot+19) + tp + 12n, i.e. sample slot + 19 + (tp+12r)/5 + 12k with slicer phase
+// (tp+12r) % 5: field r is 23 consecutive bits of one sign plane; which plane and where
+// comes from s.field.  Branch-free so that two trials per lane interleave.
+struct Trial {
+    uint32_t f[5];   // the five bit classes n mod 5 (bit k = message bit 5k + r)
+    uint32_t h;      // x^51 * H reduced: short messages' CRC residual as is (adsb_tables.h)
+    uint32_t code;   // try_phase - 4, + 5 for 112-bit messages
+    uint32_t cslot;
+    uint32_t flags;  // 1: address/parity trial, 2: self-validating hit, 4: hit that adds its address
+};
+
+__device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wcand, uint32_t t5, Trial &o)
+{
+    const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
+    const uint32_t tpi = t5 - 5u * c;
+    const uint32_t ce = wcand[c];
+    const uint32_t qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
+    o.cslot = ce & 0x1FFFu;
+    const uint32_t *ft = s.field + tpi * 60u + rs;
+    const char *plane_bytes = (const char *)s.plane;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t fe = ft[r * 12];
+        const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
+        // 4-byte aligned only: becomes one ds_read2_b32 (not an 8-byte read off its alignment,
+        // which is replayed at 64 cycles -- ADSB_NO_UNALIGNED)
+        const uint32_t *pl = (const uint32_t *)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
+        const uint32_t lo = pl[0], hi = pl[1];
+        o.f[r] = alignbit(hi, lo, qq);  // the shift is qq mod 32
+    }
+    const uint32_t *f = o.f;
+    // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
+    const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) | ((f[3] & 1u) << 1) | (f[4] & 1u);
+    const uint32_t lng = f[0] & 1u;  // DF >= 16: 112 bits
+    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks at all 14
+    // bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
+    const uint32_t nonzero = (uint32_t)((((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0);
+    const uint32_t mk0 = lng ? 0x7FFFFFu : 0xFFFu, mk1 = lng ? 0x7FFFFFu : 0x7FFu, mk2 = lng ? 0x3FFFFFu : 0x7FFu;
+    const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
+    // sum_r x^(4-r) * F'(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
+    const char *tF = (const char *)s.tab;
+    uint32_t g[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
+        g[r] = *(const uint32_t *)(tF + (x4 & 0x3FCu)) ^ *(const uint32_t *)(tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
+               *(const uint32_t *)(tF + 2048 + ((x4 >> 16) & 0x3FCu));
+    }
+    const uint32_t hp = ((g[0] << 4) ^ (g[1] << 3) ^ (g[2] << 2)) ^ ((g[3] << 1) ^ g[4]);
+    const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
+    o.h = h;
+    o.code = tpi + 5u * lng;
+    // DF classes as bit sets indexed by DF (mod.rs:56-135)
+    const uint32_t ap = (0xFF310031u >> df) & 1u;           // 0,4,5,16,20,21,24..31: address/parity
+    const uint32_t d1718 = (0x00060000u >> df) & 1u;        // clean iff residual == 0
+    const uint32_t d11 = (0x00000800u >> df) & 1u;          // clean iff residual & 0xFFFF80 == 0
+    const uint32_t z = (uint32_t)(h == 0), z11 = (uint32_t)((h & 0xFFFF80u) == 0);
+    const uint32_t hit = (d1718 & z) | (d11 & z11);
+    // DF17 and DF11 with IID 0 add their address; DF18 adds addr | 1 << 25, never matched
+    const uint32_t learn = z & (((0x00020800u >> df) & 1u));
+    o.flags = nonzero * (ap | (hit << 1) | (learn << 2));
+}
+
+__device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 8..31
+{
+    uint32_t addr = 0;
+#pragma unroll
+    for (int n = 8; n < 32; n++) addr |= ((t.f[n % 5] >> (n / 5)) & 1u) << (31 - n);
+    return addr;
+}
+
+// a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
+__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane)
+{
+    const unsigned long long mh = __ballot(is_hit);
+    if (!mh) return;
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
+    if (is_hit) {
+        if (at < (uint32_t)kHitCap) {
+            s.hit[at] = entry;
+        } else {  // more hits in one tile than the staging holds: one by one
+            const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
+            if (gi < p.hits_cap)
+                p.hits[gi] = entry;
+            else
+                atomicOr(&p.ctr->overflow, 1u);
+        }
+    }
+}
 
 // IQ of one tile, as each thread holds it between the load and the magnitude pass:
 // 8 aligned dwordx4 = 32 samples per thread, 8080 per workgroup.
@@ -187,14 +328,25 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
 // profiling aid: wave 0 of a few workgroups stamps the shader clock at phase boundaries
 #define STAMP(slot)                                                                          \
     do {                                                                                     \
-        if (p.timeline && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
+        if (p.timeline && p.debug_stop != 100 && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
             p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
+    } while (0)
+
+// profiling aid (ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2): every wave totals the clocks it
+// spends in each phase and waiting at each workgroup barrier
+#define ACCT(k)                                                   \
+    do {                                                          \
+        if (acct) {                                               \
+            const unsigned long long now_ = clock64();            \
+            acc_t[k] += now_ - acc_last;                          \
+            acc_last = now_;                                      \
+        }                                                         \
     } while (0)
 
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
 // after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParams p)
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
     const int tid = threadIdx.x;
@@ -202,7 +354,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
     const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
 
     // ---------------------------------------------------------------- P0 once per workgroup
-    for (int i = tid; i < 6 * 256; i += kThreads) s.tab[i] = p.tables[i];
+    for (int i = tid; i < 3 * 256; i += kThreads) s.tab[i] = p.tables[kTabF * 256 + i];
     for (int i = tid; i < 316; i += kThreads) {
         const uint32_t v = p.tables[kTabR16Off + i];
         if (i < 16)
@@ -228,6 +380,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
         while ((unsigned long long)clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 
+    const bool acct = p.debug_stop == 100 && p.timeline != nullptr;
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
+
     uint32_t iter = 0;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x, iter++) {
     const TileRef cur = tile_ref(p, t);
@@ -248,7 +403,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
         if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = mag4_of(pre[i]);
     }
     if (t + gridDim.x < n_tiles) load_tile_iq(p, tile_ref(p, t + gridDim.x), tid, pre);
+    ACCT(0);
     lds_barrier();
+    ACCT(1);
     STAMP(1);
     if (jn <= 0 || p.debug_stop == 1) {
         lds_barrier();
@@ -336,7 +493,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
             pb[(kPlaneGT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[6][r] >> 1);
         }
     }
+    ACCT(2);
     lds_barrier();
+    ACCT(3);
     STAMP(2);
     if (p.debug_stop == 2) continue;
 
@@ -395,6 +554,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
     // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
     const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
     uint32_t ncand_w = 0;  // candidates waiting in wcand (wave-uniform)
+    if (p.debug_stop == 3) goto tile_end;  // profiling: patterns only
 
     // One loop, one copy of each stage: take the next round of matches when the previous one
     // is used up, run one 64-lane pass of the gates, and run the trials whenever the
@@ -432,163 +592,101 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
             }
 
             // ------------------------------------------------------------ P4 value gates
-            // one lane per pattern match: high / base_signal / base_noise of the branch that
-            // matched first (:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
-            const uint32_t idx = base + (uint32_t)lane;
-            bool pass = false;
-            uint32_t slot = 0;
-            if (idx < npat_w) {
-                const uint32_t ent = wpat[idx];
-                slot = ent & 0x1FFFu;
-                // one u16 LDS read per magnitude (no unpacking on the VALU); volatile so that the
-                // compiler does not merge them into 8/16-byte reads at a 2-byte aligned address,
-                // which the LDS replays at 64 cycles each
-                typedef const volatile __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
-                lds_u16_ptr pm = (lds_u16_ptr)(s.mag + slot);
-                const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
-                          p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
-                // 0 / -1 masks of the branch's terms (signed 1-bit field extracts)
-#define TERM(bit) __builtin_amdgcn_sbfe((int)ent, 13 + (bit), 1)
-                const int s39 = p3 + p9, s410 = p4 + p10;
-                const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
-                const int sig = (p1 & TERM(4)) + (s39 & TERM(5)) + (p12 & TERM(6)) + (s410 & TERM(7));
-                const int noise = p6 + p7 + (p5 & TERM(8)) + (p8 & TERM(9));
-#undef TERM
-                const int loud = max(max(max(p5, p6), max(p7, p8)),
-                                     max(max((int)pm[14], (int)pm[15]), max(max((int)pm[16], (int)pm[17]), (int)pm[18])));
-                pass = (2 * sig >= 3 * noise) && (loud < high);  // :129, :135-146
-            }
-            const unsigned long long mask = __ballot(pass);
-            if (mask) {
-                if (pass) {
-                    const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
-                    wcand[ncand_w + mask_rank(mask)] = slot | (qs << 13) | ((slot - 12u * qs) << 23);
+            // one lane per pattern match, kGateSlots matches per lane and pass (gate_eval)
+            {
+                uint32_t ent[kGateSlots];
+                unsigned long long mask[kGateSlots];
+                bool pass[kGateSlots];
+                unsigned long long any = 0;
+#pragma unroll
+                for (int q = 0; q < kGateSlots; q++) {
+                    const uint32_t idx = base + (uint32_t)(lane + 64 * q);
+                    ent[q] = wpat[min(idx, npat_w - 1u)];
+                    pass[q] = (gate_eval(s.mag, ent[q]) & (uint32_t)(idx < npat_w)) != 0;
                 }
-                ncand_w += (uint32_t)__popcll(mask);
+#pragma unroll
+                for (int q = 0; q < kGateSlots; q++) any |= (mask[q] = __ballot(pass[q]));
+                if (any) {
+#pragma unroll
+                    for (int q = 0; q < kGateSlots; q++) {
+                        if (pass[q]) wcand[ncand_w + mask_rank(mask[q])] = cand_entry(ent[q] & 0x1FFFu);
+                        ncand_w += (uint32_t)__popcll(mask[q]);
+                    }
+                }
             }
-            base += 64;
+            base += 64 * kGateSlots;
             if (base >= npat_w) {
                 in_round = false;
                 round++;
             }
             // room for another pass of the gates and more of them to come: not yet
-            if (round < nrounds && ncand_w + 64 <= (uint32_t)kCandPerWave) continue;
+            if (round < nrounds && ncand_w + 64 * kGateSlots <= (uint32_t)kCandPerWave) continue;
         }
         if (ncand_w == 0) {
             if (round >= nrounds) break;
             continue;
         }
         wave_lds_fence();
+        if (p.debug_stop == 4) {  // profiling: gates only
+            ncand_w = 0;
+            if (round >= nrounds) break;
+            continue;
+        }
 
         // ---------------------------------------------------------------- P5 trials
-        // lane = (candidate, try_phase).  Message bit n = 5k + r of trial phase tp sits at
-        // 5x-oversampled position 5*(slot+19) + tp + 12n, i.e. sample
-        // slot + 19 + (tp+12r)/5 + 12k with slicer phase (tp+12r) % 5: field r is 23
-        // consecutive bits of one sign plane; which plane and where comes from s.field.
+        // lane = (candidate, try_phase), kTrialSlots trials per lane and pass (trial_eval).
         {
             const uint32_t ntrial = ncand_w * 5u;
             cand_count += ncand_w;
             ncand_w = 0;
-            const uint32_t *tF = s.tab, *tX51 = s.tab + 3 * 256;
-            const char *plane_bytes = (const char *)s.plane;
-            for (uint32_t tb = 0; tb < ntrial; tb += 64) {
-                const uint32_t t5 = tb + (uint32_t)lane;
-                bool is_hit = false, is_ap = false;
-                uint32_t e_lo = 0, e_hi = 0;
-                if (t5 < ntrial) {
-                    const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
-                    const uint32_t tpi = t5 - 5u * c;
-                    const uint32_t ce = wcand[c];
-                    const uint32_t cslot = ce & 0x1FFFu, qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
-                    const uint32_t *ft = s.field + tpi * 60u + rs;
-                    uint32_t f[5];
+            for (uint32_t tb = 0; tb < ntrial; tb += 64 * kTrialSlots) {
+                Trial tr[kTrialSlots];
+                uint64_t entry[kTrialSlots];
+                bool is_ap[kTrialSlots], is_hit[kTrialSlots], learn[kTrialSlots];
+                unsigned long long ma[kTrialSlots];
+                unsigned long long any_ap = 0, any_hit = 0, any_learn = 0;
 #pragma unroll
-                    for (int r = 0; r < 5; r++) {
-                        const uint32_t fe = ft[r * 12];
-                        const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
-                        // two dword reads on purpose: the address is only 4-byte aligned, and a
-                        // merged 8-byte read off its alignment is replayed at 64 cycles
-                        typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
-                        lds_u32_ptr pl = (lds_u32_ptr)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
-                        const uint32_t lo = pl[0], hi = pl[1];  // volatile: stays two 4-byte reads
-                        f[r] = alignbit(hi, lo, qq & 31u);
-                    }
-                    // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
-                    const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) |
-                                        ((f[3] & 1u) << 1) | (f[4] & 1u);
-                    const bool is_long = df >= 16;
-                    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks
-                    // at all 14 bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
-                    const bool nonzero = (((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0;
-                    const uint32_t mk0 = is_long ? 0x7FFFFFu : 0xFFFu, mk1 = is_long ? 0x7FFFFFu : 0x7FFu,
-                                   mk2 = is_long ? 0x3FFFFFu : 0x7FFu;
-                    const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
-                    // H' = sum_r x^(4-r) * F(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
-                    uint32_t hp = 0;
-#pragma unroll
-                    for (int r = 0; r < 5; r++) {
-                        const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
-                        const uint32_t g = *(const uint32_t *)((const char *)tF + (x4 & 0x3FCu)) ^
-                                           *(const uint32_t *)((const char *)tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
-                                           *(const uint32_t *)((const char *)tF + 2048 + ((x4 >> 16) & 0x3FCu));
-                        hp ^= g << (4 - r);
-                    }
-                    const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
-
-                    const bool df11 = df == 11, df1718 = df == 17 || df == 18;
-                    const bool ap_short = df == 0 || df == 4 || df == 5;
-                    const bool ap_long = df == 16 || df == 20 || df == 21 || df >= 24;
-                    bool learn = false;  // the host replay will add this address to the filter
-                    if (nonzero) {
-                        if (df1718) {                       // mod.rs:91-109: clean iff H == 0
-                            is_hit = h == 0;
-                            learn = is_hit && df == 17;     // DF18 adds addr|1<<25: never matched
-                        } else if (df11) {                  // mod.rs:73-90
-                            const uint32_t crc = tX51[h & 255u] ^ tX51[256 + ((h >> 8) & 255u)] ^ tX51[512 + (h >> 16)];
-                            is_hit = (crc & 0xFFFF80u) == 0;
-                            learn = is_hit && (crc & 0x7Fu) == 0;
-                        } else {
-                            is_ap = ap_short || ap_long;    // mod.rs:56-72, 110-135
-                        }
-                    }
+                for (int q = 0; q < kTrialSlots; q++) {
+                    const uint32_t t5 = tb + (uint32_t)(lane + 64 * q);
+                    trial_eval(s, wcand, min(t5, ntrial - 1u), tr[q]);
+                    const uint32_t fl = t5 < ntrial ? tr[q].flags : 0u;
+                    is_ap[q] = (fl & 1u) != 0;
+                    is_hit[q] = (fl & 2u) != 0;
+                    learn[q] = (fl & 4u) != 0;
                     // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
-                    const uint32_t j = (uint32_t)(jbase - kPad) + cslot;
-                    const uint32_t code = tpi + (is_long ? 5u : 0u);
-                    e_lo = h | (code << 24) | (j << 28);
-                    e_hi = (j >> 4) | (chunk << 13);
-                    if (learn) {
-                        uint32_t addr = 0;  // message bits 8..31
-#pragma unroll
-                        for (int n = 8; n < 32; n++) addr |= ((f[n % 5] >> (n / 5)) & 1u) << (31 - n);
-                        bitmap_set(p.bitmap, addr);
-                    }
+                    const uint32_t j = (uint32_t)(jbase - kPad) + tr[q].cslot;
+                    entry[q] = ((uint64_t)((j >> 4) | (chunk << 13)) << 32) | (tr[q].h | (tr[q].code << 24) | (j << 28));
                 }
-                const uint64_t entry = ((uint64_t)e_hi << 32) | e_lo;
+#pragma unroll
+                for (int q = 0; q < kTrialSlots; q++) {
+                    any_ap |= (ma[q] = __ballot(is_ap[q]));
+                    any_hit |= __ballot(is_hit[q]);
+                    any_learn |= __ballot(learn[q]);
+                }
                 // AP entries: straight into this workgroup's own segment, compacted per wave;
                 // s.nap is the workgroup's fill count for this tile
-                const unsigned long long ma = __ballot(is_ap);
-                if (ma) {
+                if (any_ap) {
+                    uint32_t total = 0;
+#pragma unroll
+                    for (int q = 0; q < kTrialSlots; q++) total += (uint32_t)__popcll(ma[q]);
                     uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s.nap, (uint32_t)__popcll(ma));
-                    at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(ma);
-                    if (is_ap && at < seg_cap) seg[at] = entry;
-                }
-                const unsigned long long mh = __ballot(is_hit);
-                if (mh) {  // rare
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
-                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
-                    if (is_hit) {
-                        if (at < (uint32_t)kHitCap) {
-                            s.hit[at] = entry;
-                        } else {  // more hits in one tile than the staging holds: one by one
-                            const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
-                            if (gi < p.hits_cap)
-                                p.hits[gi] = entry;
-                            else
-                                atomicOr(&p.ctr->overflow, 1u);
-                        }
+                    if (lane == 0) at = atomicAdd(&s.nap, total);
+                    at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+#pragma unroll
+                    for (int q = 0; q < kTrialSlots; q++) {
+                        const uint32_t mine = at + mask_rank(ma[q]);
+                        if (is_ap[q] && mine < seg_cap) seg[mine] = entry[q];
+                        at += (uint32_t)__popcll(ma[q]);
                     }
+                }
+                if (any_hit) {  // rare
+#pragma unroll
+                    for (int q = 0; q < kTrialSlots; q++) stage_hit(p, s, is_hit[q], entry[q], lane);
+                }
+                if (any_learn) {  // rare: the host replay will add this address to the filter
+#pragma unroll
+                    for (int q = 0; q < kTrialSlots; q++)
+                        if (learn[q]) bitmap_set(p.bitmap, trial_addr(tr[q]));
                 }
             }
             wave_lds_fence();  // wcand is reused by the next passes of the gates
@@ -596,7 +694,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
         if (round >= nrounds) break;
     }
     }
+tile_end:
+    ACCT(4);
     lds_barrier();
+    ACCT(5);
     STAMP(5);
     if (p.debug_stop == 5) {
         lds_barrier();
@@ -621,9 +722,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_scan_fast(ScanParam
             for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
         }
     }
+    ACCT(6);
     lds_barrier();  // counters and lists are reset / reused by the next tile
+    ACCT(7);
     STAMP(6);
     }  // tile loop
+    if (acct && lane == 0)
+        for (int k = 0; k < 8; k++) p.timeline[((size_t)blockIdx.x * kWaves + (tid >> 6)) * 8 + k] = acc_t[k];
     // candidate counts were kept per wave (diagnostic): lane 0 of each wave adds its own
     if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
     if (tid == 0) p.ctr->seg_ap[blockIdx.x] = ap_count;

@@ -10,10 +10,11 @@
 // y = x^-5 mod g:
 //     M(x) = sum_r x^(bits-1-r) * F(f_r),      F(f) = sum_k f[k] * y^k
 //          = x^(bits-5) * H,                   H = sum_r x^(4-r) * F(f_r)   (Horner in x)
-// F is three 256-entry table lookups (one per byte of the field); the constant
-// multipliers x^51 (bits = 56) and x^107 (bits = 112) are three lookups each and are
-// only applied where the residual's value matters (DF11 in the scan kernel, address/
-// parity trials in the match kernel).  A clean DF17/18 is simply H == 0.
+// The tables hold F' = x^51 * F (three 256-entry lookups, one per byte of the field), so
+// H' = x^51 * H is the residual itself for 56-bit messages (DF11's test and the short
+// address/parity trials need nothing more) and x^56 * H' for 112-bit ones; that constant
+// multiplier is three more lookups, applied only in the match kernel.  A clean DF17/18 is
+// simply H' == 0 (x is invertible mod g).
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -35,38 +36,34 @@ inline uint32_t gf_divx(uint32_t a)
     return (a & 1u) ? ((a ^ kCrcPoly) >> 1) | 0x800000u : a >> 1;
 }
 
-// tables[t][v]: t = kTabF+b: sum of y^(8b+i) over set bits i of v
-//               t = kTabX51+b / kTabX107+b: (v << 8b) * x^51 / x^107
+// tables[t][v]: t = kTabF+b:   x^51 * sum of y^(8b+i) over set bits i of v
+//               t = kTabX56+b: (v << 8b) * x^56
 inline std::vector<uint32_t> build_gf_tables()
 {
-    std::vector<uint32_t> t(9 * 256, 0);
+    std::vector<uint32_t> t(6 * 256, 0);
     // powers of y = x^-5
     uint32_t ypow[24];
     uint32_t p = 1;
+    for (int e = 0; e < 51; e++) p = gf_mulx(p);  // x^51 folded into F
     for (int k = 0; k < 24; k++) {
         ypow[k] = p;
         for (int s = 0; s < 5; s++) p = gf_divx(p);
     }
-    // x^51 * x^i and x^107 * x^i for i = 0..23
-    uint32_t x51[24], x107[24];
+    // x^56 * x^i for i = 0..23
+    uint32_t x56[24];
     p = 1;
-    for (int e = 0; e < 51; e++) p = gf_mulx(p);
-    for (int i = 0; i < 24; i++, p = gf_mulx(p)) x51[i] = p;
-    p = 1;
-    for (int e = 0; e < 107; e++) p = gf_mulx(p);
-    for (int i = 0; i < 24; i++, p = gf_mulx(p)) x107[i] = p;
+    for (int e = 0; e < 56; e++) p = gf_mulx(p);
+    for (int i = 0; i < 24; i++, p = gf_mulx(p)) x56[i] = p;
     for (int b = 0; b < 3; b++)
         for (uint32_t v = 0; v < 256; v++) {
-            uint32_t f = 0, a = 0, c = 0;
+            uint32_t f = 0, a = 0;
             for (int i = 0; i < 8; i++)
                 if (v & (1u << i)) {
                     f ^= ypow[8 * b + i];
-                    a ^= x51[8 * b + i];
-                    c ^= x107[8 * b + i];
+                    a ^= x56[8 * b + i];
                 }
             t[(0 + b) * 256 + v] = f;
             t[(3 + b) * 256 + v] = a;
-            t[(6 + b) * 256 + v] = c;
         }
     return t;
 }
