@@ -232,6 +232,19 @@ def main():
         c0 = time.perf_counter()
         want, _ = orc.demod_iq(host, cap=cap)
         cpu_s = time.perf_counter() - c0
+        # the same buffer over all host cores (workers per buffer + ordered replay)
+        n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), args.chunks))
+        mt_s = None
+        if n_thr > 1:
+            orc_mt = binding.Oracle()
+            orc_mt.icao_flush()
+            orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
+            orc_mt.icao_flush()
+            c0 = time.perf_counter()
+            want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr)
+            mt_s = time.perf_counter() - c0
+            if want_mt != want:
+                raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
         ctx.icao_flush()
         got = ctx.demod_iq_device(bufs[0].data_ptr(), n, cap=cap)
         same = [(m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level) for m in got] == \
@@ -246,6 +259,10 @@ def main():
             "cpu": _cpu_model(),
             "host_cores_available": os.cpu_count(),
         }
+        if mt_s:
+            result["cpu_baseline"]["all_cores"] = {
+                "value": round(n / mt_s / 1e6, 2), "unit": "Msamples/s", "cores": n_thr,
+                "sample": f"the same buffer, {n_thr} threads over the 131072-sample buffers + ordered replay, {mt_s:.2f} s"}
         result["parity_checked"] = bool(same)
         result["parity_frames"] = len(want)
         if not same:

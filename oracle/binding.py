@@ -33,7 +33,7 @@ class OrcFilter(C.Structure):
 
 
 def build(force: bool = False) -> Path:
-    src = [HERE / "dump1090_oracle.c", HERE / "dump1090_oracle.h", HERE / "Makefile"]
+    src = [HERE / "dump1090_oracle.c", HERE / "dump1090_oracle_mt.c", HERE / "dump1090_oracle.h", HERE / "Makefile"]
     if force or not LIB_PATH.exists() or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in src):
         subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "liboracle.so"], check=True)
     return LIB_PATH
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         L.orc_demodulate2400.restype = sz
         L.orc_demod_iq.argtypes = [vp, vp, sz, vp, sz, vp]
         L.orc_demod_iq.restype = sz
+        L.orc_demod_iq_mt.argtypes = [vp, vp, sz, vp, sz, vp, C.c_int]
+        L.orc_demod_iq_mt.restype = sz
         L.orc_read_test_data.argtypes = [C.c_char_p, vp, sz]
         L.orc_read_test_data.restype = C.c_long
         L.orc_mag_x_digest.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
@@ -117,12 +119,17 @@ class Oracle:
         assert n <= cap
         return [unpack(m) for m in out[:n]], st
 
-    def demod_iq(self, iq, cap: Optional[int] = None):
+    def demod_iq(self, iq, cap: Optional[int] = None, threads: int = 1):
+        """threads > 1: workers per buffer + ordered replay (dump1090_oracle_mt.c), same result"""
         a = as_iq(iq)
         cap = cap or max(4096, a.shape[0] // 64)
         out = (OrcMsg * cap)()
         st = OrcStats()
-        n = self.L.orc_demod_iq(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap, C.byref(st))
+        if threads > 1:
+            n = self.L.orc_demod_iq_mt(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap,
+                                       C.byref(st), threads)
+        else:
+            n = self.L.orc_demod_iq(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap, C.byref(st))
         assert n <= cap, "oracle output overflowed its buffer"
         return [unpack(m) for m in out[:n]], st
 

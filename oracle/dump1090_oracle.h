@@ -1,7 +1,7 @@
 /*
  * oracle/dump1090_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
- * Plain-C, single-threaded CPU restatement of the demod_2400 hot path of
+ * Plain-C CPU restatement of the demod_2400 hot path of
  * rsadsb/dump1090_rs v0.8.1 (reference @ /root/reference).  It exists so the
  * HIP path can be checked bit-for-bit; it is NOT part of the product.  Only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
@@ -121,6 +121,13 @@ size_t orc_all_trials(const orc_magbuf *mag, uint64_t chunk, orc_trial *out, siz
  * filter persisting across buffers.  Returns total messages found. */
 size_t orc_demod_iq(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
                     orc_msg *out, size_t cap, orc_stats *stats);
+
+/* orc_demod_iq over `threads` host threads (dump1090_oracle_mt.c): workers run to_mag, the
+ * gates and the slicer per buffer, one thread replays the trials in order through the
+ * filter.  Same result as orc_demod_iq; stats->preamble_pass / snr_pass count only the
+ * positions that were sliced. */
+size_t orc_demod_iq_mt(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
+                       orc_msg *out, size_t cap, orc_stats *stats, int threads);
 
 /* src/utils.rs:23-40 read_test_data: file order is [im][re] little-endian i16;
  * writes in-memory {re, im} pairs.  Returns samples read or -1. */

@@ -225,3 +225,23 @@ def test_chunking_keeps_filter_and_has_no_carry_over(oracle_mod, fixture_iq, gol
     assert [(m["chunk"], m["j"], m["buffer"]) for m in msgs] == want
     # the filter carried over: buffer 2 now knows addresses from buffers 0 and 1
     assert len(msgs) >= 16
+
+
+def test_threaded_oracle_matches_single_thread(oracle_mod, fixture_iq):
+    """orc_demod_iq_mt (workers per buffer + ordered replay) == orc_demod_iq, frame for frame:
+    on the three reference captures back to back (filter carried across buffers) and on
+    synthetic IQ with address/parity traffic and a ragged last buffer."""
+    import numpy as np
+    from dump1090_rs_amd import synth
+
+    three = np.concatenate([fixture_iq[k] for k in sorted(fixture_iq)])
+    dense = synth.make_iq(9 * 131072 + 4321, n_bursts=150, seed=11, n_icao=12, df11_every=5)
+    for iq in (three, dense):
+        one = oracle_mod.Oracle()
+        want, st1 = one.demod_iq(iq)
+        for threads in (2, 5):
+            many = oracle_mod.Oracle()
+            got, stn = many.demod_iq(iq, threads=threads)
+            assert got == want
+            assert (stn.trials, stn.frames, stn.quiet_pass) == (st1.trials, st1.frames, st1.quiet_pass)
+        assert len(want) > 0
