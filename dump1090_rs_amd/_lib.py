@@ -47,6 +47,17 @@ class AdsbStats(C.Structure):
     ]
 
 
+class AdsbTrial(C.Structure):
+    """adsb_trial (include/adsb_hip.h): one raw trial message, before scoring."""
+    _fields_ = [
+        ("power", C.c_uint64),
+        ("chunk", C.c_uint32),
+        ("j_tp", C.c_uint32),
+        ("msg", C.c_uint8 * 14),
+        ("pad", C.c_uint16),
+    ]
+
+
 class AdsbError(RuntimeError):
     def __init__(self, status: int, what: str, detail: str = ""):
         self.status = status
@@ -94,6 +105,8 @@ def lib() -> C.CDLL:
     L.adsb_read_test_data.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
     L.adsb_get_stats.argtypes = [vp, C.POINTER(AdsbStats)]
     L.adsb_replay_records.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_shard_scan.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_shard_finish.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.adsb_selftest_mag_digest.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.adsb_strerror.argtypes = [C.c_int]
     L.adsb_strerror.restype = C.c_char_p
@@ -104,7 +117,8 @@ def lib() -> C.CDLL:
                  "adsb_to_mag", "adsb_demodulate2400", "adsb_demod_iq", "adsb_demod_iq_device",
                  "adsb_read_test_data", "adsb_get_stats", "adsb_replay_records",
                  "adsb_selftest_mag_digest", "adsb_submit_iq_device", "adsb_collect", "adsb_pending",
-                 "adsb_ring_create", "adsb_ring_acquire", "adsb_ring_submit"):
+                 "adsb_ring_create", "adsb_ring_acquire", "adsb_ring_submit", "adsb_shard_scan",
+                 "adsb_shard_finish"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

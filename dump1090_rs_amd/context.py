@@ -64,6 +64,28 @@ def _as_iq(iq) -> np.ndarray:
     return a
 
 
+# adsb_trial as a numpy record (32 bytes)
+TRIAL_DTYPE = np.dtype([("power", "<u8"), ("chunk", "<u4"), ("j_tp", "<u4"), ("msg", "u1", (14,)), ("pad", "<u2")])
+
+
+def replay_records(records: np.ndarray, filter_table: Optional[np.ndarray] = None, cap: Optional[int] = None
+                   ) -> List["ModeSMessage"]:
+    """adsb_replay_records: the ordered host replay (scoring + best-of-5 + ICAO filter) over raw
+    trial records; `filter_table` (4096 u32, table A of the filter) is read and updated."""
+    L = _lib.lib()
+    rec = np.ascontiguousarray(records, dtype=TRIAL_DTYPE).copy()
+    table = filter_table if filter_table is not None else np.zeros(4096, dtype=np.uint32)
+    assert table.dtype == np.uint32 and table.shape == (4096,) and table.flags.c_contiguous
+    cap = cap or max(4096, rec.shape[0])
+    out = (AdsbMsg * cap)()
+    n = C.c_size_t()
+    st = L.adsb_replay_records(table.ctypes.data, rec.ctypes.data, rec.shape[0], out, cap, C.byref(n))
+    if st != _lib.ADSB_OK:
+        raise AdsbError(st, f"adsb_replay_records: {L.adsb_strerror(st).decode()}")
+    return [ModeSMessage(bytes(m.msg), int(m.len), float(m.signal_level), int(m.score), int(m.j),
+                         int(m.try_phase), int(m.chunk)) for m in out[: n.value]]
+
+
 class Context:
     """One adsb_ctx: device buffers, stream and the ICAO filter of one stream of IQ."""
 
@@ -173,6 +195,36 @@ class Context:
 
     def collect(self, cap: int = 1 << 16) -> List[ModeSMessage]:
         return self._collect(lambda out, c, n: self._L.adsb_collect(self._h, out, c, n), "adsb_collect", cap)
+
+    # -- sharded capture: two phases around a host-side exchange of learned addresses
+    def shard_scan(self, device_ptr: int, n_samples: int) -> np.ndarray:
+        """Phase 1 on this shard: the addresses its clean DF11 / DF17 frames will add (sorted u32)."""
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            n = C.c_size_t()
+            st = self._L.adsb_shard_scan(self._h, C.c_void_p(device_ptr), n_samples, out.ctypes.data, cap,
+                                         C.byref(n))
+            if st == _lib.ADSB_ERR_CAPACITY:  # the shard stays parked: finish it, then retry bigger
+                self._L.adsb_shard_finish(self._h, None, 0, None, 0, None)
+                cap = n.value
+                continue
+            self._check(st, "adsb_shard_scan")
+            return out[: n.value].copy()
+
+    def shard_finish(self, extra_addrs, cap: Optional[int] = None) -> np.ndarray:
+        """Phase 2: add the other shards' addresses, match, return the raw trial records
+        (structured array with the layout of adsb_trial; `chunk` is local to the shard)."""
+        extra = np.ascontiguousarray(extra_addrs, dtype=np.uint32)
+        cap = cap or (1 << 20)
+        rec = np.zeros(cap, dtype=TRIAL_DTYPE)
+        n = C.c_size_t()
+        st = self._L.adsb_shard_finish(self._h, extra.ctypes.data if extra.size else None, extra.size,
+                                       rec.ctypes.data, cap, C.byref(n))
+        if st == _lib.ADSB_ERR_CAPACITY:
+            raise AdsbError(st, f"adsb_shard_finish: {n.value} records exceed cap {cap}")
+        self._check(st, "adsb_shard_finish")
+        return rec[: n.value].copy()
 
     # -- streaming ring: pinned host buffers, H2D overlapped with the other slot's pass
     def ring_create(self, samples_per_slot: int) -> None:

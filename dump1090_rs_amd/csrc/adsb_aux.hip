@@ -222,7 +222,19 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         }
     }
     __syncthreads();
+    if (p.keep_counters) {  // first phase of a shard: the match still has to see the lists
+        if (threadIdx.x == 0) p.ctr->blocks_done = 0;
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) ((uint32_t *)p.ctr)[i] = 0;
+}
+
+// addresses learned elsewhere (other shards of the same capture) join the superset
+__global__ __launch_bounds__(256) void k_set_addresses(const uint32_t *__restrict__ addrs, uint32_t n,
+                                                       uint32_t *bitmap)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bitmap_set(bitmap, addrs[i] & 0xFFFFFFu);
 }
 
 // ---------------------------------------------------------------------------
@@ -289,6 +301,14 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
         hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     else
         hipLaunchKernelGGL(k_records<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_set_addresses, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_addrs, n,
+                       bitmap);
     return hip_ok(hipGetLastError());
 }
 

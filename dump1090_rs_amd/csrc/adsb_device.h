@@ -111,6 +111,7 @@ struct ScanParams {
     uint32_t stagger_ticks; // fast scan: start offset between the workgroups of a CU (clock64 ticks)
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
+    uint32_t keep_counters; // records kernel: leave the counters and lists as they are (first phase of a shard)
 };
 
 // launches; all asynchronous on `stream`, return a hipError_t as int
@@ -122,6 +123,8 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);
+// OR a list of 24-bit addresses into a bitmap (addresses learned by other shards)
+int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream);
 int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream);
 
 }  // namespace adsb

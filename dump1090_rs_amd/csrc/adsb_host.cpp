@@ -89,6 +89,12 @@ struct adsb_ctx {
     size_t ring_samples = 0;
     hipStream_t copy_stream = nullptr;
 
+    // sharded capture (adsb_shard_scan / adsb_shard_finish): the pass parked between its two phases
+    bool shard_active = false;
+    ScanParams shard_params{};
+    uint32_t *d_addrs = nullptr;
+    size_t addrs_cap = 0;
+
     IcaoFilter filter;
     Crc24 crc;
     adsb_stats stats{};
@@ -293,7 +299,7 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples)
     const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks == 0 || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
     Slot &sl = c->slot[c->submitted % kSlots];
-    if (sl.busy) return ADSB_ERR_BUSY;
+    if (sl.busy || c->shard_active) return ADSB_ERR_BUSY;
     int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks);
     if (rc) return rc;
     sl.busy = true;
@@ -487,6 +493,7 @@ void adsb_destroy(adsb_ctx *c)
         if (r.h_iq) (void)hipHostFree(r.h_iq);
         if (r.d_iq) (void)hipFree(r.d_iq);
     }
+    if (c->d_addrs) (void)hipFree(c->d_addrs);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->d_timeline && c->debug_stop == 100) {
         // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves
@@ -744,6 +751,151 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
 
 static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors TrialRecord");
 
+// ---------------------------------------------------------------------------------
+// Sharded capture: one capture cut into contiguous ranges of buffers, one
+// range per GPU.  The only thing that couples the shards is the order-dependent ICAO
+// filter, so a shard runs in two phases around a tiny host-side exchange:
+//   adsb_shard_scan    scan the shard; return the addresses its self-validating frames
+//                      will add to the filter (DF11 with IID 0, DF17)
+//   (exchange)         every shard receives the union of all shards' addresses
+//   adsb_shard_finish  add them to the shard's superset bitmap, match the address/parity
+//                      trials against it, return the raw trial records
+// and whoever holds all records replays them once, in global (chunk, j, try_phase) order,
+// through one filter (adsb_replay_records).  The union is a superset in time of what the
+// filter can hold at any point of the capture, so the result is the single-stream one.
+// ---------------------------------------------------------------------------------
+int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32_t *addrs_out, size_t cap,
+                    size_t *n_addrs)
+{
+    if (!c || (!device_iq && n_samples) || (!addrs_out && cap)) return ADSB_ERR_INVALID;
+    if (c->submitted != c->collected || c->shard_active) return ADSB_ERR_BUSY;
+    if (n_addrs) *n_addrs = 0;
+    const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
+    if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+    if ((uintptr_t)device_iq % 16) return ADSB_ERR_INVALID;
+    Slot &sl = c->slot[0];
+    ScanParams p{};
+    p.src = device_iq;
+    p.n_samples = n_samples;
+    p.n_chunks = (uint32_t)n_chunks;
+    p.clean_bitmap = nullptr;
+    uint32_t *retired = nullptr;
+    if (c->flush_pending) {
+        retired = c->d_bitmap[c->cur_bitmap];
+        c->cur_bitmap = (c->cur_bitmap + 1) % 3;
+        c->filter.flush();
+        c->flush_pending = false;
+    }
+    p.bitmap = c->d_bitmap[c->cur_bitmap];
+    p.hits = sl.d_hits;
+    p.hits_cap = c->hits_cap;
+    p.ap = sl.d_ap;
+    p.ap_cap = c->ap_cap;
+    p.dap = c->d_dap;
+    p.dap_cap = c->dap_cap;
+    p.tables = c->d_tables;
+    p.ctr = sl.d_ctr;
+    p.summary = sl.h_sum_dev;
+    p.keep_counters = 1;
+    sl.seq = c->next_seq++;
+    if (c->next_seq == 0) c->next_seq = 1;
+    sl.h_sum->seq = 0;
+    p.seq = sl.seq;
+    size_t n_hits = 0;
+    if (n_chunks) {
+        if (int e = launch_scan(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
+        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
+            c->last_error = "shard scan completed without publishing its summary";
+            return ADSB_ERR_HIP;
+        }
+        if (sl.h_sum->overflow) {
+            // leave the device state clean for the next call
+            p.keep_counters = 0;
+            p.clean_bitmap = retired;
+            (void)launch_records(p, false, sl.h_rec_dev, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            c->last_error = "shard too dense for the device lists: use smaller shards";
+            return ADSB_ERR_HIP;
+        }
+        n_hits = sl.h_sum->n_hits;
+    }
+    // the addresses the replay will add: mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17)
+    std::vector<uint32_t> addrs;
+    for (size_t i = 0; i < n_hits; i++) {
+        const uint8_t *m = sl.h_rec[i].msg;
+        const uint32_t df = m[0] >> 3;
+        const bool adds = df == 17 || (df == 11 && c->crc.residual(m, 7) == 0);
+        if (adds) addrs.push_back(uint32_t(m[1]) << 16 | uint32_t(m[2]) << 8 | m[3]);
+    }
+    std::sort(addrs.begin(), addrs.end());
+    addrs.erase(std::unique(addrs.begin(), addrs.end()), addrs.end());
+    p.clean_bitmap = retired;
+    c->shard_params = p;
+    c->shard_active = true;
+    if (n_addrs) *n_addrs = addrs.size();
+    const size_t k = std::min(cap, addrs.size());
+    if (k) std::memcpy(addrs_out, addrs.data(), k * sizeof(uint32_t));
+    return addrs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, adsb_trial *records_out,
+                      size_t cap, size_t *n_records)
+{
+    if (!c || (!extra_addrs && n_extra) || (!records_out && cap)) return ADSB_ERR_INVALID;
+    if (!c->shard_active) return ADSB_ERR_INVALID;
+    if (n_records) *n_records = 0;
+    Slot &sl = c->slot[0];
+    ScanParams p = c->shard_params;
+    p.keep_counters = 0;
+    c->shard_active = false;
+    if (n_extra) {
+        if (n_extra > c->addrs_cap) {
+            if (c->d_addrs) (void)hipFree(c->d_addrs);
+            c->d_addrs = nullptr;
+            c->addrs_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_addrs, n_extra * sizeof(uint32_t)));
+            c->addrs_cap = n_extra;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_addrs, extra_addrs, n_extra * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  c->stream));
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, c->stream))
+            return fail(c, (hipError_t)e, "launch_set_addresses");
+    }
+    sl.seq = c->next_seq++;
+    if (c->next_seq == 0) c->next_seq = 1;
+    sl.h_sum->seq = 0;
+    p.seq = sl.seq;
+    size_t n = 0;
+    if (p.n_chunks) {
+        if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
+        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
+            c->last_error = "shard finish completed without publishing its summary";
+            return ADSB_ERR_HIP;
+        }
+        if (sl.h_sum->overflow) {
+            c->last_error = "shard too dense for the device lists: use smaller shards";
+            return ADSB_ERR_HIP;
+        }
+        n = sl.h_sum->n_hits;
+    }
+    adsb_stats st{};
+    st.n_samples = p.n_samples;
+    st.n_chunks = p.n_chunks;
+    st.n_candidates = p.n_chunks ? sl.h_sum->n_cand_total : 0;
+    st.n_ap_entries = p.n_chunks ? sl.h_sum->n_ap_total : 0;
+    st.n_records = n;
+    c->stats = st;
+    if (n_records) *n_records = n;
+    const size_t k = std::min(cap, n);
+    static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "record layout is the ABI's");
+    if (k) std::memcpy(records_out, sl.h_rec, k * sizeof(adsb_trial));
+    return n > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
 int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
                         size_t cap, size_t *n_out)
 {
@@ -784,6 +936,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.4 gfx950 scan=v3-dual-slot"; }
+const char *adsb_version(void) { return "adsb_hip 0.4 gfx950 scan=v3-flat-trials"; }
 
 }  // extern "C"

@@ -2,9 +2,16 @@
 
 The unit is the 131072-sample buffer (chunk): buffers are independent except for the ICAO
 filter (reference src/utils.rs:44, src/lib.rs:36-44: a fresh zeroed MagnitudeBuffer per
-call).  Each rank demodulates a contiguous range of buffers as its own stream, with its own
-context/filter -- the same thing as running one dump1090_rs per SDR.  torch.distributed is
-used for the barrier and for reducing the timing, nothing else.
+call).  Two ways to use N GPUs:
+
+* independent streams (the bench, BASELINE config 4): each rank demodulates a contiguous
+  range of buffers as its own stream, with its own context/filter -- the same thing as
+  running one dump1090_rs per SDR.  torch.distributed is used for the barrier and for
+  reducing the timing, nothing else.
+* one capture, exact (`demod_sharded`): the ranks' results are merged into what a single
+  stream would have produced.  The filter is the only coupling, so the exchange is host-side
+  and tiny: the addresses each shard learned (all_gather of a few u32) and the raw trial
+  records (gather to rank 0, a few per buffer), then one ordered replay on rank 0.
 """
 from __future__ import annotations
 
@@ -38,3 +45,62 @@ def reduce_timing(dist, elapsed_s: float, frames: int, device="cpu") -> Tuple[fl
     f = torch.tensor([frames], dtype=torch.int64, device=device)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     return float(t.item()), int(f.item())
+
+
+def merge_records(shard_records, chunk_bases):
+    """Concatenate the shards' raw trial records with `chunk` made global."""
+    import numpy as np
+
+    parts = []
+    for rec, base in zip(shard_records, chunk_bases):
+        r = rec.copy()
+        r["chunk"] = r["chunk"] + np.uint32(base)
+        parts.append(r)
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=shard_records[0].dtype)
+
+
+def exchange_addresses(dist, mine):
+    """Union of every rank's learned addresses (sorted u32).  Object collectives: a few KB."""
+    import numpy as np
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(mine, dtype=np.uint32)
+    lists = [None] * dist.get_world_size()
+    dist.all_gather_object(lists, np.asarray(mine, dtype=np.uint32).tobytes())
+    allv = np.concatenate([np.frombuffer(b, dtype=np.uint32) for b in lists]) if lists else np.zeros(0, np.uint32)
+    return np.unique(allv)
+
+
+def gather_records(dist, mine, chunk_base: int):
+    """All shards' records on rank 0, `chunk` global (None on the other ranks)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return merge_records([mine], [chunk_base])
+    import numpy as np
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((mine.tobytes(), int(chunk_base)), parts, dst=0)
+    if rank != 0:
+        return None
+    return merge_records([np.frombuffer(b, dtype=mine.dtype) for b, _ in parts], [base for _, base in parts])
+
+
+def demod_sharded(ctx, device_ptr: int, n_samples: int, chunk_base: int, dist=None, filter_table=None):
+    """One capture cut into contiguous buffer ranges, one per rank; this rank's range is the
+    `n_samples` at `device_ptr`, starting at global buffer index `chunk_base`.  Returns the
+    single-stream frame list on rank 0 (None elsewhere): identical to demodulating the whole
+    capture on one GPU or with the reference on a CPU (`filter_table`: rank 0's filter, read
+    and updated; default empty = after icao_flush)."""
+    from .context import replay_records
+
+    import numpy as np
+
+    learned = ctx.shard_scan(device_ptr, n_samples)
+    if filter_table is not None:  # what the filter already holds can match from the first sample on
+        learned = np.concatenate([learned, filter_table[filter_table != 0] & np.uint32(0xFFFFFF)])
+    union = exchange_addresses(dist, learned)
+    records = ctx.shard_finish(union)
+    merged = gather_records(dist, records, chunk_base)
+    if merged is None:
+        return None
+    return replay_records(merged, filter_table)

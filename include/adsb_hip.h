@@ -167,6 +167,28 @@ typedef struct {
     uint16_t pad;
 } adsb_trial;
 
+/* Sharded capture: one capture cut into contiguous ranges of 131072-sample buffers, one
+ * range per GPU (BASELINE config 4; the reference's loop dump1090_rs/src/main.rs:161-167
+ * is one stream with one process-global filter, src/icao_filter.rs:8-9).  Shards run
+ * independently except for that filter, so each runs in two phases around a small host-side
+ * exchange:
+ *   adsb_shard_scan    scans the shard (device_iq: this shard's samples, 16-byte aligned)
+ *                      and returns the 24-bit addresses its clean DF11 (IID 0) / DF17 frames
+ *                      will add to the filter (src/mode_s/mod.rs:80-84, 97-99), sorted;
+ *   the caller hands every shard the union of all shards' lists (a few KB);
+ *   adsb_shard_finish  adds them to the shard's address superset, matches the shard's
+ *                      address/parity trials against it and returns the raw trial records
+ *                      (chunk = buffer index within the shard).
+ * Whoever gathers all records adds each shard's first buffer index to `chunk` and replays
+ * them once with adsb_replay_records: the result is the single-stream one.  Between the two
+ * calls the context accepts no other work (ADSB_ERR_BUSY).  `cap` too small ->
+ * ADSB_ERR_CAPACITY with the required count in *n_addrs / *n_records; for
+ * adsb_shard_scan the shard stays parked and adsb_shard_finish may still be called. */
+int adsb_shard_scan(adsb_ctx *ctx, const void *device_iq, size_t n_samples, uint32_t *addrs_out,
+                    size_t cap, size_t *n_addrs);
+int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra,
+                      adsb_trial *records_out, size_t cap, size_t *n_records);
+
 /* Host only, no device needed: the ordered replay every demod call ends with
  * (score_modes_message src/mode_s/mod.rs:34-139 + best-of-5 selection
  * src/demod_2400.rs:149-207 + icao_filter src/icao_filter.rs), exposed so the

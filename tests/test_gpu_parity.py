@@ -350,3 +350,50 @@ def test_streaming_ring_pinned_double_buffering(hip_lib, oracle_mod):
             k += 1
     assert [(ch, m.j, m.try_phase, m.score, m.msg, m.signal_level) for ch, m in got] == \
         [(w["chunk"], w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"]) for w in want]
+
+
+def test_sharded_capture_two_phases_equal_single_stream(hip_lib, oracle_mod):
+    """one capture cut into two shards (two contexts standing in for two GPUs),
+    adsb_shard_scan -> address exchange -> adsb_shard_finish -> one ordered replay, against the
+    oracle over the whole capture; the DF4 of the second shard only decodes because the first
+    shard's DF17 taught its address."""
+    import torch
+    from dump1090_rs_amd import Context, sharding
+    from dump1090_rs_amd._lib import AdsbError, ADSB_ERR_BUSY
+    from dump1090_rs_amd.context import replay_records
+    from tests.test_sharding_gloo import _coupled_capture
+
+    n = 6 * 131072 + 999
+    iq, df4 = _coupled_capture(n)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    dev = torch.from_numpy(iq).cuda()
+    spans = [sharding.sample_range(n, 2, r) for r in range(2)]
+    ctxs = [Context(max_chunks=4), Context(max_chunks=4)]
+    try:
+        ptr = lambda a: dev.data_ptr() + 4 * a
+        learned = [c.shard_scan(ptr(a), b - a) for c, (a, b) in zip(ctxs, spans)]
+        assert 0x4840D6 in learned[0].tolist() and 0x4840D6 not in learned[1].tolist()
+        with pytest.raises(AdsbError) as busy:           # parked between the phases
+            ctxs[0].demod_iq_device(ptr(0), 131072)
+        assert busy.value.status == ADSB_ERR_BUSY
+        union = np.unique(np.concatenate(learned))
+        records = [c.shard_finish(union) for c in ctxs]
+        merged = sharding.merge_records(records, [a // 131072 for a, _ in spans])
+        got = replay_records(merged)
+        assert_same(got, want)
+        assert sorted(m.chunk for m in got if m.buffer() == df4) == [2, 4, 5]
+        assert len(merged) < 2000  # of ~49 000 trials: only self-validating and matched address/parity ones
+        # without the exchange the second shard drops its DF4s
+        ctxs[1].icao_flush()
+        ctxs[1].shard_scan(ptr(spans[1][0]), spans[1][1] - spans[1][0])
+        alone = ctxs[1].shard_finish(np.zeros(0, np.uint32))
+        assert not [m for m in replay_records(alone) if m.buffer() == df4]
+        # a single shard is the ordinary path
+        ctxs[0].icao_flush()
+        one = sharding.demod_sharded(ctxs[0], ptr(0), 3 * 131072, 0)
+        ctxs[0].icao_flush()
+        assert_same(one, oracle_mod.Oracle().demod_iq(iq[: 3 * 131072])[0])
+        assert_same(ctxs[0].demod_iq_device(ptr(0), 3 * 131072), oracle_mod.Oracle().demod_iq(iq[: 3 * 131072])[0])
+    finally:
+        for c in ctxs:
+            c.close()

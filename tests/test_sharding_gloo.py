@@ -78,3 +78,95 @@ def test_two_ranks_independent_streams_and_reduction(oracle_mod):
     merged = [(c + sharding.chunk_range(6, world, r)[0], j, f) for r, _, fr, _, _ in got for c, j, f in fr]
     assert [(m["chunk"], m["j"], m["buffer"]) for m in single if m["buffer"][0] >> 3 == 17] == \
         [x for x in merged if x[2][0] >> 3 == 17]
+
+
+# --- one capture, exact merge (sharding.demod_sharded's host side) -------------------------
+def _coupled_capture(n_samples):
+    """Bursts whose result depends on the filter state across the shard boundary: an
+    address/parity DF4 (mode_s/mod.rs:56-72) for an address that a DF17 in buffer 1 teaches,
+    sent before that (must be dropped), later in the first shard and in the second shard."""
+    iq = synth.make_iq(n_samples, n_bursts=120, seed=78, n_icao=6, df11_every=4)
+    icao = 0x4840D6
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    at = lambda chunk, j: 5 * (chunk * 131072 + j)
+    synth.add_bursts(iq, [synth.Burst(at(0, 20000), 22000, 1, df4),
+                          synth.Burst(at(1, 60000), 22000, 2, synth.df17_frame(icao, 77)),
+                          synth.Burst(at(2, 90000), 22000, 5, df4),
+                          synth.Burst(at(4, 5000), 22000, 9, df4),
+                          synth.Burst(at(5, 70000), 22000, 3, df4)])
+    return iq, df4
+
+
+def _shard_trials(oracle_mod, iq):
+    """Stand-in for adsb_shard_scan/finish on a box without a GPU: every trial the oracle
+    slices in this shard (a superset of what the device keeps; the replay decides)."""
+    import ctypes as C
+    from dump1090_rs_amd.context import TRIAL_DTYPE
+    L = oracle_mod.lib()
+    parts = []
+    for c, off in enumerate(range(0, len(iq), 131072)):
+        mb = oracle_mod.OrcMagBuf()
+        part = np.ascontiguousarray(iq[off:off + 131072])
+        L.orc_to_mag(part.ctypes.data, len(part), C.byref(mb))
+        buf = np.zeros(5 * 131072 // 8, dtype=TRIAL_DTYPE)
+        n = L.orc_all_trials(C.byref(mb), c, buf.ctypes.data, len(buf))
+        assert n <= len(buf)
+        parts.append(buf[:n].copy())
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=TRIAL_DTYPE)
+
+
+def _merge_worker(rank, world, port, n_samples, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import binding
+    from dump1090_rs_amd.context import replay_records
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        iq, _ = _coupled_capture(n_samples)
+        a, b = sharding.sample_range(n_samples, world, rank)
+        recs = _shard_trials(binding, iq[a:b])
+        # the address exchange: every rank ends up with the same union
+        mine = np.unique(np.array([int.from_bytes(bytes(r["msg"][1:4]), "big") for r in recs
+                                   if r["msg"][0] >> 3 == 17][:50], dtype=np.uint32))
+        union = sharding.exchange_addresses(dist, mine)
+        merged = sharding.gather_records(dist, recs, a // 131072)
+        out = None
+        if rank == 0:
+            msgs = replay_records(merged)
+            out = [(m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level) for m in msgs]
+        q.put((rank, union.tolist(), mine.tolist(), out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_exact_merge_equals_single_stream(oracle_mod, hip_lib):
+    """Shards gathered on rank 0 and replayed once in global order == the whole capture on one
+    stream, including address/parity frames whose address was learned in the other shard."""
+    import torch.multiprocessing as mp
+    world, n = 2, 6 * 131072 + 999
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == sorted(set(got[0][2]) | set(got[1][2]))
+    iq, df4 = _coupled_capture(n)
+    single, _ = oracle_mod.Oracle().demod_iq(iq)
+    want = [(m["chunk"], m["j"], m["try_phase"], m["score"], m["msg"], m["signal_level"]) for m in single]
+    assert got[0][3] == want and got[1][3] is None
+    # the capture really exercises the coupling: the DF4 decodes in buffers 2, 4 and 5 (never
+    # in buffer 0, before its address is known); independent streams would lose 4 and 5
+    assert sorted(m["chunk"] for m in single if m["buffer"] == df4) == [2, 4, 5]
+    per_shard = []
+    for r in range(world):
+        a, b = sharding.sample_range(n, world, r)
+        per_shard += oracle_mod.Oracle().demod_iq(iq[a:b])[0]
+    assert len([m for m in per_shard if m["buffer"] == df4]) == 1
