@@ -42,10 +42,21 @@ def stale() -> bool:
     return any(p.stat().st_mtime > t for p in SOURCES + HEADERS + [Path(__file__)])
 
 
+FEED = PKG / "adsb_feed"
+FEED_SRC = CSRC / "adsb_feed.cpp"
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not stale():
+    if not force and not stale() and FEED.exists() and FEED.stat().st_mtime >= FEED_SRC.stat().st_mtime:
         return LIB
     cmd = [hipcc(), *FLAGS, *map(str, SOURCES), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    # the file/pipe -> "*hex;" feeder (host only, plain C++ over the C ABI); finds the library
+    # next to itself
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", str(FEED_SRC), "-o", str(FEED),
+           f"-L{PKG}", "-ladsb_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

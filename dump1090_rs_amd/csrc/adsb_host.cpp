@@ -912,6 +912,25 @@ int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, a
     return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
 }
 
+int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
+{
+    if (!m || !out || (m->len != ADSB_MODES_SHORT_MSG_BYTES && m->len != ADSB_MODES_LONG_MSG_BYTES))
+        return ADSB_ERR_INVALID;
+    const size_t need = 2u * m->len + 3u;  // '*', hex, ';', '\n'
+    if (out_size < need + 1) return ADSB_ERR_CAPACITY;
+    static const char digits[] = "0123456789abcdef";  // hex::encode is lowercase
+    char *w = out;
+    *w++ = '*';
+    for (int i = 0; i < m->len; i++) {
+        *w++ = digits[m->msg[i] >> 4];
+        *w++ = digits[m->msg[i] & 15];
+    }
+    *w++ = ';';
+    *w++ = '\n';
+    *w = 0;
+    return (int)need;
+}
+
 int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 {
     if (!c || !out) return ADSB_ERR_INVALID;

@@ -158,6 +158,12 @@ int adsb_ring_submit(adsb_ctx *ctx, size_t n_samples);
  * writes in-memory {re, im}.  Returns samples read via *n_out. */
 int adsb_read_test_data(const char *path, int16_t *iq_re_im, size_t max_samples, size_t *n_out);
 
+/* The raw output line of dump1090_rs/src/main.rs:172-176 for one message:
+ * "*" + lowercase hex of buffer() + ";\n" (the format port 30002 clients such as adsb_deku's
+ * radar read).  Writes 17 or 31 characters plus a terminating NUL into out (>= 32 bytes);
+ * returns the length without the NUL, or a negative status.  Host only. */
+int adsb_format_raw(const adsb_msg *msg, char *out, size_t out_size);
+
 /* One trial message as the device hands it to the host replay. */
 typedef struct {
     uint64_t power;   /* sum of the 33 squared magnitudes from j+19 (demod_2400.rs:191-196) */

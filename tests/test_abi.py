@@ -51,3 +51,36 @@ def test_product_package_never_imports_the_oracle():
 
 def test_version_string(hip_lib):
     assert hip_lib.adsb_version().startswith(b"adsb_hip")
+
+
+def test_format_raw_is_the_reference_output_line(hip_lib, golden):
+    """dump1090_rs/src/main.rs:172-176: "*" + hex::encode(buffer()) + ";\\n"."""
+    from dump1090_rs_amd._lib import AdsbMsg
+    for fx in golden["fixtures"]:
+        for hexframe in fx["frames"]:
+            raw = bytes.fromhex(hexframe)
+            m = AdsbMsg()
+            C.memmove(m.msg, raw, len(raw))
+            m.len = len(raw)
+            out = C.create_string_buffer(40)
+            n = hip_lib.adsb_format_raw(C.byref(m), out, 40)
+            assert n == 2 * len(raw) + 3 and out.value.decode() == f"*{hexframe};\n"
+    m = AdsbMsg()
+    m.len = 9
+    assert hip_lib.adsb_format_raw(C.byref(m), C.create_string_buffer(40), 40) == -1   # not 7 or 14
+    m.len = 14
+    assert hip_lib.adsb_format_raw(C.byref(m), C.create_string_buffer(40), 31) == -5   # needs 32
+
+
+def test_feed_tool_fails_loudly_without_a_gpu(hip_lib, golden):
+    """adsb_feed (file/pipe -> "*hex;" lines) has no CPU path either."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: covered by the gpu tests")
+    feed = ROOT / "dump1090_rs_amd" / "adsb_feed"
+    assert feed.exists()
+    r = subprocess.run([str(feed), str(ROOT / "tests" / "golden" / golden["fixtures"][0]["file"])],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and r.stdout == "" and "no CPU fallback" in r.stderr

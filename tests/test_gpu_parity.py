@@ -397,3 +397,54 @@ def test_sharded_capture_two_phases_equal_single_stream(hip_lib, oracle_mod):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_feed_tool_prints_and_serves_reference_raw_lines(hip_lib, oracle_mod, golden, fixture_iq):
+    """adsb_feed = the loop of dump1090_rs/src/main.rs:154-201 over a pipe: the three reference
+    captures back to back on stdin (file order, im first) -> "*hex;" lines on stdout and on a
+    raw TCP client, equal to the oracle's frames for the same stream (filter never flushed)."""
+    import socket
+    import subprocess
+    import time
+    from tests.conftest import ROOT, GOLDEN
+
+    files = [GOLDEN / fx["file"] for fx in golden["fixtures"]]
+    stream = np.concatenate([fixture_iq[fx["file"]] for fx in golden["fixtures"]])
+    want, _ = oracle_mod.Oracle().demod_iq(stream)
+    lines = [f"*{w['buffer'].hex()};" for w in want]
+    assert lines[:5] == [f"*{h};" for h in golden["fixtures"][0]["frames"]]
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    feed = subprocess.Popen([str(ROOT / "dump1090_rs_amd" / "adsb_feed"), "--port", str(port), "--buffers", "2", "-"],
+                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        client = None
+        for _ in range(200):  # the listener is up before the first read of stdin
+            try:
+                client = socket.create_connection(("127.0.0.1", port), timeout=1)
+                break
+            except OSError:
+                time.sleep(0.05)
+        assert client is not None
+        for f in files:
+            feed.stdin.write(f.read_bytes())
+        feed.stdin.close()
+        out = feed.stdout.read().decode()
+        err = feed.stderr.read().decode()
+        assert feed.wait(timeout=120) == 0, err
+        assert out.splitlines() == lines
+        assert f"{len(stream)} samples, {len(lines)} frames" in err
+        client.settimeout(5)
+        got = b""
+        while True:
+            part = client.recv(65536)
+            if not part:
+                break
+            got += part
+        assert got.decode() == "".join(l + "\n" for l in lines)
+        client.close()
+    finally:
+        if feed.poll() is None:
+            feed.kill()
