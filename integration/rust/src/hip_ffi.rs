@@ -1,0 +1,67 @@
+//! `extern "C"` declarations for `include/adsb_hip.h` (libadsb_hip.so, gfx950).
+//! UNTESTED: written without a Rust toolchain; layouts follow the header field by field.
+#![allow(dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const ADSB_OK: c_int = 0;
+pub const ADSB_ERR_INVALID: c_int = -1;
+pub const ADSB_ERR_NO_DEVICE: c_int = -2;
+pub const ADSB_ERR_HIP: c_int = -3;
+pub const ADSB_ERR_TOO_LONG: c_int = -4;
+pub const ADSB_ERR_CAPACITY: c_int = -5;
+pub const ADSB_ERR_NOMEM: c_int = -6;
+pub const ADSB_ERR_BUSY: c_int = -7;
+
+/// `adsb_msg`: `ModeSMessage` (src/demod_2400.rs:92-102) + provenance.  40 bytes.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct AdsbMsg {
+    pub msg: [u8; 14],
+    pub len: u8, // 7 | 14 == buffer().len()
+    pub try_phase: u8,
+    pub score: i32,
+    pub j: u32,
+    pub chunk: u64,
+    pub signal_level: f64,
+}
+
+/// `adsb_trial`: one raw trial message, before scoring.  32 bytes.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct AdsbTrial {
+    pub power: u64,
+    pub chunk: u32,
+    pub j_tp: u32, // j | try_phase << 24
+    pub msg: [u8; 14],
+    pub pad: u16,
+}
+
+#[repr(C)]
+pub struct AdsbCtx {
+    _private: [u8; 0],
+}
+
+#[link(name = "adsb_hip")]
+extern "C" {
+    pub fn adsb_create(out: *mut *mut AdsbCtx, device: c_int, max_chunks: usize) -> c_int;
+    pub fn adsb_destroy(ctx: *mut AdsbCtx);
+    pub fn adsb_icao_flush(ctx: *mut AdsbCtx) -> c_int;
+    pub fn adsb_to_mag(ctx: *mut AdsbCtx, iq_re_im: *const i16, n: usize, data_out: *mut u16, length_out: *mut usize) -> c_int;
+    pub fn adsb_demodulate2400(ctx: *mut AdsbCtx, data: *const u16, length: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_demod_iq(ctx: *mut AdsbCtx, iq_re_im: *const i16, n_samples: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_demod_iq_device(ctx: *mut AdsbCtx, device_iq: *const c_void, n_samples: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_submit_iq_device(ctx: *mut AdsbCtx, device_iq: *const c_void, n_samples: usize) -> c_int;
+    pub fn adsb_collect(ctx: *mut AdsbCtx, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_pending(ctx: *const AdsbCtx) -> c_int;
+    pub fn adsb_ring_create(ctx: *mut AdsbCtx, samples_per_slot: usize) -> c_int;
+    pub fn adsb_ring_acquire(ctx: *mut AdsbCtx, host_iq_re_im: *mut *mut i16, capacity_samples: *mut usize) -> c_int;
+    pub fn adsb_ring_submit(ctx: *mut AdsbCtx, n_samples: usize) -> c_int;
+    pub fn adsb_shard_scan(ctx: *mut AdsbCtx, device_iq: *const c_void, n_samples: usize, addrs_out: *mut u32, cap: usize, n_addrs: *mut usize) -> c_int;
+    pub fn adsb_shard_finish(ctx: *mut AdsbCtx, extra_addrs: *const u32, n_extra: usize, records_out: *mut AdsbTrial, cap: usize, n_records: *mut usize) -> c_int;
+    pub fn adsb_replay_records(filter_table: *mut u32, records: *mut AdsbTrial, n: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_format_raw(msg: *const AdsbMsg, out: *mut c_char, out_size: usize) -> c_int;
+    pub fn adsb_read_test_data(path: *const c_char, iq_re_im: *mut i16, max_samples: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_strerror(status: c_int) -> *const c_char;
+    pub fn adsb_last_error(ctx: *const AdsbCtx) -> *const c_char;
+    pub fn adsb_version() -> *const c_char;
+}
