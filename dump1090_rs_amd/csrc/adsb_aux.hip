@@ -103,42 +103,26 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
 // ---------------------------------------------------------------------------
 // Stores into mapped host memory: system scope, i.e. written through the caches, so they
 // are in host memory when the kernel has drained -- no cache flush needed afterwards.
-__device__ __forceinline__ void host_store64(unsigned long long *p, unsigned long long v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 __device__ __forceinline__ void host_store32(uint32_t *p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <bool FROM_MAG>
-struct WindowReader {
-    const void *src;
-    uint64_t chunk;
-    int len;
-    int j;
-    __device__ uint32_t operator[](int off) const
-    {
-        const int d = j + off;  // index into MagnitudeBuffer.data
-        if (FROM_MAG) return ((const uint16_t *)src)[d];
-        const int k = d - kLead;
-        if (k < 0 || k >= len) return 0;
-        return mag_of_dword(((const uint32_t *)src)[chunk * (uint64_t)kChunkSamples + k]);
-    }
-    __device__ WindowReader operator+(int off) const
-    {
-        WindowReader r = *this;
-        r.j += off;
-        return r;
-    }
-};
+// 16 bytes straight to (mapped host) memory at system scope
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void host_store128(void *p, u32x4_t v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+constexpr int kRecWindow = 296;   // magnitudes a trial can touch: data[j+19 .. j+290], rounded up
+constexpr int kRecBatch = 64;     // records a block stages before writing them out together
 
 template <bool FROM_MAG>
 __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 {
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Housekeeping so that no pass needs a reset launch: after an icao_flush retired a
     // bitmap, clear it here (address 0 always tests true, src/icao_filter.rs:71-80: bit 0
     // starts set); it comes back into use two flushes later.  This pass's own counters are
@@ -148,51 +132,79 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         for (uint32_t v = gi; v < (1u << 24) / 8 / 16; v += gn)
             ((uint4 *)p.clean_bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
     }
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < n; i += nwaves) {
-        const uint64_t e = p.hits[i];
-        const uint64_t chunk = entry_chunk(e);
-        const uint32_t j = entry_j(e), tp = entry_tp(e);
-        const int len = FROM_MAG ? (int)p.n_samples : chunk_len(p.n_samples, chunk);
-        const WindowReader<FROM_MAG> win{p.src, chunk, len, (int)j};
-
-        unsigned long long half[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int nbit = lane + 64 * h;
-            bool bit = false;
-            if (nbit < 112) {
-                const int pos = 5 * 19 + (int)tp + 12 * nbit;
-                const int s = pos / 5;
-                bit = slice_value(win + s, pos - 5 * s) > 0;
+    // A block owns a contiguous run of hits, so its records leave as one contiguous burst of
+    // 16-byte stores (mapped host memory sits behind PCIe: thousands of separate 8-byte writes
+    // cost ~6 ns each, wide neighbouring ones combine).  One wave per hit: the window of
+    // magnitudes behind j is rebuilt from IQ into LDS with coalesced loads (rare path: a handful
+    // of hits per chunk, so magnitudes are never kept in HBM), lanes are message bits
+    // (demod_2400.rs:158-182), the 33-sample power is summed (:191-196).
+    __shared__ uint16_t win[4][kRecWindow];
+    __shared__ alignas(16) TrialRecord stage[kRecBatch];
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t first = blockIdx.x * per, last = min(n, first + per);
+    for (uint32_t b0 = first; b0 < last; b0 += kRecBatch) {
+        const uint32_t cnt = min((uint32_t)kRecBatch, last - b0);
+        for (uint32_t q = wave; q < cnt; q += 4) {
+            const uint64_t e = p.hits[b0 + q];
+            const uint64_t chunk = entry_chunk(e);
+            const uint32_t j = entry_j(e), tp = entry_tp(e);
+            // win[k] = data[j + 19 + k]
+            if (FROM_MAG) {
+                for (int k = lane; k < kRecWindow; k += 64) {
+                    const int d = (int)j + 19 + k;
+                    win[wave][k] = d < kMagDataLen ? ((const uint16_t *)p.src)[d] : (uint16_t)0;
+                }
+            } else {
+                const int len = chunk_len(p.n_samples, chunk);
+                const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
+                for (int k = lane; k < kRecWindow; k += 64) {
+                    const int s = (int)j + 19 + k - kLead;  // IQ sample behind data[j+19+k]
+                    win[wave][k] = (s >= 0 && s < len) ? (uint16_t)mag_of_dword(iq[s]) : (uint16_t)0;
+                }
             }
-            // lane n holds message bit n; the message is MSB-first
-            half[h] = __brevll(__ballot(bit));
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned long long half[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int nbit = lane + 64 * h;
+                bool bit = false;
+                if (nbit < 112) {
+                    const int pos = (int)tp + 12 * nbit;  // relative to 5 * (j + 19)
+                    const int sidx = pos / 5;
+                    bit = slice_value(&win[wave][sidx], pos - 5 * sidx) > 0;
+                }
+                // lane n holds message bit n; the message is MSB-first
+                half[h] = __brevll(__ballot(bit));
+            }
+            unsigned long long pw = 0;
+            if (lane < 33) {
+                const unsigned long long m = win[wave][lane];
+                pw = m * m;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) pw += __shfl_down(pw, off);
+            if (lane == 0) {
+                TrialRecord r;
+                r.power = pw;
+                r.chunk = (uint32_t)chunk;
+                r.j_tp = j | (tp << 24);
+#pragma unroll
+                for (int k = 0; k < 8; k++) r.msg[k] = (uint8_t)(half[0] >> (56 - 8 * k));
+#pragma unroll
+                for (int k = 0; k < 6; k++) r.msg[8 + k] = (uint8_t)(half[1] >> (56 - 8 * k));
+                r.pad = 0;
+                stage[q] = r;
+            }
+            __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next hit
         }
-        unsigned long long pw = 0;
-        if (lane < 33) {
-            const unsigned long long m = win[19 + lane];
-            pw = m * m;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) pw += __shfl_down(pw, off);
-        if (lane == 0) {
-            TrialRecord r;
-            r.power = pw;
-            r.chunk = (uint32_t)chunk;
-            r.j_tp = j | (tp << 24);
-#pragma unroll
-            for (int b = 0; b < 8; b++) r.msg[b] = (uint8_t)(half[0] >> (56 - 8 * b));
-#pragma unroll
-            for (int b = 0; b < 6; b++) r.msg[8 + b] = (uint8_t)(half[1] >> (56 - 8 * b));
-            r.pad = 0;
-            const unsigned long long *src = (const unsigned long long *)&r;
-            unsigned long long *dst = (unsigned long long *)&rec[i];
-#pragma unroll
-            for (int k = 0; k < 4; k++) host_store64(dst + k, src[k]);
-        }
+        __syncthreads();
+        if (threadIdx.x < 2 * cnt)
+            host_store128((char *)(rec + b0) + 16 * threadIdx.x, ((const u32x4_t *)stage)[threadIdx.x]);
+        __syncthreads();  // stage is refilled by the next batch
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's records have left
+
     // The last block to finish totals the counters into the summary for the host -- like the
     // records it goes straight into mapped host memory with write-through stores, so the
     // completion event behind this kernel needs no system-scope cache flush -- and then
@@ -295,8 +307,10 @@ int launch_match(const ScanParams &p, void *stream)
 
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream)
 {
-    uint32_t blocks = p.n_chunks / 2 + 8;  // 4 waves each; ~a few hits per chunk
-    if (blocks > 4096) blocks = 4096;
+    // contiguous runs of hits per block (the count lives on the device): enough blocks that a
+    // dense pass (tens of hits per chunk) still has only a few hits per wave
+    uint32_t blocks = p.n_chunks + 8;
+    if (blocks > 2048) blocks = 2048;
     if (from_mag)
         hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     else

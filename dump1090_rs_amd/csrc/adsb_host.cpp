@@ -126,20 +126,49 @@ int fail(adsb_ctx *c, hipError_t e, const char *what)
 void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
             std::vector<adsb_msg> &out)
 {
-    std::sort(rec, rec + n, [](const TrialRecord &a, const TrialRecord &b) {
-        if (a.chunk != b.chunk) return a.chunk < b.chunk;
-        const uint32_t ja = a.j_tp & 0xFFFFFFu, jb = b.j_tp & 0xFFFFFFu;
-        if (ja != jb) return ja < jb;
-        return (a.j_tp >> 24) < (b.j_tp >> 24);
-    });
+    // order = (chunk, j, try_phase); the records stay where they are (they may sit in mapped
+    // host memory), only 16-byte (key, index) pairs are sorted
+    struct Ref {
+        uint64_t key;
+        uint32_t idx;
+    };
+    std::vector<Ref> order(n);
+    bool sorted = true;
+    uint64_t all_or = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t jt = rec[i].j_tp;
+        order[i] = {(uint64_t)rec[i].chunk << 32 | (uint64_t)(jt & 0xFFFFFFu) << 8 | (jt >> 24), (uint32_t)i};
+        sorted = sorted && (i == 0 || order[i - 1].key <= order[i].key);
+        all_or |= order[i].key;
+    }
+    if (!sorted) {
+        // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
+        // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
+        std::vector<Ref> tmp(n);
+        Ref *src = order.data(), *dst = tmp.data();
+        for (int shift = 0; shift < 64; shift += 11) {
+            if (((all_or >> shift) & 0x7FFu) == 0) continue;
+            uint32_t count[2048] = {0};
+            for (size_t i = 0; i < n; i++) count[(src[i].key >> shift) & 0x7FFu]++;
+            uint32_t at = 0;
+            for (uint32_t &c : count) {
+                const uint32_t k = c;
+                c = at;
+                at += k;
+            }
+            for (size_t i = 0; i < n; i++) dst[count[(src[i].key >> shift) & 0x7FFu]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != order.data()) order.swap(tmp);
+    }
     size_t i = 0;
     while (i < n) {
-        const uint32_t chunk = rec[i].chunk, j = rec[i].j_tp & 0xFFFFFFu;
+        const uint64_t pos = order[i].key >> 8;  // (chunk, j)
         adsb_msg best{};
         best.score = -2;
         best.len = ADSB_MODES_SHORT_MSG_BYTES;
-        for (; i < n && rec[i].chunk == chunk && (rec[i].j_tp & 0xFFFFFFu) == j; i++) {
-            const TrialRecord &r = rec[i];
+        for (; i < n && (order[i].key >> 8) == pos; i++) {
+            const TrialRecord &r = rec[order[i].idx];
             const Score s = score_modes_message(filter, crc, r.msg);
             if (!s.some || s.value <= best.score) continue;
             std::memcpy(best.msg, r.msg, 14);
@@ -151,8 +180,8 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
             best.signal_level = signal_power / 33.0;
         }
         if (best.score < 0) continue;
-        best.j = j;
-        best.chunk = chunk_offset + chunk;
+        best.j = (uint32_t)(pos & 0xFFFFFFu);
+        best.chunk = chunk_offset + (pos >> 24);
         out.push_back(best);
     }
 }
@@ -160,7 +189,7 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
-                 uint32_t n_chunks)
+                 uint32_t n_chunks, bool inline_tail = false)
 {
     ScanParams p{};
     p.src = d_src;
@@ -209,9 +238,13 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
     // the tail runs on its own stream behind the scan: the next pass's scan does not wait
     // for it (it works on the other slot's lists and counters)
-    HIP_TRY(c, hipEventRecord(sl.scanned, c->stream));
-    hipStream_t ts = c->tail_stream;
-    HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+    // (a blocking call has nothing to overlap with: its tail stays on the scan stream and
+    // saves the cross-stream hand-off)
+    hipStream_t ts = inline_tail ? c->stream : c->tail_stream;
+    if (!inline_tail) {
+        HIP_TRY(c, hipEventRecord(sl.scanned, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+    }
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
     if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
@@ -294,13 +327,13 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     return ADSB_OK;
 }
 
-int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples)
+int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false)
 {
     const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks == 0 || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
     Slot &sl = c->slot[c->submitted % kSlots];
     if (sl.busy || c->shard_active) return ADSB_ERR_BUSY;
-    int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks);
+    int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks, inline_tail);
     if (rc) return rc;
     sl.busy = true;
     c->submitted++;
@@ -311,7 +344,7 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples)
 int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out)
 {
     if (c->submitted != c->collected) return ADSB_ERR_BUSY;
-    int rc = submit(c, d_src, from_mag, n_samples);
+    int rc = submit(c, d_src, from_mag, n_samples, true);
     if (rc) return rc;
     return collect_oldest(c, out);
 }

@@ -198,8 +198,8 @@ int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra
 /* Host only, no device needed: the ordered replay every demod call ends with
  * (score_modes_message src/mode_s/mod.rs:34-139 + best-of-5 selection
  * src/demod_2400.rs:149-207 + icao_filter src/icao_filter.rs), exposed so the
- * sequential logic can be exercised on its own.  `records` is sorted in place by
- * (chunk, j, try_phase).  `filter_table` is table A of the filter (4096 u32,
+ * sequential logic can be exercised on its own.  `records` may come in any order (they are
+ * replayed by (chunk, j, try_phase) and left as they are).  `filter_table` is table A of the filter (4096 u32,
  * src/icao_filter.rs:8), read and updated. */
 int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
                         size_t cap, size_t *n_out);
