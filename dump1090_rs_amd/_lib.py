@@ -105,6 +105,8 @@ def lib() -> C.CDLL:
     L.adsb_read_test_data.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
     L.adsb_get_stats.argtypes = [vp, C.POINTER(AdsbStats)]
     L.adsb_replay_records.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_set_carry_over.argtypes = [vp, C.c_int]
+    L.adsb_set_carry_over.restype = C.c_int
     L.adsb_format_raw.argtypes = [vp, C.c_char_p, sz]
     L.adsb_format_raw.restype = C.c_int
     L.adsb_shard_scan.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]

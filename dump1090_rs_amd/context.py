@@ -246,6 +246,10 @@ class Context:
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._L.adsb_set_stream(self._h, C.c_void_p(hip_stream)), "adsb_set_stream")
 
+    def set_carry_over(self, enabled: bool) -> None:
+        """Opt-in, not the reference's semantics: buffer lead-ins hold the preceding samples."""
+        self._check(self._L.adsb_set_carry_over(self._h, 1 if enabled else 0), "adsb_set_carry_over")
+
     def set_profiling(self, level: int) -> None:
         """0 = no HIP events, 1 = scan kernel + whole chain (default), 2 = every kernel."""
         self._check(self._L.adsb_set_profiling(self._h, int(level)), "adsb_set_profiling")

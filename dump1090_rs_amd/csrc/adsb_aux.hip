@@ -157,9 +157,17 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             } else {
                 const int len = chunk_len(p.n_samples, chunk);
                 const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
+                const bool lead = p.carry != nullptr && (chunk > 0 || p.lead_from_src);
                 for (int k = lane; k < kRecWindow; k += 64) {
                     const int s = (int)j + 19 + k - kLead;  // IQ sample behind data[j+19+k]
-                    win[wave][k] = (s >= 0 && s < len) ? (uint16_t)mag_of_dword(iq[s]) : (uint16_t)0;
+                    uint32_t w = 0;
+                    if (s >= 0 && s < len)
+                        w = iq[s];
+                    else if (s < 0 && lead)                 // carry-over mode: the samples before
+                        w = *(iq + s);
+                    else if (s < 0 && p.carry != nullptr)
+                        w = p.carry[s + kCarrySamples];
+                    win[wave][k] = (uint16_t)mag_of_dword(w);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -239,6 +247,15 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         return;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) ((uint32_t *)p.ctr)[i] = 0;
+}
+
+// carry-over mode: the last kCarrySamples samples of the stream so far
+__global__ __launch_bounds__(kCarrySamples) void k_update_carry(const uint32_t *__restrict__ prev,
+                                                               const uint32_t *__restrict__ src, long long n,
+                                                               uint32_t *__restrict__ next)
+{
+    const long long i = threadIdx.x, idx = n - kCarrySamples + i;
+    next[i] = idx >= 0 ? src[idx] : prev[i + n];
 }
 
 // addresses learned elsewhere (other shards of the same capture) join the superset
@@ -323,6 +340,13 @@ int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, 
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_set_addresses, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_addrs, n,
                        bitmap);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_update_carry(const uint32_t *prev, const void *d_src, uint64_t n_samples, uint32_t *next, void *stream)
+{
+    hipLaunchKernelGGL(k_update_carry, dim3(1), dim3(kCarrySamples), 0, (hipStream_t)stream, prev,
+                       (const uint32_t *)d_src, (long long)n_samples, next);
     return hip_ok(hipGetLastError());
 }
 

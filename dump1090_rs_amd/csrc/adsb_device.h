@@ -112,7 +112,15 @@ struct ScanParams {
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
     uint32_t keep_counters; // records kernel: leave the counters and lists as they are (first phase of a shard)
+    // carry-over mode (opt-in, not the reference's semantics): the 326-sample lead-in of a
+    // buffer holds the samples that preceded it.  Buffers after the first take them from src
+    // itself; the first takes them from `carry` (kCarrySamples IQ samples, the end of the
+    // previous call), or from src[-kCarrySamples..] when lead_from_src is set.
+    const uint32_t *carry;
+    uint32_t lead_from_src;
 };
+
+constexpr int kCarrySamples = 328;  // kLead rounded up to whole 16-byte loads
 
 // launches; all asynchronous on `stream`, return a hipError_t as int
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
@@ -125,6 +133,9 @@ int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);
 // OR a list of 24-bit addresses into a bitmap (addresses learned by other shards)
 int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream);
+// next[i] = sample (n - kCarrySamples + i) of the stream: from d_src, or from `prev` where the
+// call was shorter than the carry
+int launch_update_carry(const uint32_t *prev, const void *d_src, uint64_t n_samples, uint32_t *next, void *stream);
 int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream);
 
 }  // namespace adsb

@@ -38,6 +38,8 @@ struct Slot {
     // stream) fills the other slot's
     Counters *d_ctr = nullptr;
     uint64_t *d_ap = nullptr, *d_hits = nullptr;
+    uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
+    bool done_recorded = false;    // `done` has been recorded at least once
     hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
     uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
@@ -88,6 +90,8 @@ struct adsb_ctx {
     } ring[kSlots];
     size_t ring_samples = 0;
     hipStream_t copy_stream = nullptr;
+
+    bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
 
     // sharded capture (adsb_shard_scan / adsb_shard_finish): the pass parked between its two phases
     bool shard_active = false;
@@ -189,7 +193,8 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
-                 uint32_t n_chunks, bool inline_tail = false)
+                 uint32_t n_chunks, bool inline_tail = false, bool lead_from_src = false,
+                 bool advance_carry = true)
 {
     ScanParams p{};
     p.src = d_src;
@@ -213,6 +218,8 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.stagger_ticks = c->stagger_ticks;
     p.debug_stop = c->debug_stop;
     p.timeline = c->d_timeline;
+    p.carry = c->carry_over && !from_mag ? sl.d_carry : nullptr;
+    p.lead_from_src = lead_from_src ? 1u : 0u;
 
     sl.src = d_src;
     sl.from_mag = from_mag;
@@ -236,6 +243,14 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
     if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
+    if (p.carry && advance_carry) {
+        // the next pass (other slot) starts from the end of this one's input.  That slot's
+        // previous pass may still be reading its carry in its records kernel: behind it.
+        Slot &next = c->slot[(&sl - c->slot + 1) % kSlots];
+        if (next.done_recorded) HIP_TRY(c, hipStreamWaitEvent(c->stream, next.done, 0));
+        if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, next.d_carry, c->stream))
+            return fail(c, (hipError_t)e, "launch_update_carry");
+    }
     // the tail runs on its own stream behind the scan: the next pass's scan does not wait
     // for it (it works on the other slot's lists and counters)
     // (a blocking call has nothing to overlap with: its tail stays on the scan stream and
@@ -254,6 +269,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         return fail(c, (hipError_t)e, "launch_records");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
     HIP_TRY(c, hipEventRecord(sl.done, ts));
+    sl.done_recorded = true;
     return ADSB_OK;
 }
 
@@ -311,7 +327,9 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         for (uint64_t ch = 0; ch < sl.n_chunks && rc == 0; ch++) {
             const uint64_t off = ch * kChunkSamples;
             const uint64_t n = std::min<uint64_t>(kChunkSamples, sl.n_samples - off);
-            rc = enqueue_pass(c, tmp, (const uint32_t *)sl.src + off, false, n, 1);
+            // (carry-over mode: buffers after the first find their lead-in in src itself; the
+            // carry for the next call was already taken when the pass was first enqueued)
+            rc = enqueue_pass(c, tmp, (const uint32_t *)sl.src + off, false, n, 1, false, ch > 0, false);
             if (rc == 0) rc = finish_pass(c, tmp, ch, st, out);
         }
         c->flush_pending = keep_flush;
@@ -450,6 +468,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipEventCreateWithFlags(&sl.scanned, hipEventDisableTiming | hipEventDisableSystemFence));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_carry, kCarrySamples * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t)));
         }
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
@@ -508,6 +528,7 @@ void adsb_destroy(adsb_ctx *c)
         if (sl.d_ctr) (void)hipFree(sl.d_ctr);
         if (sl.d_hits) (void)hipFree(sl.d_hits);
         if (sl.d_ap) (void)hipFree(sl.d_ap);
+        if (sl.d_carry) (void)hipFree(sl.d_carry);
         if (sl.h_sum) (void)hipHostFree(sl.h_sum);
         if (sl.h_rec) (void)hipHostFree(sl.h_rec);
     }
@@ -581,6 +602,18 @@ int adsb_set_profiling(adsb_ctx *c, int enabled)
 {
     if (!c) return ADSB_ERR_INVALID;
     c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    return ADSB_OK;
+}
+
+int adsb_set_carry_over(adsb_ctx *c, int enabled)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    if (c->submitted != c->collected || c->shard_active) return ADSB_ERR_BUSY;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->carry_over = enabled != 0;
+    // the stream starts here: nothing precedes the next call
+    for (Slot &sl : c->slot) HIP_TRY(c, hipMemsetAsync(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ADSB_OK;
 }
 

@@ -315,13 +315,28 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
                                              uint4 (&pre)[kLoadsPerThread])
 {
     const uint32_t *iq = (const uint32_t *)p.src + r.chunk * (uint64_t)kChunkSamples;
+    // carry-over mode: the resource starts kCarrySamples before the buffer when those samples
+    // exist in src, so the lead-in is simply in range (the reference's mode: it is not)
+    const bool lead = p.carry != nullptr && (r.chunk > 0 || p.lead_from_src);
+    const int shift = lead ? kCarrySamples : 0;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)iq, 0, r.len * 4, 0x00020000);
-    const int k0 = r.jbase - kPad - kLead;  // IQ sample index of slot 0 (multiple of 4)
+        __builtin_amdgcn_make_buffer_rsrc((void *)(iq - shift), 0, (r.len + shift) * 4, 0x00020000);
+    const int k0 = r.jbase - kPad - kLead + shift;  // IQ sample index of slot 0 (multiple of 4)
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; i++) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k0 + 4 * (tid + i * kThreads)) * 4, 0, 0);
         pre[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    if (p.carry != nullptr && !lead && r.tile == 0) {
+        // first buffer of a call: its lead-in is the end of the previous call (out of range of
+        // one resource = zero from it, so the two loads just OR together)
+        const __amdgpu_buffer_rsrc_t crsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.carry, 0, kCarrySamples * 4, 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(crsrc, (k0 + kCarrySamples + 4 * tid) * 4, 0, 0);
+        pre[0].x |= v.x;
+        pre[0].y |= v.y;
+        pre[0].z |= v.z;
+        pre[0].w |= v.w;
     }
 }
 

@@ -173,6 +173,18 @@ typedef struct {
     uint16_t pad;
 } adsb_trial;
 
+/* Carry-over mode -- opt-in and NOT the reference's semantics.  dump1090_rs starts every
+ * MagnitudeBuffer with 326 zero samples (src/lib.rs:24,36-44; the constant is what upstream
+ * C dump1090 uses to carry the end of the previous buffer over), so a frame that straddles
+ * two buffers is lost.  With carry-over enabled the lead-in of every 131072-sample buffer
+ * holds the 326 samples that preceded it in the stream -- within a call and from the
+ * previous call on this context -- and such frames are decoded in the later buffer
+ * (j < 326 there).  Applies to the IQ entry points (adsb_demod_iq*, submit/collect, the
+ * ring); adsb_to_mag / adsb_demodulate2400 keep working on the caller's buffer as is.
+ * Enabling or disabling restarts the stream (nothing precedes the next call).  Returns
+ * ADSB_ERR_BUSY while passes are pending. */
+int adsb_set_carry_over(adsb_ctx *ctx, int enabled);
+
 /* Sharded capture: one capture cut into contiguous ranges of 131072-sample buffers, one
  * range per GPU (BASELINE config 4; the reference's loop dump1090_rs/src/main.rs:161-167
  * is one stream with one process-global filter, src/icao_filter.rs:8-9).  Shards run

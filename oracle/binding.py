@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         L.orc_demodulate2400.restype = sz
         L.orc_demod_iq.argtypes = [vp, vp, sz, vp, sz, vp]
         L.orc_demod_iq.restype = sz
+        L.orc_demod_iq_carry.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+        L.orc_demod_iq_carry.restype = sz
         L.orc_demod_iq_mt.argtypes = [vp, vp, sz, vp, sz, vp, C.c_int]
         L.orc_demod_iq_mt.restype = sz
         L.orc_read_test_data.argtypes = [C.c_char_p, vp, sz]
@@ -132,6 +134,20 @@ class Oracle:
             n = self.L.orc_demod_iq(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap, C.byref(st))
         assert n <= cap, "oracle output overflowed its buffer"
         return [unpack(m) for m in out[:n]], st
+
+
+def demod_iq_carry(orc: "Oracle", iq, carry: np.ndarray, cap: Optional[int] = None):
+    """The carry-over extension (NOT reference behaviour, see dump1090_oracle.h): `carry` is a
+    (326, 2) int16 array holding the stream state, updated in place."""
+    a = as_iq(iq)
+    assert carry.dtype == np.int16 and carry.shape == (326, 2) and carry.flags.c_contiguous
+    cap = cap or max(4096, a.shape[0] // 64)
+    out = (OrcMsg * cap)()
+    st = OrcStats()
+    n = orc.L.orc_demod_iq_carry(C.byref(orc.filter), a.ctypes.data, a.shape[0], out, cap, C.byref(st),
+                                 carry.ctypes.data)
+    assert n <= cap
+    return [unpack(m) for m in out[:n]], st
 
 
 def unpack(m: OrcMsg) -> dict:

@@ -456,6 +456,42 @@ size_t orc_demod_iq(orc_filter *f, const int16_t *iq_re_im, size_t n_samples, or
     return found;
 }
 
+/* Carry-over extension (see the header: NOT reference behaviour). */
+size_t orc_demod_iq_carry(orc_filter *f, const int16_t *iq_re_im, size_t n_samples, orc_msg *out,
+                          size_t cap, orc_stats *stats, int16_t *carry)
+{
+    orc_magbuf *mb = (orc_magbuf *)malloc(sizeof(orc_magbuf));
+    if (!mb)
+        return 0;
+    size_t found = 0;
+    uint64_t chunk = 0;
+    for (size_t off = 0; off < n_samples; off += ORC_MODES_MAG_BUF_SAMPLES, chunk++) {
+        size_t n = n_samples - off;
+        if (n > ORC_MODES_MAG_BUF_SAMPLES)
+            n = ORC_MODES_MAG_BUF_SAMPLES;
+        orc_to_mag(iq_re_im + 2 * off, n, mb);
+        /* lead-in data[326 - d] = magnitude of the sample d before this buffer (d = 1..326) */
+        for (size_t d = 1; d <= ORC_TRAILING_SAMPLES; d++) {
+            const int16_t *s = off >= d ? iq_re_im + 2 * (off - d)
+                                        : carry + 2 * (ORC_TRAILING_SAMPLES - (d - off));
+            mb->data[ORC_TRAILING_SAMPLES - d] = orc_mag_sample(s[0], s[1]);
+        }
+        size_t room = found < cap ? cap - found : 0;
+        found += orc_demodulate2400(f, mb, chunk, out ? out + (found < cap ? found : cap) : out,
+                                    room, stats);
+    }
+    /* the last 326 samples of the stream so far */
+    if (n_samples >= ORC_TRAILING_SAMPLES) {
+        memcpy(carry, iq_re_im + 2 * (n_samples - ORC_TRAILING_SAMPLES),
+               2 * ORC_TRAILING_SAMPLES * sizeof(int16_t));
+    } else if (n_samples) {
+        memmove(carry, carry + 2 * n_samples, 2 * (ORC_TRAILING_SAMPLES - n_samples) * sizeof(int16_t));
+        memcpy(carry + 2 * (ORC_TRAILING_SAMPLES - n_samples), iq_re_im, 2 * n_samples * sizeof(int16_t));
+    }
+    free(mb);
+    return found;
+}
+
 /* src/utils.rs:23-40: each file pair is [im][re], little-endian i16 */
 long orc_read_test_data(const char *path, int16_t *iq_re_im, size_t max_samples)
 {

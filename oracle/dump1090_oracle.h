@@ -122,6 +122,16 @@ size_t orc_all_trials(const orc_magbuf *mag, uint64_t chunk, orc_trial *out, siz
 size_t orc_demod_iq(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
                     orc_msg *out, size_t cap, orc_stats *stats);
 
+/* NOT reference behaviour -- the opt-in "carry-over" extension of SURVEY.md 8(f)-3, restated
+ * here only so that the product's carry-over mode has a checker.  As orc_demod_iq, but the
+ * 326-sample lead-in of every buffer (src/lib.rs:24,36-44 leaves it zero) holds the
+ * magnitudes of the 326 samples that preceded the buffer in the stream, as upstream C
+ * dump1090 does, so frames that straddle a buffer edge are found (in the later buffer).
+ * `carry` is the stream state: the last 326 IQ samples seen (652 int16, {re,im} pairs,
+ * zero-initialised by the caller), read for the first buffer and updated on return. */
+size_t orc_demod_iq_carry(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
+                          orc_msg *out, size_t cap, orc_stats *stats, int16_t *carry);
+
 /* orc_demod_iq over `threads` host threads (dump1090_oracle_mt.c): workers run to_mag, the
  * gates and the slicer per buffer, one thread replays the trials in order through the
  * filter.  Same result as orc_demod_iq; stats->preamble_pass / snr_pass count only the

@@ -448,3 +448,63 @@ def test_feed_tool_prints_and_serves_reference_raw_lines(hip_lib, oracle_mod, go
     finally:
         if feed.poll() is None:
             feed.kill()
+
+
+def test_carry_over_mode_recovers_frames_across_buffer_edges(hip_lib, oracle_mod):
+    """Opt-in extension, checked against the oracle's restatement of the same
+    extension: lead-ins hold the preceding 326 samples, within a call, across calls (blocking,
+    pipelined and ring), and the default mode is untouched."""
+    import torch
+    from dump1090_rs_amd import Context
+    from oracle.binding import demod_iq_carry
+
+    n = 5 * 131072 + 7777
+    iq = synth.make_iq(n, n_bursts=60, seed=99, n_icao=10, df11_every=3)
+    fr = synth.df17_frame(0xABCDEF, 12345)
+    edges = [synth.Burst(5 * (131072 - 100), 20000, 3, fr), synth.Burst(5 * (2 * 131072 - 250), 20000, 5, fr),
+             synth.Burst(5 * (3 * 131072 - 30), 20000, 7, fr), synth.Burst(5 * (4 * 131072 + 40000), 20000, 1, fr)]
+    synth.add_bursts(iq, edges)
+    plain, _ = oracle_mod.Oracle().demod_iq(iq)
+    carry = np.zeros((326, 2), np.int16)
+    want, _ = demod_iq_carry(oracle_mod.Oracle(), iq, carry)
+    assert len([w for w in want if w["buffer"] == fr]) == 4 and len([w for w in plain if w["buffer"] == fr]) == 1
+
+    c = Context(max_chunks=8)
+    try:
+        assert_same(c.demod_iq(iq), plain)                       # default: the reference's semantics
+        c.set_carry_over(True)
+        c.icao_flush()
+        got = c.demod_iq(iq)
+        assert_same(got, want)
+        assert sorted((m.chunk, m.j) for m in got if m.buffer() == fr)[:3] == [(1, 225), (2, 75), (3, 295)]
+
+        # the same stream in three calls cut at awkward places (one shorter than the carry)
+        cuts = [0, 131072 + 500, 131072 + 700, n]
+        orc, carry = oracle_mod.Oracle(), np.zeros((326, 2), np.int16)
+        c.set_carry_over(True)                                   # restarts the stream
+        c.icao_flush()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            w, _ = demod_iq_carry(orc, iq[a:b], carry)
+            assert_same(c.demod_iq(iq[a:b]), w)
+
+        # pipelined device-resident passes: pass i+1 starts from the end of pass i's input
+        dev = torch.from_numpy(iq).cuda()
+        orc, carry = oracle_mod.Oracle(), np.zeros((326, 2), np.int16)
+        c.set_carry_over(True)
+        c.icao_flush()
+        cuts = [0, 2 * 131072, 3 * 131072 + 131000, n]
+        wants = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            wants.append(demod_iq_carry(orc, iq[a:b], carry)[0])
+        c.submit_iq_device(dev.data_ptr() + 4 * cuts[0], cuts[1] - cuts[0])
+        c.submit_iq_device(dev.data_ptr() + 4 * cuts[1], cuts[2] - cuts[1])
+        assert_same(c.collect(), wants[0])
+        c.submit_iq_device(dev.data_ptr() + 4 * cuts[2], cuts[3] - cuts[2])
+        assert_same(c.collect(), wants[1])
+        assert_same(c.collect(), wants[2])
+
+        c.set_carry_over(False)
+        c.icao_flush()
+        assert_same(c.demod_iq(iq), plain)
+    finally:
+        c.close()
