@@ -49,7 +49,9 @@ FEED_SRC = CSRC / "adsb_feed.cpp"
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and not stale() and FEED.exists() and FEED.stat().st_mtime >= FEED_SRC.stat().st_mtime:
         return LIB
-    cmd = [hipcc(), *FLAGS, *map(str, SOURCES), "-o", str(LIB)]
+    # ADSB_HIPCC_FLAGS: extra flags, e.g. -DADSB_KERNEL_ACCT for the in-kernel phase accounting
+    extra = os.environ.get("ADSB_HIPCC_FLAGS", "").split()
+    cmd = [hipcc(), *FLAGS, *extra, *map(str, SOURCES), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -194,7 +194,7 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
                  uint32_t n_chunks, bool inline_tail = false, bool lead_from_src = false,
-                 bool advance_carry = true)
+                 bool advance_carry = true, bool force_simple = false)
 {
     ScanParams p{};
     p.src = d_src;
@@ -235,13 +235,15 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // level 1: the scan launch stamps its own begin/end (no extra packets on the stream);
     // level 2: classic event records between all kernels
     static const bool ext_events = !std::getenv("ADSB_NO_EXT_EVENTS");
-    p.ev_start = ext_events && prof == 1 && !from_mag ? sl.ev[0] : nullptr;
-    p.ev_stop = ext_events && prof == 1 && !from_mag ? sl.ev[1] : nullptr;
+    const bool fast = !from_mag && !force_simple;
+    p.ev_start = ext_events && prof == 1 && fast ? sl.ev[0] : nullptr;
+    p.ev_stop = ext_events && prof == 1 && fast ? sl.ev[1] : nullptr;
 
     c->flush_pending = false;
-    const bool classic = prof > 1 || (prof == 1 && (from_mag || !ext_events));
+    const bool classic = prof > 1 || (prof == 1 && (!fast || !ext_events));
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
-    if (int e = launch_scan(p, from_mag, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
+    if (int e = force_simple ? launch_scan_simple(p, from_mag, c->stream) : launch_scan(p, from_mag, c->stream))
+        return fail(c, (hipError_t)e, "launch_scan");
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
     if (p.carry && advance_carry) {
         // the next pass (other slot) starts from the end of this one's input.  That slot's
@@ -316,7 +318,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     st.n_chunks = sl.n_chunks;
     if (sl.flush_before) c->filter.flush();  // icao_flush() took effect before this pass
     int rc = finish_pass(c, sl, 0, st, out);
-    if (rc > 0 && !sl.from_mag && sl.n_chunks > 1) {
+    if (rc > 0 && !sl.from_mag) {
         st.retries++;
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // later passes have their results on the host
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
@@ -329,7 +331,8 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
             const uint64_t n = std::min<uint64_t>(kChunkSamples, sl.n_samples - off);
             // (carry-over mode: buffers after the first find their lead-in in src itself; the
             // carry for the next call was already taken when the pass was first enqueued)
-            rc = enqueue_pass(c, tmp, (const uint32_t *)sl.src + off, false, n, 1, false, ch > 0, false);
+            // the reference-shaped kernel: its lists hold the worst case of a chunk
+            rc = enqueue_pass(c, tmp, (const uint32_t *)sl.src + off, false, n, 1, false, ch > 0, false, true);
             if (rc == 0) rc = finish_pass(c, tmp, ch, st, out);
         }
         c->flush_pending = keep_flush;

@@ -340,15 +340,17 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
     }
 }
 
-// profiling aid: wave 0 of a few workgroups stamps the shader clock at phase boundaries
+// profiling aids, compiled in with -DADSB_KERNEL_ACCT only (they cost registers):
+// wave 0 of a few workgroups stamps the shader clock at phase boundaries
+#ifdef ADSB_KERNEL_ACCT
 #define STAMP(slot)                                                                          \
     do {                                                                                     \
         if (p.timeline && p.debug_stop != 100 && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
             p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
     } while (0)
 
-// profiling aid (ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2): every wave totals the clocks it
-// spends in each phase and waiting at each workgroup barrier
+// (ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2): every wave totals the clocks it spends in each
+// phase and waiting at each workgroup barrier
 #define ACCT(k)                                                   \
     do {                                                          \
         if (acct) {                                               \
@@ -357,6 +359,10 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
             acc_last = now_;                                      \
         }                                                         \
     } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#define ACCT(k) do {} while (0)
+#endif
 
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
@@ -395,8 +401,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
         while ((unsigned long long)clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 
+#ifdef ADSB_KERNEL_ACCT
     const bool acct = p.debug_stop == 100 && p.timeline != nullptr;
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
+#endif
 
     uint32_t iter = 0;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x, iter++) {
@@ -742,8 +750,10 @@ tile_end:
     ACCT(7);
     STAMP(6);
     }  // tile loop
+#ifdef ADSB_KERNEL_ACCT
     if (acct && lane == 0)
         for (int k = 0; k < 8; k++) p.timeline[((size_t)blockIdx.x * kWaves + (tid >> 6)) * 8 + k] = acc_t[k];
+#endif
     // candidate counts were kept per wave (diagnostic): lane 0 of each wave adds its own
     if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
     if (tid == 0) p.ctr->seg_ap[blockIdx.x] = ap_count;

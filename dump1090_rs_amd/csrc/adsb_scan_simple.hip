@@ -5,7 +5,9 @@
 // walks them, then every trial phase sliced bit by bit (:158-182) and scored as far as
 // the device goes (DF class + CRC residual, src/mode_s/mod.rs:41-135).  It is slow
 // (every thread walks 112 bits serially) and serves adsb_demodulate2400, whose input is
-// a caller-supplied MagnitudeBuffer (one chunk; throughput is irrelevant there).
+// a caller-supplied MagnitudeBuffer (one chunk; throughput is irrelevant there), and the
+// chunk-by-chunk fallback for input so dense that the fast scan's lists overflow: its lists
+// hold the worst case of a chunk (every position sliced).
 #include "adsb_dev_common.h"
 
 namespace adsb {
@@ -21,9 +23,10 @@ static_assert((kLead + kPad) % 4 == 0, "tile origin must be 16-byte aligned in I
 
 // fill smag[0..kSlots) with data[jbase - kPad ...] of `chunk` (len = samples in the chunk)
 template <bool FROM_MAG>
-__device__ __forceinline__ void load_tile(const void *src, uint64_t chunk, int jbase, int len,
+__device__ __forceinline__ void load_tile(const ScanParams &p, uint64_t chunk, int jbase, int len,
                                           uint16_t *smag)
 {
+    const void *src = p.src;
     const int d0 = jbase - kPad;
     if (FROM_MAG) {
         // src = MagnitudeBuffer.data (kMagDataLen u16), used as handed in
@@ -35,8 +38,21 @@ __device__ __forceinline__ void load_tile(const void *src, uint64_t chunk, int j
     } else {
         const uint32_t *iq = (const uint32_t *)src + chunk * (uint64_t)kChunkSamples;
         const int k0 = d0 - kLead;  // IQ sample index of slot 0 (multiple of 4, may be < 0)
-        for (int g = threadIdx.x; g < kSlots / 4; g += blockDim.x)
-            *(uint2 *)(smag + 4 * g) = mag4(iq, k0 + 4 * g, len);
+        if (p.carry == nullptr) {   // the reference's semantics: nothing before the buffer
+            for (int g = threadIdx.x; g < kSlots / 4; g += blockDim.x)
+                *(uint2 *)(smag + 4 * g) = mag4(iq, k0 + 4 * g, len);
+        } else {                    // carry-over mode (adsb_device.h): the lead-in holds what preceded
+            const bool lead = chunk > 0 || p.lead_from_src;
+            for (int i = threadIdx.x; i < kSlots; i += blockDim.x) {
+                const int k = k0 + i;
+                uint32_t w = 0;
+                if (k >= 0)
+                    w = k < len ? iq[k] : 0u;
+                else if (k >= -kLead)
+                    w = lead ? *(iq + k) : p.carry[k + kCarrySamples];
+                smag[i] = (uint16_t)mag_of_dword(w);
+            }
+        }
     }
 }
 
@@ -47,7 +63,7 @@ __device__ __forceinline__ void scan_simple_tile(const ScanParams &p, uint32_t c
 {
     scrc[threadIdx.x] = crc_table_entry(threadIdx.x);
     if (threadIdx.x == 0) *sncand = 0;
-    load_tile<FROM_MAG>(p.src, chunk, jbase, len, smag);
+    load_tile<FROM_MAG>(p, chunk, jbase, len, smag);
     __syncthreads();
 
     // --- preamble / SNR / quiet gates for every j of the tile (demod_2400.rs:121-146)

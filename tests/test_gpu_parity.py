@@ -508,3 +508,48 @@ def test_carry_over_mode_recovers_frames_across_buffer_edges(hip_lib, oracle_mod
         assert_same(c.demod_iq(iq), plain)
     finally:
         c.close()
+
+
+ADVERSARIAL_PERIODS = [
+    [18143, 6637, 18778, 14788, 3662, 8402, 2882, 16543],                            # 25 % of all j pass every gate
+    [17914, 17500, 12559, 14370, 1698, 4482, 12099, 13742, 8850, 18749, 13607],      # 18 %
+    [833, 13831, 15021, 13358, 19412, 4686, 19425, 17026, 15059, 11206, 19308, 3905, 13173, 6101, 4342, 10650, 7787],
+    [4962, 12056, 7113, 852, 14360, 11334, 17932, 13963, 124, 14783, 17800, 508, 13806, 1459],
+]
+
+
+def test_adversarial_periodic_input_keeps_every_capacity_path_exact(hip_lib, oracle_mod):
+    """Periodic magnitudes found by search: up to a quarter of all positions pass the preamble
+    and both gates (noise: 1 %), i.e. 20-30x the density the kernel's wave-private regions,
+    candidate regions, hit staging and AP segments are sized for.  Rounds, flushes and the
+    per-chunk fallback must leave the result exactly the oracle's."""
+    from dump1090_rs_amd import Context
+    n = 6 * 131072
+    iq = synth.make_iq(n, n_bursts=30, seed=5150)
+    for k, amps in enumerate(ADVERSARIAL_PERIODS):
+        a, b = k * 131072 + 40000, k * 131072 + 40000 + 60000 + 1000 * k
+        tile = np.tile(np.array(amps, dtype=np.int16), (b - a) // len(amps) + 1)[: b - a]
+        iq[a:b, 0] = tile
+        iq[a:b, 1] = 0
+    # one buffer that is periodic from end to end, and noise riding on a periodic carrier
+    tile = np.tile(np.array(ADVERSARIAL_PERIODS[0], dtype=np.int16), 131072 // 8)
+    iq[4 * 131072: 5 * 131072, 0] = tile
+    iq[4 * 131072: 5 * 131072, 1] = 0
+    iq[5 * 131072 + 1000: 5 * 131072 + 90000, 0] += np.tile(np.array(ADVERSARIAL_PERIODS[1], dtype=np.int16), 9000)[:89000] // 2
+    orc = oracle_mod.Oracle()
+    want, st = orc.demod_iq(iq, cap=1 << 20)
+    assert st.quiet_pass > 60000                      # ~10 % of all positions were sliced
+    for max_chunks in (8, 1):
+        with Context(0, max_chunks) as c:
+            c.icao_flush()
+            got = c.demod_iq(iq, cap=1 << 20)
+            assert_same(got, want)
+            assert c.stats()["n_candidates"] == st.quiet_pass or c.stats()["retries"] > 0
+    # and in carry-over mode (the fallback kernel has its own lead-in path)
+    from oracle.binding import demod_iq_carry
+    carry = np.zeros((326, 2), np.int16)
+    want_c, _ = demod_iq_carry(oracle_mod.Oracle(), iq, carry, cap=1 << 20)
+    with Context(0, 1) as c:
+        c.set_carry_over(True)
+        c.icao_flush()
+        assert_same(c.demod_iq(iq, cap=1 << 20), want_c)
