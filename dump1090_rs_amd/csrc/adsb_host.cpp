@@ -39,7 +39,7 @@ struct Slot {
     Counters *d_ctr = nullptr;
     uint64_t *d_ap = nullptr, *d_hits = nullptr;
     uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
-    bool done_recorded = false;    // `done` has been recorded at least once
+                                   // (kept until the slot is reused: the overflow fallback re-reads it)
     hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
     uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
@@ -92,9 +92,11 @@ struct adsb_ctx {
     hipStream_t copy_stream = nullptr;
 
     bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
+    uint32_t *d_carry_next = nullptr;  // the end of the latest submission's input: the next one's lead-in
 
     // sharded capture (adsb_shard_scan / adsb_shard_finish): the pass parked between its two phases
     bool shard_active = false;
+    bool shard_by_chunk = false;  // the shard overflowed the fast scan's lists: both phases go chunk by chunk
     ScanParams shard_params{};
     uint32_t *d_addrs = nullptr;
     size_t addrs_cap = 0;
@@ -242,15 +244,16 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     c->flush_pending = false;
     const bool classic = prof > 1 || (prof == 1 && (!fast || !ext_events));
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
+    if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
+        HIP_TRY(c, hipMemcpyAsync(sl.d_carry, c->d_carry_next, kCarrySamples * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, c->stream));
     if (int e = force_simple ? launch_scan_simple(p, from_mag, c->stream) : launch_scan(p, from_mag, c->stream))
         return fail(c, (hipError_t)e, "launch_scan");
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
     if (p.carry && advance_carry) {
-        // the next pass (other slot) starts from the end of this one's input.  That slot's
-        // previous pass may still be reading its carry in its records kernel: behind it.
-        Slot &next = c->slot[(&sl - c->slot + 1) % kSlots];
-        if (next.done_recorded) HIP_TRY(c, hipStreamWaitEvent(c->stream, next.done, 0));
-        if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, next.d_carry, c->stream))
+        // the next submission starts from the end of this one's input (taken now: the caller
+        // may reuse the buffer as soon as this pass is collected)
+        if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, c->d_carry_next, c->stream))
             return fail(c, (hipError_t)e, "launch_update_carry");
     }
     // the tail runs on its own stream behind the scan: the next pass's scan does not wait
@@ -271,7 +274,6 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         return fail(c, (hipError_t)e, "launch_records");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
     HIP_TRY(c, hipEventRecord(sl.done, ts));
-    sl.done_recorded = true;
     return ADSB_OK;
 }
 
@@ -474,6 +476,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMalloc((void **)&sl.d_carry, kCarrySamples * sizeof(uint32_t)));
             HIP_TRY(c, hipMemset(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t)));
         }
+        HIP_TRY(c, hipMalloc((void **)&c->d_carry_next, kCarrySamples * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
@@ -551,6 +555,7 @@ void adsb_destroy(adsb_ctx *c)
         if (r.d_iq) (void)hipFree(r.d_iq);
     }
     if (c->d_addrs) (void)hipFree(c->d_addrs);
+    if (c->d_carry_next) (void)hipFree(c->d_carry_next);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->d_timeline && c->debug_stop == 100) {
         // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves
@@ -616,6 +621,7 @@ int adsb_set_carry_over(adsb_ctx *c, int enabled)
     c->carry_over = enabled != 0;
     // the stream starts here: nothing precedes the next call
     for (Slot &sl : c->slot) HIP_TRY(c, hipMemsetAsync(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ADSB_OK;
 }
@@ -833,6 +839,50 @@ static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors Tri
 // through one filter (adsb_replay_records).  The union is a superset in time of what the
 // filter can hold at any point of the capture, so the result is the single-stream one.
 // ---------------------------------------------------------------------------------
+namespace {
+
+// One 131072-sample buffer of a parked shard through the reference-shaped kernel, whose lists
+// hold the worst case of a buffer: scan (+ match) + records, synchronously.  The records land
+// in the slot's host buffer with chunk = 0; *n_out = how many.
+int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, uint32_t *clean, size_t *n_out)
+{
+    Slot &sl = c->slot[0];
+    const uint64_t off = ch * kChunkSamples;
+    p.src = (const uint32_t *)p.src + off;
+    p.n_samples = std::min<uint64_t>(kChunkSamples, p.n_samples - off);
+    p.n_chunks = 1;
+    p.keep_counters = 0;
+    p.clean_bitmap = clean;
+    sl.seq = c->next_seq++;
+    if (c->next_seq == 0) c->next_seq = 1;
+    sl.h_sum->seq = 0;
+    p.seq = sl.seq;
+    if (int e = launch_scan_simple(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan_simple");
+    if (with_match)
+        if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
+    if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq || sl.h_sum->overflow) {
+        c->last_error = "shard: a single buffer overflowed the worst-case lists";
+        return ADSB_ERR_HIP;
+    }
+    *n_out = sl.h_sum->n_hits;
+    return ADSB_OK;
+}
+
+// mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17): the addresses the replay will add
+void learned_addresses(const adsb_ctx *c, const TrialRecord *rec, size_t n, std::vector<uint32_t> &addrs)
+{
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *m = rec[i].msg;
+        const uint32_t df = m[0] >> 3;
+        const bool adds = df == 17 || (df == 11 && c->crc.residual(m, 7) == 0);
+        if (adds) addrs.push_back(uint32_t(m[1]) << 16 | uint32_t(m[2]) << 8 | m[3]);
+    }
+}
+
+}  // namespace
+
 int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32_t *addrs_out, size_t cap,
                     size_t *n_addrs)
 {
@@ -871,6 +921,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     sl.h_sum->seq = 0;
     p.seq = sl.seq;
     size_t n_hits = 0;
+    bool by_chunk = false;
     if (n_chunks) {
         if (int e = launch_scan(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
         if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
@@ -879,25 +930,27 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
             c->last_error = "shard scan completed without publishing its summary";
             return ADSB_ERR_HIP;
         }
-        if (sl.h_sum->overflow) {
-            // leave the device state clean for the next call
-            p.keep_counters = 0;
-            p.clean_bitmap = retired;
-            (void)launch_records(p, false, sl.h_rec_dev, c->stream);
-            (void)hipStreamSynchronize(c->stream);
-            c->last_error = "shard too dense for the device lists: use smaller shards";
-            return ADSB_ERR_HIP;
-        }
+        by_chunk = sl.h_sum->overflow != 0;
         n_hits = sl.h_sum->n_hits;
     }
-    // the addresses the replay will add: mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17)
     std::vector<uint32_t> addrs;
-    for (size_t i = 0; i < n_hits; i++) {
-        const uint8_t *m = sl.h_rec[i].msg;
-        const uint32_t df = m[0] >> 3;
-        const bool adds = df == 17 || (df == 11 && c->crc.residual(m, 7) == 0);
-        if (adds) addrs.push_back(uint32_t(m[1]) << 16 | uint32_t(m[2]) << 8 | m[3]);
+    if (by_chunk) {
+        // Far denser than the fast scan's lists are sized for: zero this pass's counters (the
+        // records kernel does that on its way out), then both phases go buffer by buffer
+        // through the reference-shaped kernel, whose lists hold a buffer's worst case.
+        ScanParams q = p;
+        q.keep_counters = 0;
+        if (int e = launch_records(q, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (uint64_t ch = 0; ch < n_chunks; ch++) {
+            size_t k = 0;
+            if (int rc = shard_chunk_pass(c, p, ch, false, nullptr, &k)) return rc;
+            learned_addresses(c, sl.h_rec, k, addrs);
+        }
+    } else {
+        learned_addresses(c, sl.h_rec, n_hits, addrs);
     }
+    c->shard_by_chunk = by_chunk;
     std::sort(addrs.begin(), addrs.end());
     addrs.erase(std::unique(addrs.begin(), addrs.end()), addrs.end());
     p.clean_bitmap = retired;
@@ -931,6 +984,35 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
                                   c->stream));
         if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, c->stream))
             return fail(c, (hipError_t)e, "launch_set_addresses");
+    }
+    if (c->shard_by_chunk) {
+        c->shard_by_chunk = false;
+        std::vector<TrialRecord> all;
+        uint64_t cand = 0, ap = 0;
+        for (uint64_t ch = 0; ch < p.n_chunks; ch++) {
+            size_t k = 0;
+            uint32_t *clean = ch + 1 == p.n_chunks ? p.clean_bitmap : nullptr;
+            if (int rc = shard_chunk_pass(c, p, ch, true, clean, &k)) return rc;
+            for (size_t i = 0; i < k; i++) {
+                TrialRecord r = sl.h_rec[i];
+                r.chunk = (uint32_t)ch;
+                all.push_back(r);
+            }
+            cand += sl.h_sum->n_cand_total;
+            ap += sl.h_sum->n_ap_total;
+        }
+        adsb_stats st{};
+        st.n_samples = p.n_samples;
+        st.n_chunks = p.n_chunks;
+        st.n_candidates = cand;
+        st.n_ap_entries = ap;
+        st.n_records = all.size();
+        st.retries = 1;
+        c->stats = st;
+        if (n_records) *n_records = all.size();
+        const size_t k = std::min(cap, all.size());
+        if (k) std::memcpy(records_out, all.data(), k * sizeof(adsb_trial));
+        return all.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
     }
     sl.seq = c->next_seq++;
     if (c->next_seq == 0) c->next_seq = 1;

@@ -1,0 +1,189 @@
+"""Randomised parity soak: the HIP path (through the C ABI) against the CPU oracle on seeded
+random captures -- ragged lengths, mixed frame kinds (DF17, DF11, address/parity DF4/DF20),
+overlapping and saturating bursts, adversarial periodic patches, reference and carry-over
+semantics, and every entry point (blocking host / device, pipelined submit/collect, ring,
+two-phase shards).  Test infrastructure (uses oracle/); run on the GPU box:
+
+    python tests/fuzz_gpu.py --cases 200 --seed 1
+
+Exits non-zero at the first mismatch and prints the case so it can be replayed.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+CHUNK = 131072
+PERIODS = [
+    [18143, 6637, 18778, 14788, 3662, 8402, 2882, 16543],
+    [17914, 17500, 12559, 14370, 1698, 4482, 12099, 13742, 8850, 18749, 13607],
+    [4962, 12056, 7113, 852, 14360, 11334, 17932, 13963, 124, 14783, 17800, 508, 13806, 1459],
+]
+
+
+def make_case(rng, synth):
+    n_chunks = int(rng.integers(1, 9))
+    n = int(n_chunks * CHUNK - (rng.integers(0, CHUNK - 400) if rng.random() < 0.6 else 0))
+    n -= n % 4  # device-resident entry points want 16-byte multiples between cuts; keep it simple
+    n = max(n, 400)
+    seed = int(rng.integers(1, 1 << 30))
+    iq = synth.noise_numpy(n, seed=seed)
+    if rng.random() < 0.15:
+        iq //= int(rng.integers(2, 40))          # quiet capture
+    if rng.random() < 0.1:
+        iq = (iq.astype(np.int32) * 12).clip(-32768, 32767).astype(np.int16)  # loud, saturating
+    icaos = [int(x) for x in rng.integers(1, 1 << 24, size=int(rng.integers(1, 12)))]
+    bursts = []
+    for _ in range(int(rng.integers(0, 40 * n_chunks))):
+        icao = icaos[int(rng.integers(0, len(icaos)))]
+        kind = rng.random()
+        if kind < 0.5:
+            frame = synth.df17_frame(icao, int(rng.integers(0, 1 << 56)))
+        elif kind < 0.7:
+            frame = synth.df11_frame(icao)
+        elif kind < 0.85:   # short address/parity (DF 0, 4, 5)
+            body = bytes([int(rng.choice([0x00, 0x20, 0x28])) | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 3).tolist())
+            frame = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+        else:               # long address/parity (DF 16, 20, 21)
+            body = bytes([int(rng.choice([0x80, 0xA0, 0xA8])) | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 10).tolist())
+            frame = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+        tick = int(rng.integers(-200, 5 * n))
+        if rng.random() < 0.2:  # hug a buffer edge
+            tick = 5 * (CHUNK * int(rng.integers(0, n_chunks + 1)) - int(rng.integers(0, 330))) + int(rng.integers(0, 5))
+        bursts.append(synth.Burst(tick, int(rng.integers(1500, 32000)), int(rng.integers(0, 16)), frame))
+    synth.add_bursts(iq, bursts)
+    for _ in range(int(rng.integers(0, 3))):
+        if rng.random() < 0.5:
+            amps = np.array(PERIODS[int(rng.integers(0, len(PERIODS)))], dtype=np.int16)
+            a = int(rng.integers(0, max(1, n - 100)))
+            b = min(n, a + int(rng.integers(50, 30000)))
+            iq[a:b, 0] = np.tile(amps, (b - a) // len(amps) + 1)[: b - a]
+            iq[a:b, 1] = 0
+    return iq, seed
+
+
+def key(m):
+    return (m.chunk, m.j, m.try_phase, m.score, m.msglen, m.msg, m.signal_level)
+
+
+def okey(w):
+    return (w["chunk"], w["j"], w["try_phase"], w["score"], w["len"], w["msg"], w["signal_level"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="replay just this case of the seed")
+    ap.add_argument("--api", default="", help="with --only: force this entry point")
+    ap.add_argument("--ringcuts", action="store_true", help="with --only: cut every 2 buffers, as the ring does")
+    args = ap.parse_args()
+    import torch
+    from dump1090_rs_amd import Context, sharding, synth
+    from dump1090_rs_amd.context import replay_records
+    from oracle import binding
+    from oracle.binding import demod_iq_carry
+
+    rng = np.random.default_rng(args.seed)
+    ctx = Context(0, 8)
+    ctx.ring_create(2 * CHUNK)
+    shard_ctx = [Context(0, 8), Context(0, 8)]
+    t0 = time.time()
+    modes = {}
+    for case in range(args.cases):
+        iq, seed = make_case(rng, synth)
+        n = len(iq)
+        carry_mode = rng.random() < 0.35
+        api = str(rng.choice(["host", "device", "pipelined", "ring", "shards"]))
+        if carry_mode and api == "shards":
+            api = "device"
+        ncuts = int(rng.integers(1, 4))
+        cut_draw = rng.integers(1, n, size=ncuts - 1)
+        if args.only >= 0 and case != args.only:
+            continue
+        if args.only >= 0 and args.api:
+            api = args.api
+        modes[(api, carry_mode)] = modes.get((api, carry_mode), 0) + 1
+        # cut the stream into 1-3 calls (filter and carry persist across them)
+        cuts = sorted(set([0, n] + [int(x) // 4 * 4 for x in cut_draw]))
+        if args.ringcuts:
+            cuts = list(range(0, n, 2 * CHUNK)) + [n]
+        orc = binding.Oracle()
+        carry = np.zeros((326, 2), np.int16)
+        wants = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            w = demod_iq_carry(orc, iq[a:b], carry, cap=1 << 20)[0] if carry_mode else orc.demod_iq(iq[a:b], cap=1 << 20)[0]
+            wants.append([okey(x) for x in w])
+        ctx.set_carry_over(carry_mode)
+        ctx.icao_flush()
+        gots = []
+        dev = torch.from_numpy(iq).cuda() if api in ("device", "pipelined", "shards") else None
+        if api == "host":
+            gots = [[key(m) for m in ctx.demod_iq(iq[a:b], cap=1 << 20)] for a, b in zip(cuts[:-1], cuts[1:])]
+        elif api == "device":
+            gots = [[key(m) for m in ctx.demod_iq_device(dev.data_ptr() + 4 * a, b - a, cap=1 << 20)]
+                    for a, b in zip(cuts[:-1], cuts[1:])]
+        elif api == "pipelined":
+            pend = 0
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if pend == 2:
+                    gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
+                    pend -= 1
+                ctx.submit_iq_device(dev.data_ptr() + 4 * a, b - a)
+                pend += 1
+            while pend:
+                gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
+                pend -= 1
+        elif api == "ring":
+            # the ring takes at most 2 buffers per slot: cut accordingly (oracle redone to match)
+            cuts = list(range(0, n, 2 * CHUNK)) + [n]
+            orc = binding.Oracle()
+            carry = np.zeros((326, 2), np.int16)
+            wants = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                w = demod_iq_carry(orc, iq[a:b], carry, cap=1 << 20)[0] if carry_mode else orc.demod_iq(iq[a:b], cap=1 << 20)[0]
+                wants.append([okey(x) for x in w])
+            pend = 0
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if pend == 2:
+                    gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
+                    pend -= 1
+                buf = ctx.ring_acquire()
+                buf[: b - a] = iq[a:b]
+                ctx.ring_submit(b - a)
+                pend += 1
+            while pend:
+                gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
+                pend -= 1
+        else:  # shards: the whole capture as one stream over two contexts
+            wants = [[okey(x) for x in binding.Oracle().demod_iq(iq, cap=1 << 20)[0]]]
+            spans = [sharding.sample_range(n, 2, r) for r in range(2)]
+            for c in shard_ctx:
+                c.icao_flush()
+            learned = [c.shard_scan(dev.data_ptr() + 4 * a, b - a) for c, (a, b) in zip(shard_ctx, spans)]
+            union = np.unique(np.concatenate(learned)) if learned else np.zeros(0, np.uint32)
+            recs = [c.shard_finish(union) for c in shard_ctx]
+            merged = sharding.merge_records(recs, [a // CHUNK for a, _ in spans])
+            gots = [[key(m) for m in replay_records(merged, cap=1 << 20)]]
+        if gots != wants:
+            print(f"MISMATCH case {case} (fuzz seed {args.seed}, noise seed {seed}): api={api} carry={carry_mode} "
+                  f"n={n} cuts={cuts} frames want {[len(w) for w in wants]} got {[len(g) for g in gots]}")
+            for w, g in zip(wants, gots):
+                for x, y in zip(w, g):
+                    if x != y:
+                        print(" first difference:", x, y)
+                        break
+            sys.exit(1)
+    print(f"{args.cases} cases identical in {time.time() - t0:.1f} s; modes: "
+          + ", ".join(f"{k[0]}{'+carry' if k[1] else ''}={v}" for k, v in sorted(modes.items())))
+
+
+if __name__ == "__main__":
+    main()

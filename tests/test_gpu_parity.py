@@ -553,3 +553,17 @@ def test_adversarial_periodic_input_keeps_every_capacity_path_exact(hip_lib, ora
         c.set_carry_over(True)
         c.icao_flush()
         assert_same(c.demod_iq(iq, cap=1 << 20), want_c)
+
+
+def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
+    """tests/fuzz_gpu.py: seeded random captures (ragged lengths, mixed frame kinds, bursts at
+    buffer edges, saturation, adversarial patches) through every entry point -- blocking,
+    pipelined, ring, two-phase shards -- in reference and carry-over semantics, each against
+    the oracle.  (Longer runs: python tests/fuzz_gpu.py --cases 1000 --seed N.)"""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "80", "--seed", "7"],
+                       capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "80 cases identical" in r.stdout
