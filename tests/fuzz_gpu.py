@@ -28,8 +28,8 @@ PERIODS = [
 ]
 
 
-def make_case(rng, synth):
-    n_chunks = int(rng.integers(1, 9))
+def make_case(rng, synth, max_chunks=8):
+    n_chunks = int(rng.integers(1, max_chunks + 1))
     n = int(n_chunks * CHUNK - (rng.integers(0, CHUNK - 400) if rng.random() < 0.6 else 0))
     n -= n % 4  # device-resident entry points want 16-byte multiples between cuts; keep it simple
     n = max(n, 400)
@@ -81,6 +81,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-chunks", type=int, default=8, help="captures of 1..N buffers (ring slots stay 2 buffers)")
     ap.add_argument("--only", type=int, default=-1, help="replay just this case of the seed")
     ap.add_argument("--api", default="", help="with --only: force this entry point")
     ap.add_argument("--ringcuts", action="store_true", help="with --only: cut every 2 buffers, as the ring does")
@@ -92,13 +93,13 @@ def main():
     from oracle.binding import demod_iq_carry
 
     rng = np.random.default_rng(args.seed)
-    ctx = Context(0, 8)
+    ctx = Context(0, args.max_chunks)
     ctx.ring_create(2 * CHUNK)
-    shard_ctx = [Context(0, 8), Context(0, 8)]
+    shard_ctx = [Context(0, args.max_chunks), Context(0, args.max_chunks)]
     t0 = time.time()
     modes = {}
     for case in range(args.cases):
-        iq, seed = make_case(rng, synth)
+        iq, seed = make_case(rng, synth, args.max_chunks)
         n = len(iq)
         carry_mode = rng.random() < 0.35
         api = str(rng.choice(["host", "device", "pipelined", "ring", "shards"]))
