@@ -205,6 +205,11 @@ def main():
             "other_kernels_avg_ms": {"k_match": round(match_ms / args.steps, 4),
                                      "k_records": round(rec_ms / args.steps, 4)},
             "device_chain_avg_ms": round(dev_ms / args.steps, 4),
+            # consecutive pipelined launches overlap by about one tile round (two scan streams):
+            # a launch's own duration then includes time it shared the GPU with its neighbour;
+            # the rate the GPU sustains over whole steps is bytes / ms_per_step
+            "launches_overlap": not args.sync,
+            "achieved_over_steps": round(BYTES_PER_SAMPLE * n * args.steps / elapsed / 1e9, 1),
         },
         "device_stats_last_step": {k: stats[k] for k in
                                    ("n_candidates", "n_ap_entries", "n_records", "n_messages", "retries")},

@@ -72,6 +72,14 @@ struct adsb_ctx {
     uint32_t *d_bitmap[3] = {nullptr, nullptr, nullptr};
     int cur_bitmap = 0;
     hipStream_t tail_stream = nullptr;  // match + records of pass i run here, beside scan i+1
+    // The scans run on two internal streams, alternating between consecutive pipelined passes:
+    // those do not depend on each other (own lists and counters per slot; bits another scan
+    // adds to the bitmap meanwhile only widen the superset), so the next scan's workgroups
+    // fill the CUs as the previous scan's persistent grid drains instead of waiting ~13 us
+    // behind an in-order queue's end-of-kernel barrier.  `stream` (the caller's) only orders
+    // the input: each scan waits for the point `stream` had reached at submit.
+    hipStream_t scan_stream[2] = {nullptr, nullptr};
+    hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
     uint64_t *d_dap = nullptr;
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0;
@@ -243,26 +251,34 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
 
     c->flush_pending = false;
     const bool classic = prof > 1 || (prof == 1 && (!fast || !ext_events));
-    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], c->stream));
+    // odd slots scan on the second stream, unless something orders consecutive passes (the
+    // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
+    static const bool one_scan_stream = std::getenv("ADSB_ONE_SCAN_STREAM") != nullptr;
+    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (&sl - c->slot) == 1;
+    hipStream_t ss = c->scan_stream[second ? 1 : 0];
+    hipEvent_t ready = c->input_ready[second ? 1 : 0];
+    HIP_TRY(c, hipEventRecord(ready, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
+    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));
     if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
         HIP_TRY(c, hipMemcpyAsync(sl.d_carry, c->d_carry_next, kCarrySamples * sizeof(uint32_t),
-                                  hipMemcpyDeviceToDevice, c->stream));
-    if (int e = force_simple ? launch_scan_simple(p, from_mag, c->stream) : launch_scan(p, from_mag, c->stream))
+                                  hipMemcpyDeviceToDevice, ss));
+    if (int e = force_simple ? launch_scan_simple(p, from_mag, ss) : launch_scan(p, from_mag, ss))
         return fail(c, (hipError_t)e, "launch_scan");
-    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], c->stream));
+    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], ss));
     if (p.carry && advance_carry) {
         // the next submission starts from the end of this one's input (taken now: the caller
         // may reuse the buffer as soon as this pass is collected)
-        if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, c->d_carry_next, c->stream))
+        if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, c->d_carry_next, ss))
             return fail(c, (hipError_t)e, "launch_update_carry");
     }
     // the tail runs on its own stream behind the scan: the next pass's scan does not wait
     // for it (it works on the other slot's lists and counters)
     // (a blocking call has nothing to overlap with: its tail stays on the scan stream and
     // saves the cross-stream hand-off)
-    hipStream_t ts = inline_tail ? c->stream : c->tail_stream;
+    hipStream_t ts = inline_tail ? ss : c->tail_stream;
     if (!inline_tail) {
-        HIP_TRY(c, hipEventRecord(sl.scanned, c->stream));
+        HIP_TRY(c, hipEventRecord(sl.scanned, ss));
         HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
     }
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
@@ -322,7 +338,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     int rc = finish_pass(c, sl, 0, st, out);
     if (rc > 0 && !sl.from_mag) {
         st.retries++;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // later passes have their results on the host
+        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
         const bool keep_flush = c->flush_pending;
         c->flush_pending = false;
@@ -467,6 +483,18 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         c->stream = c->own_stream;
         HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
         HIP_TRY(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
+        {
+            // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+            // default) and two streams on one queue run strictly one after the other; queues
+            // are pooled per priority, so giving the two scan streams different priorities
+            // guarantees that they can overlap whatever else the process has created.
+            int least = 0, greatest = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, least));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, greatest));
+        }
+        for (auto &e : c->input_ready)
+            HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
         for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapBytes));
         for (Slot &sl : c->slot) {
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
@@ -543,6 +571,13 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_mag) (void)hipFree(c->d_mag);
     for (auto &b : c->d_bitmap)
         if (b) (void)hipFree(b);
+    for (hipStream_t q : c->scan_stream)
+        if (q) {
+            (void)hipStreamSynchronize(q);
+            (void)hipStreamDestroy(q);
+        }
+    for (hipEvent_t e : c->input_ready)
+        if (e) (void)hipEventDestroy(e);
     if (c->tail_stream) {
         (void)hipStreamSynchronize(c->tail_stream);
         (void)hipStreamDestroy(c->tail_stream);
