@@ -45,6 +45,9 @@ pub struct AdsbCtx {
 extern "C" {
     pub fn adsb_create(out: *mut *mut AdsbCtx, device: c_int, max_chunks: usize) -> c_int;
     pub fn adsb_destroy(ctx: *mut AdsbCtx);
+    pub fn adsb_set_stream(ctx: *mut AdsbCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn adsb_set_profiling(ctx: *mut AdsbCtx, level: c_int) -> c_int;
+    pub fn adsb_set_carry_over(ctx: *mut AdsbCtx, enabled: c_int) -> c_int; // opt-in, not the reference's semantics
     pub fn adsb_icao_flush(ctx: *mut AdsbCtx) -> c_int;
     pub fn adsb_to_mag(ctx: *mut AdsbCtx, iq_re_im: *const i16, n: usize, data_out: *mut u16, length_out: *mut usize) -> c_int;
     pub fn adsb_demodulate2400(ctx: *mut AdsbCtx, data: *const u16, length: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
