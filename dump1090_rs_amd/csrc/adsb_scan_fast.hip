@@ -159,7 +159,7 @@ struct alignas(16) FastLds {
     uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch terms << 13
     uint32_t cand[kWaves * kCandPerWave];  // per wave: slot | slot/12 << 13 | slot%12 << 23
     uint64_t hit[kHitCap];
-    uint32_t nap, nhit, hit_base;
+    uint32_t nap[2], nhit[2], hit_base;  // tile counters, double-buffered by tile parity
 };
 
 // P4, one pattern match: high / base_signal / base_noise of the branch that matched first
@@ -265,12 +265,13 @@ __device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 
 }
 
 // a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
-__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane)
+__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane,
+                                          uint32_t par)
 {
     const unsigned long long mh = __ballot(is_hit);
     if (!mh) return;
     uint32_t at = 0;
-    if (lane == 0) at = atomicAdd(&s.nhit, (uint32_t)__popcll(mh));
+    if (lane == 0) at = atomicAdd(&s.nhit[par], (uint32_t)__popcll(mh));
     at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
     if (is_hit) {
         if (at < (uint32_t)kHitCap) {
@@ -384,6 +385,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
             s.field[i - 16] = v;
     }
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
+    if (tid < 2) {
+        s.nap[tid] = 0;
+        s.nhit[tid] = 0;
+    }
 
     const uint32_t seg_cap = p.ap_cap / kApSegments;
     uint64_t *const seg = p.ap + (uint64_t)blockIdx.x * seg_cap;  // this workgroup's AP segment
@@ -414,10 +419,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     const int len = cur.len, jbase = cur.jbase;
     const int jn = min(kTile, len - jbase);  // <= 0 for tiles past the end of a short chunk
 
-    if (tid == 0) {
-        s.nap = 0;
-        s.nhit = 0;
-    }
+    const uint32_t par = iter & 1u;  // which copy of the tile counters this tile uses
 
     // ---------------------------------------------------------------- P1 magnitudes
 #pragma unroll
@@ -428,6 +430,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     if (t + gridDim.x < n_tiles) load_tile_iq(p, tile_ref(p, t + gridDim.x), tid, pre);
     ACCT(0);
     lds_barrier();
+    // every thread is past the previous tile's epilogue: its counters can be zeroed for the next
+    // tile (this tile counts in the other copy), so the tile needs no barrier at its end
+    if (tid == 0) {
+        s.nap[par ^ 1u] = 0;
+        s.nhit[par ^ 1u] = 0;
+    }
     ACCT(1);
     STAMP(1);
     if (jn <= 0 || p.debug_stop == 1) {
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
 #pragma unroll
                     for (int q = 0; q < kTrialSlots; q++) total += (uint32_t)__popcll(ma[q]);
                     uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s.nap, total);
+                    if (lane == 0) at = atomicAdd(&s.nap[par], total);
                     at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
 #pragma unroll
                     for (int q = 0; q < kTrialSlots; q++) {
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 }
                 if (any_hit) {  // rare
 #pragma unroll
-                    for (int q = 0; q < kTrialSlots; q++) stage_hit(p, s, is_hit[q], entry[q], lane);
+                    for (int q = 0; q < kTrialSlots; q++) stage_hit(p, s, is_hit[q], entry[q], lane, par);
                 }
                 if (any_learn) {  // rare: the host replay will add this address to the filter
 #pragma unroll
@@ -730,12 +738,12 @@ tile_end:
     // ---------------------------------------------------------------- tile epilogue
     // The AP fill count of the private segment is a register; it is written back once
     // when the workgroup retires.
-    ap_count += s.nap;
+    ap_count += s.nap[par];
     if (ap_count > seg_cap) {
         ap_count = seg_cap;
         if (tid == 0) atomicOr(&p.ctr->overflow, 2u);
     }
-    const uint32_t nhit = min(s.nhit, (uint32_t)kHitCap);
+    const uint32_t nhit = min(s.nhit[par], (uint32_t)kHitCap);
     if (nhit) {  // rare: a handful per chunk
         if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
         lds_barrier();
@@ -746,8 +754,6 @@ tile_end:
         }
     }
     ACCT(6);
-    lds_barrier();  // counters and lists are reset / reused by the next tile
-    ACCT(7);
     STAMP(6);
     }  // tile loop
 #ifdef ADSB_KERNEL_ACCT
