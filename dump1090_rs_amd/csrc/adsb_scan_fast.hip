@@ -156,7 +156,7 @@ struct alignas(16) FastLds {
     uint32_t tab[3 * 256];             // F'0 F'1 F'2 (adsb_tables.h)
     uint32_t r16[16];                  // x^24..x^27 reduction
     uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
-    uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch terms << 13
+    uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
     uint32_t cand[kWaves * kCandPerWave];  // per wave: slot | slot/12 << 13 | slot%12 << 23
     uint64_t hit[kHitCap];
     uint32_t nap[2], nhit[2], hit_base;  // tile counters, double-buffered by tile parity
@@ -174,8 +174,14 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
     const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
               p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
     const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
-    // 0 / -1 masks of the branch's terms (signed 1-bit field extracts)
-#define TERM(bit) __builtin_amdgcn_sbfe((int)ent, 13 + (bit), 1)
+    // the branch's terms (kBranchTerms, 10 bits each, packed into one 64-bit constant) as
+    // 0 / -1 masks (signed 1-bit field extracts)
+    constexpr unsigned long long kTermsPacked =
+        (unsigned long long)kBranchTerms[0] | ((unsigned long long)kBranchTerms[1] << 10) |
+        ((unsigned long long)kBranchTerms[2] << 20) | ((unsigned long long)kBranchTerms[3] << 30) |
+        ((unsigned long long)kBranchTerms[4] << 40);
+    const int terms = (int)(uint32_t)(kTermsPacked >> (10u * ((ent >> 13) & 7u)));
+#define TERM(bit) __builtin_amdgcn_sbfe(terms, (bit), 1)
     const int s39 = p3 + p9, s410 = p4 + p10;
     const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
     const int sig = (p1 & TERM(4)) + (s39 & TERM(5)) + (p12 & TERM(6)) + (s410 & TERM(7));
@@ -579,8 +585,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     }
     const uint32_t slot0 = (uint32_t)(12 * 32 * pw + pres);
     const uint32_t any_all = b[0] | b[1] | b[2] | b[3] | b[4];
-    const uint32_t total_all =
-        (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)__popc(any_all)), 63);
+    // which branch matched, as three planes of a 3-bit code (0..4), so that compaction is one
+    // loop over the union instead of one per branch
+    const uint32_t code0 = b[1] | b[3], code1 = b[2] | b[3], code2 = b[4];
+    const uint32_t cnt_all = (uint32_t)__popc(any_all);
+    const uint32_t incl_all = wave_inclusive_scan(cnt_all);
+    const uint32_t total_all = (uint32_t)__builtin_amdgcn_readlane((int)incl_all, 63);
     // all matches in one round when they fit the wave's region (the normal case: ~90 of
     // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
     const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
@@ -600,22 +610,24 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 // counts (DPP, no LDS traffic), then every lane writes its own
                 const uint32_t rmask = nrounds == 1 ? 0xFFFFFFFFu
                                                     : (((1u << kRoundBits) - 1u) << (round * kRoundBits));
-                const uint32_t cnt = (uint32_t)__popc(any_all & rmask);
-                const uint32_t incl = wave_inclusive_scan(cnt);
-                npat_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t cnt = cnt_all, incl = incl_all;
+                npat_w = total_all;
+                if (nrounds != 1) {
+                    cnt = (uint32_t)__popc(any_all & rmask);
+                    incl = wave_inclusive_scan(cnt);
+                    npat_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
                 if (npat_w == 0) {
                     round++;
                     continue;
                 }
                 uint32_t at = incl - cnt;
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    uint32_t m = b[k] & rmask;
-                    while (m) {
-                        const int bit = __ffs(m) - 1;
-                        m &= m - 1;
-                        wpat[at++] = (slot0 + 12u * (uint32_t)bit) | (kBranchTerms[k] << 13);
-                    }
+                uint32_t m = any_all & rmask;
+                while (m) {
+                    const uint32_t bit = (uint32_t)__ffs(m) - 1u;
+                    m &= m - 1;
+                    const uint32_t k = ((code0 >> bit) & 1u) | (((code1 >> bit) & 1u) << 1) | (((code2 >> bit) & 1u) << 2);
+                    wpat[at++] = (slot0 + 12u * bit) | (k << 13);
                 }
                 wave_lds_fence();
                 in_round = true;
