@@ -55,18 +55,20 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     // the x^56 multiplier table (3 KB) is read through the vector cache: staging it in LDS
     // first costs every block a global round trip before it can start
     const uint32_t *stab = p.tables + kTabX56 * 256;
-    const uint32_t seg_cap = p.ap_cap / kApSegments;
-    // work units: the kApSegments segments of the fast scan's list, then the dap list; two
-    // blocks share a unit (the grid is 2 x units) so that the usual ~1500 entries of a
-    // segment are a single trip
+    const uint32_t seg_cap = p.ap_cap / kApWaveSegs;
+    // work units: the kApWaveSegs wave segments of the fast scan's list (a few hundred entries
+    // each: one trip), then the dap list of the simple kernel, which all the blocks past the
+    // segments share
     {
-        const uint32_t sg = blockIdx.x >> 1, half = blockIdx.x & 1u;
-        const bool is_dap = sg == (uint32_t)kApSegments;
+        const bool is_dap = blockIdx.x >= (uint32_t)kApWaveSegs;
+        const uint32_t sg = blockIdx.x;
         const uint32_t n = is_dap ? min(p.ctr->n_dap, p.dap_cap) : min(p.ctr->seg_ap[sg], seg_cap);
         const uint64_t *ap = is_dap ? p.dap : p.ap + (uint64_t)sg * seg_cap;
+        const uint32_t first = is_dap ? (blockIdx.x - kApWaveSegs) * 4 * blockDim.x : 0u;
+        const uint32_t stride = is_dap ? (gridDim.x - kApWaveSegs) * 4 * blockDim.x : 4 * blockDim.x;
         // four entries per thread per trip: their list loads, then their bitmap loads, are
         // in flight together (the chain entry -> residual -> bitmap word is all latency)
-        for (uint32_t i0 = half * 4 * blockDim.x + threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+        for (uint32_t i0 = first + threadIdx.x; i0 < n; i0 += stride) {
             uint64_t e[4];
             uint32_t w[4], c[4];
 #pragma unroll
@@ -224,10 +226,8 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     if (!is_last) return;
     if (threadIdx.x < 64) {
         uint32_t ap = 0, cand = 0;
-        for (int i = lane; i < kApSegments; i += 64) {
-            ap += p.ctr->seg_ap[i];
-            cand += p.ctr->seg_cand[i];
-        }
+        for (int i = lane; i < kApWaveSegs; i += 64) ap += p.ctr->seg_ap[i];
+        for (int i = lane; i < kApSegments; i += 64) cand += p.ctr->seg_cand[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             ap += __shfl_down(ap, off);
@@ -315,9 +315,9 @@ int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
 
 int launch_match(const ScanParams &p, void *stream)
 {
-    // two blocks per segment of the fast scan's AP list and for the dap list; the fill
+    // one block per wave segment of the fast scan's AP list, 64 for the dap list; the fill
     // counts live on the device
-    const uint32_t blocks = 2 * (kApSegments + 1);
+    const uint32_t blocks = kApWaveSegs + 64;  // 64 blocks share the dap list
     hipLaunchKernelGGL(k_match, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }

@@ -56,12 +56,14 @@ struct TrialRecord {
 };
 static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 
-// The AP list of the fast scan is split into kApSegments equal segments; persistent
-// workgroup b owns segment b outright, so appending needs no atomic at all (a returning
-// global atomic costs a workgroup 1-2 us per tile, and one hot counter saturates near
-// 90 atomics/us on this chip).  The simple kernel appends to a second list,
-// `dap`, through one shared counter: it is the slow path anyway.
+// The AP list of the fast scan is split into kApWaveSegs equal segments: every wave of
+// every persistent workgroup owns one outright, so appending needs no atomic and no shared
+// counter at all (a returning global atomic costs a workgroup 1-2 us per tile, one hot
+// counter saturates near 90 atomics/us on this chip, and even an LDS counter is a round
+// trip per trial pass).  The simple kernel appends to a second list, `dap`, through one
+// shared counter: it is the slow path anyway.
 constexpr int kApSegments = 1024;
+constexpr int kApWaveSegs = 4 * kApSegments;  // one per wave of a persistent workgroup
 
 // Device counters block (one per context).
 struct Counters {
@@ -72,7 +74,7 @@ struct Counters {
     uint32_t n_cand_simple;  // candidates seen by the simple kernel (diagnostic)
     uint32_t blocks_done;    // records kernel: blocks that have finished (last one publishes)
     uint32_t pad[2];
-    uint32_t seg_ap[kApSegments];    // entries in each AP segment
+    uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
 };
 
@@ -98,8 +100,8 @@ struct ScanParams {
     uint32_t *bitmap;       // 2^24 bits
     uint64_t *hits;
     uint32_t hits_cap;
-    uint64_t *ap;           // kApSegments segments of ap_cap / kApSegments entries
-    uint32_t ap_cap;        // a multiple of kApSegments
+    uint64_t *ap;           // kApWaveSegs segments of ap_cap / kApWaveSegs entries
+    uint32_t ap_cap;        // a multiple of kApWaveSegs
     uint64_t *dap;          // AP entries of the simple kernel
     uint32_t dap_cap;
     const uint32_t *tables; // kTabCount x 256

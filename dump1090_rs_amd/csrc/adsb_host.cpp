@@ -471,8 +471,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     // tile's staging buffer so that a single-chunk pass always fits.  Denser input falls
     // back to per-chunk passes.  dap (simple kernel) holds a whole chunk's worst
     // case: every j sliced, five trials each.
-    uint64_t seg = std::max<uint64_t>(2048, (max_chunks * (uint64_t)kChunkSamples / 8 + kApSegments - 1) / kApSegments);
-    c->ap_cap = (uint32_t)std::min<uint64_t>(seg * kApSegments, 0xFFFFFC00u);
+    uint64_t seg = std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + kApWaveSegs - 1) / kApWaveSegs);
+    c->ap_cap = (uint32_t)std::min<uint64_t>(seg * kApWaveSegs, 0xFFFFF000u);
     c->dap_cap = kWorstPerChunk;
     c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
 

@@ -159,7 +159,7 @@ struct alignas(16) FastLds {
     uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
     uint32_t cand[kWaves * kCandPerWave];  // per wave: slot | slot/12 << 13 | slot%12 << 23
     uint64_t hit[kHitCap];
-    uint32_t nap[2], nhit[2], hit_base;  // tile counters, double-buffered by tile parity
+    uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
 };
 
 // P4, one pattern match: high / base_signal / base_noise of the branch that matched first
@@ -391,14 +391,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
             s.field[i - 16] = v;
     }
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
-    if (tid < 2) {
-        s.nap[tid] = 0;
-        s.nhit[tid] = 0;
-    }
+    if (tid < 2) s.nhit[tid] = 0;
 
-    const uint32_t seg_cap = p.ap_cap / kApSegments;
-    uint64_t *const seg = p.ap + (uint64_t)blockIdx.x * seg_cap;  // this workgroup's AP segment
-    uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this workgroup
+    const uint32_t seg_cap = p.ap_cap / kApWaveSegs;
+    const uint32_t my_seg = blockIdx.x * kWaves + (uint32_t)(tid >> 6);
+    uint64_t *const seg = p.ap + (uint64_t)my_seg * seg_cap;  // this wave's own AP segment
+    uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this wave
 
     uint4 pre[kLoadsPerThread];
     if (blockIdx.x < n_tiles) load_tile_iq(p, tile_ref(p, blockIdx.x), tid, pre);
@@ -438,10 +436,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     lds_barrier();
     // every thread is past the previous tile's epilogue: its counters can be zeroed for the next
     // tile (this tile counts in the other copy), so the tile needs no barrier at its end
-    if (tid == 0) {
-        s.nap[par ^ 1u] = 0;
-        s.nhit[par ^ 1u] = 0;
-    }
+    if (tid == 0) s.nhit[par ^ 1u] = 0;
     ACCT(1);
     STAMP(1);
     if (jn <= 0 || p.debug_stop == 1) {
@@ -706,20 +701,14 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                     any_hit |= __ballot(is_hit[q]);
                     any_learn |= __ballot(learn[q]);
                 }
-                // AP entries: straight into this workgroup's own segment, compacted per wave;
-                // s.nap is the workgroup's fill count for this tile
+                // AP entries: straight into this wave's own segment of the list (no atomic, no
+                // shared counter: the fill count is a wave-uniform register)
                 if (any_ap) {
-                    uint32_t total = 0;
-#pragma unroll
-                    for (int q = 0; q < kTrialSlots; q++) total += (uint32_t)__popcll(ma[q]);
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s.nap[par], total);
-                    at = ap_count + (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
 #pragma unroll
                     for (int q = 0; q < kTrialSlots; q++) {
-                        const uint32_t mine = at + mask_rank(ma[q]);
+                        const uint32_t mine = ap_count + mask_rank(ma[q]);
                         if (is_ap[q] && mine < seg_cap) seg[mine] = entry[q];
-                        at += (uint32_t)__popcll(ma[q]);
+                        ap_count += (uint32_t)__popcll(ma[q]);
                     }
                 }
                 if (any_hit) {  // rare
@@ -748,13 +737,7 @@ tile_end:
     }
 
     // ---------------------------------------------------------------- tile epilogue
-    // The AP fill count of the private segment is a register; it is written back once
-    // when the workgroup retires.
-    ap_count += s.nap[par];
-    if (ap_count > seg_cap) {
-        ap_count = seg_cap;
-        if (tid == 0) atomicOr(&p.ctr->overflow, 2u);
-    }
+    // (the AP fill counts are registers; they are written back when the workgroup retires)
     const uint32_t nhit = min(s.nhit[par], (uint32_t)kHitCap);
     if (nhit) {  // rare: a handful per chunk
         if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
@@ -774,7 +757,10 @@ tile_end:
 #endif
     // candidate counts were kept per wave (diagnostic): lane 0 of each wave adds its own
     if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
-    if (tid == 0) p.ctr->seg_ap[blockIdx.x] = ap_count;
+    if (lane == 0) {
+        if (ap_count > seg_cap) atomicOr(&p.ctr->overflow, 2u);
+        p.ctr->seg_ap[my_seg] = min(ap_count, seg_cap);
+    }
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -799,7 +785,7 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
         }
         resident = per_cu * cus;
         if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) resident = std::atoi(e) * cus;
-        if (resident > kApSegments) resident = kApSegments;  // one private AP segment each
+        if (resident > kApSegments) resident = kApSegments;  // four private AP segments (one per wave) each
         if (resident < 1) resident = 1;
         if (std::getenv("ADSB_TIMELINE"))
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
