@@ -56,42 +56,53 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     // first costs every block a global round trip before it can start
     const uint32_t *stab = p.tables + kTabX56 * 256;
     const uint32_t seg_cap = p.ap_cap / kApWaveSegs;
-    // work units: the kApWaveSegs wave segments of the fast scan's list (a few hundred entries
-    // each: one trip), then the dap list of the simple kernel, which all the blocks past the
-    // segments share
-    {
-        const bool is_dap = blockIdx.x >= (uint32_t)kApWaveSegs;
-        const uint32_t sg = blockIdx.x;
-        const uint32_t n = is_dap ? min(p.ctr->n_dap, p.dap_cap) : min(p.ctr->seg_ap[sg], seg_cap);
-        const uint64_t *ap = is_dap ? p.dap : p.ap + (uint64_t)sg * seg_cap;
-        const uint32_t first = is_dap ? (blockIdx.x - kApWaveSegs) * 4 * blockDim.x : 0u;
-        const uint32_t stride = is_dap ? (gridDim.x - kApWaveSegs) * 4 * blockDim.x : 4 * blockDim.x;
-        // four entries per thread per trip: their list loads, then their bitmap loads, are
-        // in flight together (the chain entry -> residual -> bitmap word is all latency)
-        for (uint32_t i0 = first + threadIdx.x; i0 < n; i0 += stride) {
-            uint64_t e[4];
-            uint32_t w[4], c[4];
+    // work units: pairs of wave segments of the fast scan's list (a few hundred entries per
+    // segment), then the dap list of the simple kernel, which all the blocks past the segments
+    // share.  Four entries per thread per trip -- two from each segment of the pair -- so that
+    // their list loads, then their bitmap loads, are in flight together (the chain entry ->
+    // residual -> bitmap word is all latency) and the usual pair is a single trip.
+    const bool is_dap = blockIdx.x >= (uint32_t)kApWaveSegs / 2;
+    uint32_t n[2];
+    const uint64_t *ap[2];
+    uint32_t first = 0, stride = 2 * blockDim.x;
+    if (is_dap) {  // both halves walk the same list, interleaved
+        n[0] = n[1] = min(p.ctr->n_dap, p.dap_cap);
+        ap[0] = ap[1] = p.dap;
+        first = (blockIdx.x - kApWaveSegs / 2) * 4 * blockDim.x;
+        stride = (gridDim.x - kApWaveSegs / 2) * 4 * blockDim.x;
+    } else {
+        for (int h = 0; h < 2; h++) {
+            const uint32_t sg = 2 * blockIdx.x + h;
+            n[h] = min(p.ctr->seg_ap[sg], seg_cap);
+            ap[h] = p.ap + (uint64_t)sg * seg_cap;
+        }
+    }
+    const uint32_t nmax = max(n[0], n[1]);
+    for (uint32_t i0 = first + threadIdx.x; i0 < nmax; i0 += stride) {
+        uint64_t e[4];
+        uint32_t w[4], c[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t i = i0 + k * blockDim.x;
-                e[k] = i < n ? ap[i] : ~0ull;
-            }
+        for (int k = 0; k < 4; k++) {
+            // segment pair: k = 0,1 from the first, 2,3 from the second; dap: four consecutive strides
+            const int h = is_dap ? 0 : k >> 1;
+            const uint32_t i = i0 + (is_dap ? (uint32_t)k : (uint32_t)(k & 1)) * blockDim.x;
+            e[k] = i < n[h] ? ap[h][i] : ~0ull;
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t code = entry_code(e[k]);
-                c[k] = entry_value(e[k]);
-                if (code >= 5 && code < 10) c[k] = gf_apply(stab, c[k]);
-                w[k] = p.bitmap[c[k] >> 5];
-            }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t code = entry_code(e[k]);
+            c[k] = entry_value(e[k]);
+            if (code >= 5 && code < 10) c[k] = gf_apply(stab, c[k]);
+            w[k] = p.bitmap[c[k] >> 5];
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (e[k] != ~0ull && ((w[k] >> (c[k] & 31)) & 1u)) {  // rare: one atomic each
-                    const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
-                    if (idx < p.hits_cap)
-                        p.hits[idx] = e[k];
-                    else
-                        atomicOr(&p.ctr->overflow, 1u);
-                }
+        for (int k = 0; k < 4; k++) {
+            if (e[k] != ~0ull && ((w[k] >> (c[k] & 31)) & 1u)) {  // rare: one atomic each
+                const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
+                if (idx < p.hits_cap)
+                    p.hits[idx] = e[k];
+                else
+                    atomicOr(&p.ctr->overflow, 1u);
             }
         }
     }
@@ -315,9 +326,9 @@ int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
 
 int launch_match(const ScanParams &p, void *stream)
 {
-    // one block per wave segment of the fast scan's AP list, 64 for the dap list; the fill
+    // one block per two wave segments of the fast scan's AP list, 64 for the dap list; the fill
     // counts live on the device
-    const uint32_t blocks = kApWaveSegs + 64;  // 64 blocks share the dap list
+    const uint32_t blocks = kApWaveSegs / 2 + 64;  // 64 blocks share the dap list
     hipLaunchKernelGGL(k_match, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }

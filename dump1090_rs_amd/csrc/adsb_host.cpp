@@ -482,16 +482,18 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
         {
             // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
             // default) and two streams on one queue run strictly one after the other; queues
             // are pooled per priority, so giving the two scan streams different priorities
             // guarantees that they can overlap whatever else the process has created.
+            // (Which of the three levels each stream gets made no measurable difference.)
             int least = 0, greatest = 0;
             HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, least));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, least));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, (least + greatest) / 2));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, greatest));
+            if (std::getenv("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
         }
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1141,6 +1143,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.4 gfx950 scan=v3-flat-trials"; }
+const char *adsb_version(void) { return "adsb_hip 0.5 gfx950 scan=v4-wave-segments"; }
 
 }  // extern "C"
