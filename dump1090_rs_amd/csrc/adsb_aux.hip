@@ -30,11 +30,7 @@ __global__ __launch_bounds__(256) void k_reset(Counters *ctr, uint32_t *bitmap)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr uint32_t kCtrDwords = sizeof(Counters) / 4;
     if (i < kCtrDwords) ((uint32_t *)ctr)[i] = 0;
-    if (bitmap) {
-        constexpr uint32_t kBitmapVec = (1u << 24) / 8 / 16;  // uint4 units
-        for (uint32_t v = i; v < kBitmapVec; v += gridDim.x * blockDim.x)
-            ((uint4 *)bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
-    }
+    if (bitmap) bitmap_clear(bitmap, i, gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -52,9 +48,14 @@ __device__ __forceinline__ uint32_t gf_apply(const uint32_t *tab3, uint32_t h)
 
 __global__ __launch_bounds__(256) void k_match(ScanParams p)
 {
-    // the x^56 multiplier table (3 KB) is read through the vector cache: staging it in LDS
-    // first costs every block a global round trip before it can start
-    const uint32_t *stab = p.tables + kTabX56 * 256;
+    // the x^56 multiplier table (3 KB) and the bitmap's 4096-bit summary in LDS: an entry costs
+    // one coalesced 8-byte load and LDS lookups; only the few per cent of residuals whose low 12
+    // bits are taken by some address go on to the 2 MiB bitmap
+    __shared__ uint32_t stab[3 * 256];
+    __shared__ uint32_t coarse[kCoarseWords];
+    for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) stab[i] = p.tables[kTabX56 * 256 + i];
+    if (threadIdx.x < kCoarseWords) coarse[threadIdx.x] = p.bitmap[kBitmapWords + threadIdx.x];
+    __syncthreads();
     const uint32_t seg_cap = p.ap_cap / kApWaveSegs;
     // work units: pairs of wave segments of the fast scan's list (a few hundred entries per
     // segment), then the dap list of the simple kernel, which all the blocks past the segments
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     const uint32_t nmax = max(n[0], n[1]);
     for (uint32_t i0 = first + threadIdx.x; i0 < nmax; i0 += stride) {
         uint64_t e[4];
-        uint32_t w[4], c[4];
+        uint32_t c[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             // segment pair: k = 0,1 from the first, 2,3 from the second; dap: four consecutive strides
@@ -93,11 +94,11 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
             const uint32_t code = entry_code(e[k]);
             c[k] = entry_value(e[k]);
             if (code >= 5 && code < 10) c[k] = gf_apply(stab, c[k]);
-            w[k] = p.bitmap[c[k] >> 5];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (e[k] != ~0ull && ((w[k] >> (c[k] & 31)) & 1u)) {  // rare: one atomic each
+            if (e[k] == ~0ull || !((coarse[(c[k] & 4095u) >> 5] >> (c[k] & 31)) & 1u)) continue;
+            if ((p.bitmap[c[k] >> 5] >> (c[k] & 31)) & 1u) {  // rare: one atomic each
                 const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
                 if (idx < p.hits_cap)
                     p.hits[idx] = e[k];
@@ -140,11 +141,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     // bitmap, clear it here (address 0 always tests true, src/icao_filter.rs:71-80: bit 0
     // starts set); it comes back into use two flushes later.  This pass's own counters are
     // zeroed at the very end, by the last block to finish.
-    if (p.clean_bitmap) {
-        const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
-        for (uint32_t v = gi; v < (1u << 24) / 8 / 16; v += gn)
-            ((uint4 *)p.clean_bitmap)[v] = make_uint4(v == 0 ? 1u : 0u, 0u, 0u, 0u);
-    }
+    if (p.clean_bitmap) bitmap_clear(p.clean_bitmap, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     // A block owns a contiguous run of hits, so its records leave as one contiguous burst of
     // 16-byte stores (mapped host memory sits behind PCIe: thousands of separate 8-byte writes
     // cost ~6 ns each, wide neighbouring ones combine).  One wave per hit: the window of

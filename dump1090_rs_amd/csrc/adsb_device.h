@@ -122,6 +122,12 @@ struct ScanParams {
     uint32_t lead_from_src;
 };
 
+// The address bitmap: 2^24 bits, followed by a 4096-bit summary (bit a & 4095 is set when any
+// address a is): the match kernel tests the summary from LDS and goes to the big bitmap only
+// for the few per cent of residuals that pass it.
+constexpr uint32_t kBitmapWords = 1u << 19, kCoarseWords = 128;
+constexpr uint32_t kBitmapAllocWords = kBitmapWords + kCoarseWords;
+
 constexpr int kCarrySamples = 328;  // kLead rounded up to whole 16-byte loads
 
 // launches; all asynchronous on `stream`, return a hipError_t as int

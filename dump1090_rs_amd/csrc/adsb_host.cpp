@@ -117,7 +117,6 @@ struct adsb_ctx {
 
 namespace {
 
-constexpr size_t kBitmapBytes = (1u << 24) / 8;
 constexpr uint32_t kWorstPerChunk = 5u * kChunkSamples;  // every j sliced, 5 trials each
 
 int fail(adsb_ctx *c, hipError_t e, const char *what)
@@ -497,7 +496,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
-        for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapBytes));
+        for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapAllocWords * sizeof(uint32_t)));
         for (Slot &sl : c->slot) {
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
