@@ -1,0 +1,32 @@
+"""BASELINE config 1: the reference's `cargo bench` case (benches/demod_benchmark.rs:7-12) --
+icao_flush + to_mag + demodulate2400 on test_iq/test_1641427457780.iq (131072 samples) -- timed
+through the drop-in entry points.  Prints microseconds per iteration."""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+from dump1090_rs_amd import Context
+
+raw = np.fromfile(ROOT / "tests" / "golden" / "test_1641427457780.iq", dtype="<i2").reshape(-1, 2)
+iq = np.ascontiguousarray(raw[:, ::-1])           # file order is [im][re]
+ctx = Context(0, 1)
+dev = torch.from_numpy(iq).cuda()
+
+def timeit(fn, n=200):
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
+
+def ref_api():
+    ctx.icao_flush(); m = ctx.to_mag(iq); return ctx.demodulate2400(m)
+def fused_host():
+    ctx.icao_flush(); return ctx.demod_iq(iq)
+def fused_dev():
+    ctx.icao_flush(); return ctx.demod_iq_device(dev.data_ptr(), len(iq))
+assert len(ref_api()) == len(fused_host()) == len(fused_dev()) == 5
+print(f"to_mag + demodulate2400 (host buffers, the reference's API shape): {timeit(ref_api):8.1f} us")
+print(f"adsb_demod_iq (host IQ in, fused):                                {timeit(fused_host):8.1f} us")
+print(f"adsb_demod_iq_device (IQ resident):                               {timeit(fused_dev):8.1f} us")
