@@ -335,7 +335,14 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     st.n_chunks = sl.n_chunks;
     if (sl.flush_before) c->filter.flush();  // icao_flush() took effect before this pass
     int rc = finish_pass(c, sl, 0, st, out);
-    if (rc > 0 && !sl.from_mag) {
+    if (rc > 0 && sl.from_mag) {  // a caller-supplied buffer denser than the fast scan's lists: again, the slow way
+        st.retries++;
+        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
+        HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        Slot tmp = sl;
+        rc = enqueue_pass(c, tmp, sl.src, true, sl.n_samples, 1, false, false, false, true);
+        if (rc == 0) rc = finish_pass(c, tmp, 0, st, out);
+    } else if (rc > 0) {
         st.retries++;
         for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));

@@ -301,12 +301,14 @@ struct TileRef {
     int tile, len, jbase;
 };
 
+template <bool FROM_MAG>
 __device__ __forceinline__ TileRef tile_ref(const ScanParams &p, uint32_t t)
 {
     TileRef r;
     r.chunk = t / kTilesPerChunk;
     r.tile = (int)(t % kTilesPerChunk);
-    r.len = chunk_len(p.n_samples, r.chunk);
+    // a caller-supplied MagnitudeBuffer is one buffer: n_samples is its `length`
+    r.len = FROM_MAG ? (int)p.n_samples : chunk_len(p.n_samples, r.chunk);
     r.jbase = r.tile * kTile;
     return r;
 }
@@ -318,9 +320,24 @@ __device__ __forceinline__ TileRef tile_ref(const ScanParams &p, uint32_t t)
 // back to back with no branch and no wait between them.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+template <bool FROM_MAG>
 __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef &r, int tid,
                                              uint4 (&pre)[kLoadsPerThread])
 {
+    if (FROM_MAG) {
+        // caller-supplied magnitudes (adsb_demodulate2400): MagnitudeBuffer.data as handed in,
+        // lead-in included; 4 u16 per load, zero outside [0, kMagDataLen) by the range check
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.src, 0, kMagDataLen * 2, 0x00020000);
+        const int d0 = r.jbase - kPad;  // data index of slot 0
+#pragma unroll
+        for (int i = 0; i < kLoadsPerThread; i++) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (d0 + 4 * (tid + i * kThreads)) * 2, 0, 0);
+            pre[i] = make_uint4(v.x, v.y, 0u, 0u);
+        }
+        return;
+    }
     const uint32_t *iq = (const uint32_t *)p.src + r.chunk * (uint64_t)kChunkSamples;
     // carry-over mode: the resource starts kCarrySamples before the buffer when those samples
     // exist in src, so the lead-in is simply in range (the reference's mode: it is not)
@@ -374,6 +391,7 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
 // after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
+template <bool FROM_MAG>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this wave
 
     uint4 pre[kLoadsPerThread];
-    if (blockIdx.x < n_tiles) load_tile_iq(p, tile_ref(p, blockIdx.x), tid, pre);
+    if (blockIdx.x < n_tiles) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, blockIdx.x), tid, pre);
 
     // Workgroups that share a CU start a fraction of a tile period apart, so that the
     // VALU-dense phases of one overlap the latency-bound phases of the others instead of
@@ -417,7 +435,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
 
     uint32_t iter = 0;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x, iter++) {
-    const TileRef cur = tile_ref(p, t);
+    const TileRef cur = tile_ref<FROM_MAG>(p, t);
     STAMP(0);
     const uint32_t chunk = cur.chunk;
     const int len = cur.len, jbase = cur.jbase;
@@ -429,9 +447,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; i++) {
         const int g = tid + i * kThreads;
-        if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = mag4_of(pre[i]);
+        if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = FROM_MAG ? make_uint2(pre[i].x, pre[i].y) : mag4_of(pre[i]);
     }
-    if (t + gridDim.x < n_tiles) load_tile_iq(p, tile_ref(p, t + gridDim.x), tid, pre);
+    if (t + gridDim.x < n_tiles) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t + gridDim.x), tid, pre);
     ACCT(0);
     lds_barrier();
     // every thread is past the previous tile's epilogue: its counters can be zeroed for the next
@@ -769,7 +787,6 @@ inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 int launch_scan(const ScanParams &p, bool from_mag, void *stream)
 {
-    if (from_mag) return launch_scan_simple(p, true, stream);
     const uint32_t tiles = p.n_chunks * kTilesPerChunk;
     if (tiles == 0) return 0;
     // persistent grid = what is resident at once (occupancy API x CUs), found once
@@ -777,7 +794,7 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
     if (resident == 0) {
         int dev = 0, per_cu = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast, kThreads, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast<false>, kThreads, 0) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             per_cu <= 0 || cus <= 0) {
             per_cu = 2;
@@ -793,11 +810,13 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
     const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
     // With events, the launch itself carries them (hipExtLaunchKernelGGL): the dispatch
     // packet's own begin/end timestamps, no barrier packets in the stream around it.
-    if (p.ev_start && p.ev_stop)
-        hipExtLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,
+    if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
+        hipLaunchKernelGGL(k_scan_fast<true>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else if (p.ev_start && p.ev_stop)
+        hipExtLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,
                               (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
     else
-        hipLaunchKernelGGL(k_scan_fast, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

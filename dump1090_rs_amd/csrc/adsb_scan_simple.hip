@@ -4,10 +4,9 @@
 // then every j through the gates (src/demod_2400.rs:121-146) exactly as the reference
 // walks them, then every trial phase sliced bit by bit (:158-182) and scored as far as
 // the device goes (DF class + CRC residual, src/mode_s/mod.rs:41-135).  It is slow
-// (every thread walks 112 bits serially) and serves adsb_demodulate2400, whose input is
-// a caller-supplied MagnitudeBuffer (one chunk; throughput is irrelevant there), and the
-// chunk-by-chunk fallback for input so dense that the fast scan's lists overflow: its lists
-// hold the worst case of a chunk (every position sliced).
+// (every thread walks 112 bits serially) and serves as the chunk-by-chunk fallback for
+// input so dense that the fast scan's lists overflow: its lists hold the worst case of a
+// chunk (every position sliced).  Both input kinds: IQ, or a caller-supplied MagnitudeBuffer.
 #include "adsb_dev_common.h"
 
 namespace adsb {

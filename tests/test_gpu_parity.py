@@ -545,6 +545,20 @@ def test_adversarial_periodic_input_keeps_every_capacity_path_exact(hip_lib, ora
             got = c.demod_iq(iq, cap=1 << 20)
             assert_same(got, want)
             assert c.stats()["n_candidates"] == st.quiet_pass or c.stats()["retries"] > 0
+    # the reference's two-call shape on the fully periodic buffer and on a mixed one: the
+    # caller-supplied magnitudes go through the fast scan too, and through its fallback
+    from dump1090_rs_amd import MagnitudeBuffer
+    with Context(0, 1) as c:
+        for k in (4, 5, 0):
+            part = iq[k * 131072:(k + 1) * 131072 - (777 if k == 0 else 0)]
+            data, length = oracle_mod.Oracle().to_mag(part)
+            data[3:40] = np.arange(37, dtype=np.uint16) * 911      # a lead-in that is not zero
+            want_m, _ = oracle_mod.Oracle().demodulate2400(data, length, cap=1 << 18)
+            mb = MagnitudeBuffer()
+            mb.data[:] = data
+            mb.length = length
+            c.icao_flush()
+            assert_same(c.demodulate2400(mb, cap=1 << 18), want_m)
     # and in carry-over mode (the fallback kernel has its own lead-in path)
     from oracle.binding import demod_iq_carry
     carry = np.zeros((326, 2), np.int16)

@@ -30,3 +30,6 @@ assert len(ref_api()) == len(fused_host()) == len(fused_dev()) == 5
 print(f"to_mag + demodulate2400 (host buffers, the reference's API shape): {timeit(ref_api):8.1f} us")
 print(f"adsb_demod_iq (host IQ in, fused):                                {timeit(fused_host):8.1f} us")
 print(f"adsb_demod_iq_device (IQ resident):                               {timeit(fused_dev):8.1f} us")
+m = ctx.to_mag(iq)
+print(f"  adsb_to_mag alone:                                              {timeit(lambda: ctx.to_mag(iq)):8.1f} us")
+print(f"  adsb_demodulate2400 alone:                                      {timeit(lambda: (ctx.icao_flush(), ctx.demodulate2400(m))):8.1f} us")
