@@ -102,8 +102,8 @@ def main():
         iq, seed = make_case(rng, synth, args.max_chunks)
         n = len(iq)
         carry_mode = rng.random() < 0.35
-        api = str(rng.choice(["host", "device", "pipelined", "ring", "shards"]))
-        if carry_mode and api == "shards":
+        api = str(rng.choice(["host", "device", "pipelined", "ring", "shards", "magbuf"]))
+        if carry_mode and api in ("shards", "magbuf"):
             api = "device"
         ncuts = int(rng.integers(1, 4))
         cut_draw = rng.integers(1, n, size=ncuts - 1)
@@ -163,6 +163,20 @@ def main():
             while pend:
                 gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
                 pend -= 1
+        elif api == "magbuf":
+            # the reference's two-call shape, one 131072-sample buffer at a time (filter persists)
+            from dump1090_rs_amd import MagnitudeBuffer
+            orc = binding.Oracle()
+            wants, gots = [], []
+            for a in range(0, n, CHUNK):
+                part = iq[a:a + CHUNK]
+                data, length = orc.to_mag(part)
+                m = ctx.to_mag(part)
+                if m.length != length or not np.array_equal(m.data, data):
+                    print(f"MISMATCH case {case}: to_mag differs in buffer {a // CHUNK}")
+                    sys.exit(1)
+                wants.append([okey(x) for x in orc.demodulate2400(data, length, cap=1 << 18)[0]])
+                gots.append([key(x) for x in ctx.demodulate2400(m, cap=1 << 18)])
         else:  # shards: the whole capture as one stream over two contexts
             wants = [[okey(x) for x in binding.Oracle().demod_iq(iq, cap=1 << 20)[0]]]
             spans = [sharding.sample_range(n, 2, r) for r in range(2)]
