@@ -303,11 +303,14 @@ __global__ __launch_bounds__(256) void k_mag_digest(uint32_t first_bits, uint32_
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+// hipGetLastError is sticky across unrelated calls (the caller's too): start every launch clean
+inline void hip_clear() { (void)hipGetLastError(); }
 
 }  // namespace
 
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream)
 {
+    hip_clear();
     const int blocks = (kMagDataLen + 255) / 256;
     hipLaunchKernelGGL(k_to_mag, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t *)d_iq, n, d_data);
@@ -316,6 +319,7 @@ int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream)
 
 int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
 {
+    hip_clear();
     const uint32_t blocks = bitmap ? 512u : (uint32_t)((sizeof(Counters) / 4 + 255) / 256);
     hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ctr, bitmap);
     return hip_ok(hipGetLastError());
@@ -323,6 +327,7 @@ int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
 
 int launch_match(const ScanParams &p, void *stream)
 {
+    hip_clear();
     // one block per two wave segments of the fast scan's AP list, 64 for the dap list; the fill
     // counts live on the device
     const uint32_t blocks = kApWaveSegs / 2 + 64;  // 64 blocks share the dap list
@@ -332,6 +337,7 @@ int launch_match(const ScanParams &p, void *stream)
 
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream)
 {
+    hip_clear();
     // contiguous runs of hits per block (the count lives on the device): enough blocks that a
     // dense pass (tens of hits per chunk) still has only a few hits per wave
     uint32_t blocks = p.n_chunks + 8;
@@ -345,6 +351,7 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
 
 int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream)
 {
+    hip_clear();
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_set_addresses, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_addrs, n,
                        bitmap);
@@ -353,6 +360,7 @@ int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, 
 
 int launch_update_carry(const uint32_t *prev, const void *d_src, uint64_t n_samples, uint32_t *next, void *stream)
 {
+    hip_clear();
     hipLaunchKernelGGL(k_update_carry, dim3(1), dim3(kCarrySamples), 0, (hipStream_t)stream, prev,
                        (const uint32_t *)d_src, (long long)n_samples, next);
     return hip_ok(hipGetLastError());
@@ -360,6 +368,7 @@ int launch_update_carry(const uint32_t *prev, const void *d_src, uint64_t n_samp
 
 int launch_mag_digest(uint32_t first_bits, uint32_t count, unsigned long long *d_out, void *stream)
 {
+    hip_clear();
     hipLaunchKernelGGL(k_mag_digest, dim3(1024), dim3(256), 0, (hipStream_t)stream, first_bits, count,
                        d_out);
     return hip_ok(hipGetLastError());

@@ -782,11 +782,14 @@ tile_end:
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+// hipGetLastError is sticky across unrelated calls (the caller's too): start every launch clean
+inline void hip_clear() { (void)hipGetLastError(); }
 
 }  // namespace
 
 int launch_scan(const ScanParams &p, bool from_mag, void *stream)
 {
+    hip_clear();
     const uint32_t tiles = p.n_chunks * kTilesPerChunk;
     if (tiles == 0) return 0;
     // persistent grid = what is resident at once (occupancy API x CUs), found once

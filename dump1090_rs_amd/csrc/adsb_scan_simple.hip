@@ -139,11 +139,14 @@ __global__ __launch_bounds__(256) void k_scan_simple(ScanParams p)
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+// hipGetLastError is sticky across unrelated calls (the caller's too): start every launch clean
+inline void hip_clear() { (void)hipGetLastError(); }
 
 }  // namespace
 
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream)
 {
+    hip_clear();
     const uint32_t blocks = p.n_chunks * kTilesPerChunk;
     if (blocks == 0) return 0;
     if (from_mag)
