@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) stab[i] = p.tables[kTabX56 * 256 + i];
     if (threadIdx.x < kCoarseWords) coarse[threadIdx.x] = p.bitmap[kBitmapWords + threadIdx.x];
     __syncthreads();
-    const uint32_t seg_cap = p.ap_cap / kApWaveSegs;
+    const uint32_t seg_cap = p.seg_cap;
     // work units: pairs of wave segments of the fast scan's list (a few hundred entries per
     // segment), then the dap list of the simple kernel, which all the blocks past the segments
     // share.  Four entries per thread per trip -- two from each segment of the pair -- so that

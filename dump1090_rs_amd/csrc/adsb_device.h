@@ -100,8 +100,9 @@ struct ScanParams {
     uint32_t *bitmap;       // 2^24 bits
     uint64_t *hits;
     uint32_t hits_cap;
-    uint64_t *ap;           // kApWaveSegs segments of ap_cap / kApWaveSegs entries
-    uint32_t ap_cap;        // a multiple of kApWaveSegs
+    uint64_t *ap;           // wave segment g at ap + g * seg_cap (only the segments a context's largest pass can use are allocated)
+    uint32_t ap_cap;        // entries allocated
+    uint32_t seg_cap;       // entries per wave segment
     uint64_t *dap;          // AP entries of the simple kernel
     uint32_t dap_cap;
     const uint32_t *tables; // kTabCount x 256

@@ -82,7 +82,7 @@ struct adsb_ctx {
     hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
     uint64_t *d_dap = nullptr;
     uint32_t *d_tables = nullptr;
-    uint32_t hits_cap = 0, ap_cap = 0, dap_cap = 0;
+    uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0, dap_cap = 0;
 
     Slot slot[kSlots];
     uint64_t submitted = 0, collected = 0;
@@ -219,6 +219,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.hits_cap = c->hits_cap;
     p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
+    p.seg_cap = c->seg_cap;
     p.dap = c->d_dap;
     p.dap_cap = c->dap_cap;
     p.tables = c->d_tables;
@@ -477,8 +478,11 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     // tile's staging buffer so that a single-chunk pass always fits.  Denser input falls
     // back to per-chunk passes.  dap (simple kernel) holds a whole chunk's worst
     // case: every j sliced, five trials each.
-    uint64_t seg = std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + kApWaveSegs - 1) / kApWaveSegs);
-    c->ap_cap = (uint32_t)std::min<uint64_t>(seg * kApWaveSegs, 0xFFFFF000u);
+    // (a pass of n buffers runs min(17 n, 1024) workgroups of four waves: a small context only
+    // gets the segments it can ever use)
+    const uint64_t used_segs = 4 * std::min<uint64_t>(kApSegments, max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
+    c->seg_cap = (uint32_t)std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + used_segs - 1) / used_segs);
+    c->ap_cap = (uint32_t)(used_segs * c->seg_cap);
     c->dap_cap = kWorstPerChunk;
     c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
 
@@ -953,6 +957,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     p.hits_cap = c->hits_cap;
     p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
+    p.seg_cap = c->seg_cap;
     p.dap = c->d_dap;
     p.dap_cap = c->dap_cap;
     p.tables = c->d_tables;

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
     if (tid < 2) s.nhit[tid] = 0;
 
-    const uint32_t seg_cap = p.ap_cap / kApWaveSegs;
+    const uint32_t seg_cap = p.seg_cap;
     const uint32_t my_seg = blockIdx.x * kWaves + (uint32_t)(tid >> 6);
     uint64_t *const seg = p.ap + (uint64_t)my_seg * seg_cap;  // this wave's own AP segment
     uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this wave
