@@ -118,6 +118,7 @@ struct adsb_ctx {
 namespace {
 
 constexpr uint32_t kWorstPerChunk = 5u * kChunkSamples;  // every j sliced, 5 trials each
+constexpr uint32_t kInlineTailChunks = 16;               // passes this small keep their tail on the scan stream
 
 int fail(adsb_ctx *c, hipError_t e, const char *what)
 {
@@ -203,7 +204,7 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
                  uint32_t n_chunks, bool inline_tail = false, bool lead_from_src = false,
-                 bool advance_carry = true, bool force_simple = false)
+                 bool advance_carry = true, bool force_simple = false, hipEvent_t input_done = nullptr)
 {
     ScanParams p{};
     p.src = d_src;
@@ -256,8 +257,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     static const bool one_scan_stream = std::getenv("ADSB_ONE_SCAN_STREAM") != nullptr;
     const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (&sl - c->slot) == 1;
     hipStream_t ss = c->scan_stream[second ? 1 : 0];
-    hipEvent_t ready = c->input_ready[second ? 1 : 0];
-    HIP_TRY(c, hipEventRecord(ready, c->stream));
+    // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
+    hipEvent_t ready = input_done;
+    if (!ready) {
+        ready = c->input_ready[second ? 1 : 0];
+        HIP_TRY(c, hipEventRecord(ready, c->stream));
+    }
     HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));
     if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
@@ -276,7 +281,16 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // for it (it works on the other slot's lists and counters)
     // (a blocking call has nothing to overlap with: its tail stays on the scan stream and
     // saves the cross-stream hand-off)
+    // A small pass is all launch overhead: its tail stays on its scan stream too (the two scan
+    // streams still let consecutive passes overlap), which saves the cross-stream hand-off.
+    if (n_chunks <= kInlineTailChunks) inline_tail = true;
     hipStream_t ts = inline_tail ? ss : c->tail_stream;
+    if (p.clean_bitmap && fast) {
+        // this pass's records kernel clears the bitmap the previous passes matched against: not
+        // before the pass still in flight (whichever stream its tail is on) is through with it
+        Slot &other = c->slot[1 - (&sl - c->slot)];
+        if (other.busy) HIP_TRY(c, hipStreamWaitEvent(ts, other.done, 0));
+    }
     if (!inline_tail) {
         HIP_TRY(c, hipEventRecord(sl.scanned, ss));
         HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
@@ -373,13 +387,15 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     return ADSB_OK;
 }
 
-int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false)
+int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false,
+           hipEvent_t input_done = nullptr)
 {
     const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks == 0 || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
     Slot &sl = c->slot[c->submitted % kSlots];
     if (sl.busy || c->shard_active) return ADSB_ERR_BUSY;
-    int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks, inline_tail);
+    int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks, inline_tail, false, true, false,
+                          input_done);
     if (rc) return rc;
     sl.busy = true;
     c->submitted++;
@@ -789,8 +805,7 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     // transfer overlaps the other slot's kernels
     HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(c, hipEventRecord(r.copied, c->copy_stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, r.copied, 0));
-    return submit(c, r.d_iq, false, n_samples);
+    return submit(c, r.d_iq, false, n_samples, false, r.copied);
 }
 
 int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *out, size_t cap,
