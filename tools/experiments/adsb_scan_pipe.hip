@@ -1,0 +1,824 @@
+// adsb_scan_pipe.hip -- the gfx950 scan kernel, software-pipelined inside the workgroup:
+// IQ in, trial syndromes out, magnitudes never leave the CU.
+//
+// One workgroup (256 threads = 4 wave64) owns a tile of 7712 preamble positions j of
+// one chunk; the 8004 magnitudes those positions can touch (j .. j+290) live in LDS.
+// The reference walks j serially and slices 5 x 112 bits per surviving j with a small
+// state machine (src/demod_2400.rs:121-207).  Here the same decisions are taken densely
+// and bit-parallel:
+//
+//  P1 magnitudes   dwordx4 IQ loads (4 samples / lane, aligned, coalesced) -> exact f32
+//                  magnitude (src/utils.rs:47-55) -> u16 in LDS.
+//  P2 sign planes  every decision the reference can ever take on this tile is the sign of
+//                  a short integer correlation of neighbouring magnitudes:
+//                    slicer phase ph at sample s (demod_2400.rs:72-83)   5 kinds
+//                    m[s] < m[s+1], m[s] > m[s+1] (check_preamble :221-317) 2 kinds
+//                  All seven are taken for every sample.  A lane walks samples 12 apart
+//                  (bit n and bit n+5 of a message are 12 samples apart), four
+//                  neighbouring residues at a time so the first differences are shared,
+//                  and shifts each sign into an accumulator with one v_alignbit -- no
+//                  compare, no cross-lane traffic.  The accumulators are stored as bytes
+//                  of bit planes: plane (kind, s mod 12), bit s div 12.
+//  P3 preamble     check_preamble's five patterns are AND/OR of the LT/GT planes at fixed
+//                  offsets: one lane evaluates 32 positions j per instruction.
+//  P4 gates        the ~4.5 % of positions that match a pattern get the value tests
+//                  (high/SNR/quiet, :129-146) from LDS magnitudes, one lane each.
+//  P5 trials       for the ~1 % that survive, each (j, try_phase) is one lane: the five
+//                  bit classes n mod 5 of the message are five 23-bit fields cut out of the
+//                  sign planes with two dword loads and a funnel shift; DF and the CRC-24
+//                  syndrome come from table lookups on the fields (adsb_tables.h); the
+//                  message bytes are never assembled here.
+//
+// The kernel is VALU-issue bound (tools/valu_rate.hip: ~4.2 cycles per wave64 VOP3 /
+// mad / cvt / compare, ~2.7 for plain VOP2 add/and/shift), so the code below is written
+// to the instruction: 24-bit multiplies with magic constants instead of divisions,
+// shifts and masks instead of bit-field extracts, u16 LDS reads instead of unpacking.
+//
+// Nothing in the kernel has a capacity that input density could exceed: each wave keeps
+// its matches and candidates in its own small LDS regions and drains them in rounds
+// (P3..P5 below), so exactness never depends on how dense the signal is.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include <hip/hip_ext.h>
+
+#include "adsb_dev_common.h"
+#include "adsb_scan_geometry.h"
+
+namespace adsb {
+
+namespace {
+
+using namespace fastgeo;
+
+#ifndef ADSB_SCAN_THREADS
+#define ADSB_SCAN_THREADS 256
+#endif
+constexpr int kThreads = ADSB_SCAN_THREADS;   // 256 (512 was measured: 7 % slower)
+constexpr int kWavesPerSimd = kThreads == 512 ? 8 : 4;
+constexpr int kResPerItem = kThreads == 512 ? 2 : 4;  // residues one P2 lane walks
+constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
+constexpr int kPlaneLT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
+constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..107: GT 0..23
+constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
+constexpr int kItems2 = (12 / kResPerItem) * kPlaneBytes;  // P2 items: (residue group, plane byte)
+constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
+static_assert(kItems2 <= kThreads && kItems3 <= 256, "one item per thread");
+static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
+constexpr int kWaves = kThreads / 64;
+constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
+constexpr int kRoundBits = 4;                 // plane bits per round when they do not fit: 64 x 4 <= 256
+#ifndef ADSB_GATE_SLOTS
+#define ADSB_GATE_SLOTS 1
+#endif
+#ifndef ADSB_TRIAL_SLOTS
+#define ADSB_TRIAL_SLOTS 1
+#endif
+constexpr int kGateSlots = ADSB_GATE_SLOTS;   // pattern matches one lane gates per pass
+constexpr int kTrialSlots = ADSB_TRIAL_SLOTS; // trials one lane evaluates per pass
+constexpr int kCandPerWave = 64 + 64 * kGateSlots;  // a wave's candidates waiting for the trial stage
+static_assert(64 * kRoundBits <= kPatPerWave, "wave-private regions");
+constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
+
+// LDS accesses wider than their address is aligned are legal on gfx950 but replayed at 64
+// cycles (SQ_LDS_UNALIGNED_STALL); with unaligned-access-mode on (the default) the
+// compiler merges neighbouring u16 / u32 LDS reads into exactly those.  The scan kernel is
+// compiled with the mode off: merges only happen where alignment is known.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ADSB_NO_UNALIGNED __attribute__((target("no-unaligned-access-mode")))
+#else
+#define ADSB_NO_UNALIGNED
+#endif
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for the next tile's IQ prefetch at every phase boundary; here only LDS
+// traffic (lgkmcnt) is drained before s_barrier, global loads stay in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Order this wave's own LDS traffic: writes before, reads after.  LDS operations of one
+// wave complete in order, so draining lgkmcnt is all it takes; "memory" keeps the
+// compiler from moving LDS accesses across.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh)[31:0], sh in 0..31
+}
+
+// shift the sign bit of v into acc from the right
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, int v)
+{
+    return alignbit(acc, (uint32_t)v, 31);
+}
+
+// inclusive prefix sum across the 64 lanes of a wave, in registers (DPP row shifts and
+// row broadcasts; lanes with no source add 0)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)v;
+}
+
+// rank of this lane among the set bits of a wave mask
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped to 0..32
+{
+    return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
+}
+
+// Which magnitudes enter high / base_signal / base_noise for each of check_preamble's five
+// branches (src/demod_2400.rs:227-317), one bit per term:
+//   high  = (p1 + p12 + A*(p3+p9) + B*p11 + C*(p4+p10) + D*p2) / 4
+//   sig   = E*p1 + F*(p3+p9) + G*p12 + H*(p4+p10)
+//   noise = p6 + p7 + I*p5 + J*p8                              bits: A=0 B=1 ... J=9
+constexpr uint32_t kBranchTerms[5] = {0x133u, 0x371u, 0x055u, 0x3D4u, 0x2CCu};
+
+struct alignas(16) FastLds {
+    uint16_t mag2[2][kAllocSlots];     // P1..P4, double-buffered by tile parity
+    uint32_t plane2[2][kPlanes * kPlaneDw];
+    uint32_t tab[3 * 256];             // F'0 F'1 F'2 (adsb_tables.h)
+    uint32_t r16[16];                  // x^24..x^27 reduction
+    uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
+    uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
+    uint32_t cand[kWaves * kCandPerWave];  // per wave: slot | slot/12 << 13 | slot%12 << 23
+    uint64_t hit2[2][kHitCap];
+    uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
+};
+
+// P4, one pattern match: high / base_signal / base_noise of the branch that matched first
+// (demod_2400.rs:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
+// Branch-free; returns 1 when the position goes on to be sliced.
+__device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
+{
+    // one u16 LDS read per magnitude (no unpacking on the VALU).  The kernel is compiled
+    // without unaligned-access-mode (ADSB_NO_UNALIGNED below), or these would be merged into
+    // 8/16-byte reads at a 2-byte aligned address, which the LDS replays at 64 cycles each.
+    const uint16_t *pm = mag + (ent & 0x1FFFu);
+    const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
+              p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
+    const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
+    // the branch's terms (kBranchTerms, 10 bits each, packed into one 64-bit constant) as
+    // 0 / -1 masks (signed 1-bit field extracts)
+    constexpr unsigned long long kTermsPacked =
+        (unsigned long long)kBranchTerms[0] | ((unsigned long long)kBranchTerms[1] << 10) |
+        ((unsigned long long)kBranchTerms[2] << 20) | ((unsigned long long)kBranchTerms[3] << 30) |
+        ((unsigned long long)kBranchTerms[4] << 40);
+    const int terms = (int)(uint32_t)(kTermsPacked >> (10u * ((ent >> 13) & 7u)));
+#define TERM(bit) __builtin_amdgcn_sbfe(terms, (bit), 1)
+    const int s39 = p3 + p9, s410 = p4 + p10;
+    const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
+    const int sig = (p1 & TERM(4)) + (s39 & TERM(5)) + (p12 & TERM(6)) + (s410 & TERM(7));
+    const int noise = p6 + p7 + (p5 & TERM(8)) + (p8 & TERM(9));
+#undef TERM
+    const int loud = max(max(max(p5, p6), max(p7, p8)), max(max(q14, q15), max(max(q16, q17), q18)));
+    return (uint32_t)(2 * sig >= 3 * noise) & (uint32_t)(loud < high);  // :129, :135-146
+}
+
+// candidate entry: slot | slot/12 << 13 | slot%12 << 23
+__device__ __forceinline__ uint32_t cand_entry(uint32_t slot)
+{
+    const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
+    return slot | (qs << 13) | ((slot - 12u * qs) << 23);
+}
+
+// P5, one trial.  Message bit n = 5k + r of trial phase tp sits at 5x-oversampled position
+// 5*(slot+19) + tp + 12n, i.e. sample slot + 19 + (tp+12r)/5 + 12k with slicer phase
+// (tp+12r) % 5: field r is 23 consecutive bits of one sign plane; which plane and where
+// comes from s.field.  Branch-free so that two trials per lane interleave.
+struct Trial {
+    uint32_t f[5];   // the five bit classes n mod 5 (bit k = message bit 5k + r)
+    uint32_t h;      // x^51 * H reduced: short messages' CRC residual as is (adsb_tables.h)
+    uint32_t code;   // try_phase - 4, + 5 for 112-bit messages
+    uint32_t cslot;
+    uint32_t flags;  // 1: address/parity trial, 2: self-validating hit, 4: hit that adds its address
+};
+
+__device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *plane, const uint32_t *wcand, uint32_t t5,
+                                           Trial &o)
+{
+    const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
+    const uint32_t tpi = t5 - 5u * c;
+    const uint32_t ce = wcand[c];
+    const uint32_t qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
+    o.cslot = ce & 0x1FFFu;
+    const uint32_t *ft = s.field + tpi * 60u + rs;
+    const char *plane_bytes = (const char *)plane;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t fe = ft[r * 12];
+        const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
+        // 4-byte aligned only: becomes one ds_read2_b32 (not an 8-byte read off its alignment,
+        // which is replayed at 64 cycles -- ADSB_NO_UNALIGNED)
+        const uint32_t *pl = (const uint32_t *)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
+        const uint32_t lo = pl[0], hi = pl[1];
+        o.f[r] = alignbit(hi, lo, qq);  // the shift is qq mod 32
+    }
+    const uint32_t *f = o.f;
+    // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
+    const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) | ((f[3] & 1u) << 1) | (f[4] & 1u);
+    const uint32_t lng = f[0] & 1u;  // DF >= 16: 112 bits
+    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks at all 14
+    // bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
+    const uint32_t nonzero = (uint32_t)((((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0);
+    const uint32_t mk0 = lng ? 0x7FFFFFu : 0xFFFu, mk1 = lng ? 0x7FFFFFu : 0x7FFu, mk2 = lng ? 0x3FFFFFu : 0x7FFu;
+    const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
+    // sum_r x^(4-r) * F'(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
+    const char *tF = (const char *)s.tab;
+    uint32_t g[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
+        g[r] = *(const uint32_t *)(tF + (x4 & 0x3FCu)) ^ *(const uint32_t *)(tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
+               *(const uint32_t *)(tF + 2048 + ((x4 >> 16) & 0x3FCu));
+    }
+    const uint32_t hp = ((g[0] << 4) ^ (g[1] << 3) ^ (g[2] << 2)) ^ ((g[3] << 1) ^ g[4]);
+    const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
+    o.h = h;
+    o.code = tpi + 5u * lng;
+    // DF classes as bit sets indexed by DF (mod.rs:56-135)
+    const uint32_t ap = (0xFF310031u >> df) & 1u;           // 0,4,5,16,20,21,24..31: address/parity
+    const uint32_t d1718 = (0x00060000u >> df) & 1u;        // clean iff residual == 0
+    const uint32_t d11 = (0x00000800u >> df) & 1u;          // clean iff residual & 0xFFFF80 == 0
+    const uint32_t z = (uint32_t)(h == 0), z11 = (uint32_t)((h & 0xFFFF80u) == 0);
+    const uint32_t hit = (d1718 & z) | (d11 & z11);
+    // DF17 and DF11 with IID 0 add their address; DF18 adds addr | 1 << 25, never matched
+    const uint32_t learn = z & (((0x00020800u >> df) & 1u));
+    o.flags = nonzero * (ap | (hit << 1) | (learn << 2));
+}
+
+__device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 8..31
+{
+    uint32_t addr = 0;
+#pragma unroll
+    for (int n = 8; n < 32; n++) addr |= ((t.f[n % 5] >> (n / 5)) & 1u) << (31 - n);
+    return addr;
+}
+
+// a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
+__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane,
+                                          uint32_t par)  // par: parity of the tile (its hit staging and counter)
+{
+    const unsigned long long mh = __ballot(is_hit);
+    if (!mh) return;
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&s.nhit[par], (uint32_t)__popcll(mh));
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
+    if (is_hit) {
+        if (at < (uint32_t)kHitCap) {
+            s.hit2[par][at] = entry;
+        } else {  // more hits in one tile than the staging holds: one by one
+            const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
+            if (gi < p.hits_cap)
+                p.hits[gi] = entry;
+            else
+                atomicOr(&p.ctr->overflow, 1u);
+        }
+    }
+}
+
+// IQ of one tile, as each thread holds it between the load and the magnitude pass:
+// 8 aligned dwordx4 = 32 samples per thread, 8080 per workgroup.
+constexpr int kLoadsPerThread = (kAllocSlots / 4 + kThreads - 1) / kThreads;  // 8
+
+struct TileRef {
+    uint32_t chunk;
+    int tile, len, jbase;
+};
+
+template <bool FROM_MAG>
+__device__ __forceinline__ TileRef tile_ref(const ScanParams &p, uint32_t t)
+{
+    TileRef r;
+    r.chunk = t / kTilesPerChunk;
+    r.tile = (int)(t % kTilesPerChunk);
+    // a caller-supplied MagnitudeBuffer is one buffer: n_samples is its `length`
+    r.len = FROM_MAG ? (int)p.n_samples : chunk_len(p.n_samples, r.chunk);
+    r.jbase = r.tile * kTile;
+    return r;
+}
+
+// The tile's IQ through a buffer resource that spans exactly this chunk's samples: the
+// hardware range check returns zero for every dword outside [0, len) -- the 326-sample
+// lead-in before the chunk (negative offsets wrap to huge unsigned ones), the zero tail
+// and the ragged end of a short last chunk -- so the eight dwordx4 loads are issued
+// back to back with no branch and no wait between them.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// A front wave owns the slots its sign-plane items read: [2016 fw, 2016 fw + 2032) -- its 21
+// plane bytes of 96 slots each plus 16 slots of look-ahead -- as 508 groups of four samples,
+// eight per lane.  Nothing it loads or writes is needed by another front wave, so P1 -> P2
+// needs no workgroup barrier.
+constexpr int kWaveSlots = 2016, kWaveGroups = 508;
+
+template <bool FROM_MAG>
+__device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef &r, int fw, int lane,
+                                             uint4 (&pre)[kLoadsPerThread])
+{
+    const int slot0 = kWaveSlots * fw + 4 * lane;  // this lane's first slot; the others are 256 slots apart
+    if (FROM_MAG) {
+        // caller-supplied magnitudes (adsb_demodulate2400): MagnitudeBuffer.data as handed in,
+        // lead-in included; 4 u16 per load, zero outside [0, kMagDataLen) by the range check
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.src, 0, kMagDataLen * 2, 0x00020000);
+        const int d0 = r.jbase - kPad + slot0;  // data index of the lane's first slot
+#pragma unroll
+        for (int i = 0; i < kLoadsPerThread; i++) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (d0 + 256 * i) * 2, 0, 0);
+            pre[i] = make_uint4(v.x, v.y, 0u, 0u);
+        }
+        return;
+    }
+    const uint32_t *iq = (const uint32_t *)p.src + r.chunk * (uint64_t)kChunkSamples;
+    // carry-over mode: the resource starts kCarrySamples before the buffer when those samples
+    // exist in src, so the lead-in is simply in range (the reference's mode: it is not)
+    const bool lead = p.carry != nullptr && (r.chunk > 0 || p.lead_from_src);
+    const int shift = lead ? kCarrySamples : 0;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(iq - shift), 0, (r.len + shift) * 4, 0x00020000);
+    const int k0 = r.jbase - kPad - kLead + shift + slot0;  // IQ sample index of the lane's first slot (multiple of 4)
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; i++) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k0 + 256 * i) * 4, 0, 0);
+        pre[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    if (p.carry != nullptr && !lead && r.tile == 0 && fw == 0) {
+        // first buffer of a call: its lead-in is the end of the previous call (out of range of
+        // one resource = zero from it, so the loads just OR together); slots 0..327
+        const __amdgpu_buffer_rsrc_t crsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.carry, 0, kCarrySamples * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(crsrc, (k0 + kCarrySamples + 256 * i) * 4, 0, 0);
+            pre[i].x |= v.x;
+            pre[i].y |= v.y;
+            pre[i].z |= v.z;
+            pre[i].w |= v.w;
+        }
+    }
+}
+
+// profiling aids, compiled in with -DADSB_KERNEL_ACCT only (they cost registers):
+// wave 0 of a few workgroups stamps the shader clock at phase boundaries
+#ifdef ADSB_KERNEL_ACCT
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        if (p.timeline && p.debug_stop != 100 && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
+            p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
+    } while (0)
+
+// (ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2): every wave totals the clocks it spends in each
+// phase and waiting at each workgroup barrier
+#define ACCT(k)                                                   \
+    do {                                                          \
+        if (acct) {                                               \
+            const unsigned long long now_ = clock64();            \
+            acc_t[k] += now_ - acc_last;                          \
+            acc_last = now_;                                      \
+        }                                                         \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#define ACCT(k) do {} while (0)
+#endif
+
+// One wave moves a finished tile's staged hits to the global hit list and zeroes its counter
+// (the other back waves are already staging the next tile's in the other copy).
+__device__ __forceinline__ void flush_hits(const ScanParams &p, FastLds &s, uint32_t par, int lane)
+{
+    const uint32_t nhit = min(s.nhit[par], (uint32_t)kHitCap);
+    if (nhit == 0) return;  // the usual case
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&p.ctr->n_hits, nhit);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + nhit > p.hits_cap) {
+        if (lane == 0) atomicOr(&p.ctr->overflow, 1u);
+    } else if ((uint32_t)lane < nhit) {
+        p.hits[base + lane] = s.hit2[par][lane];
+    }
+    wave_lds_fence();
+    if (lane == 0) s.nhit[par] = 0;
+}
+
+// Persistent and pipelined inside the workgroup.  The grid is what is resident at once and
+// each workgroup walks tiles t = block, block + grid, ...  A workgroup is eight waves in two
+// roles:
+//   front waves 0-3  P1 + P2 of tile k: magnitudes and sign planes into LDS buffer k & 1.
+//                    VALU-dense.  Each front wave owns the slots its own P2 items read
+//                    (load_tile_iq), so there is no barrier between P1 and P2; the IQ of tile
+//                    k + 1 is loaded into registers as soon as tile k's magnitudes are in LDS.
+//   back waves 4-7   P3..P5 of tile k - 1 from buffer (k - 1) & 1: patterns, gates, trials.
+//                    Latency-bound (chains of LDS round trips), wave-private.
+// One workgroup barrier per tile hands buffer k & 1 from the front to the back.  The hardware
+// places wave i on SIMD i mod 4, so every SIMD always holds front and back waves at once: the
+// dense phases of one tile fill the issue slots the latency-bound phases of the previous one
+// leave idle -- by construction, where the flat kernel relies on the phases of four
+// independent workgroups happening to differ.
+template <bool FROM_MAG>
+__global__ __launch_bounds__(2 * kThreads, 4) ADSB_NO_UNALIGNED void k_scan_pipe(ScanParams p)
+{
+    __shared__ FastLds s;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const bool front = tid < kThreads;
+    const int fw = tid >> 6;                 // front wave 0..3 (front role)
+    const int btid = tid - kThreads, bw = btid >> 6;  // back role: thread / wave within the role
+    const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
+
+    // ---------------------------------------------------------------- P0 once per workgroup
+    for (int i = tid; i < 3 * 256; i += 2 * kThreads) s.tab[i] = p.tables[kTabF * 256 + i];
+    for (int i = tid; i < 316; i += 2 * kThreads) {
+        const uint32_t v = p.tables[kTabR16Off + i];
+        if (i < 16)
+            s.r16[i] = v;
+        else
+            s.field[i - 16] = v;
+    }
+    if (tid < 2 * kPlanes) s.plane2[tid / kPlanes][(tid % kPlanes) * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
+    if (tid < 2) s.nhit[tid] = 0;
+
+    const uint32_t seg_cap = p.seg_cap;
+    const uint32_t my_seg = blockIdx.x * kWaves + (uint32_t)(bw & 3);
+    uint64_t *const seg = p.ap + (uint64_t)my_seg * seg_cap;  // this back wave's own AP segment
+    uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this wave
+
+    uint4 pre[kLoadsPerThread];
+    if (front && blockIdx.x < n_tiles) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, blockIdx.x), fw, lane, pre);
+
+    // tiles of this workgroup: t_k = blockIdx.x + k * gridDim.x, k = 0 .. m-1; step k has the
+    // front on tile k and the back on tile k - 1
+    const uint32_t m = blockIdx.x < n_tiles ? (n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    lds_barrier();  // tables in place
+    for (uint32_t k = 0; k <= m; k++) {
+        if (front) {
+            if (k < m) {
+                const uint32_t t = blockIdx.x + k * gridDim.x;
+                const TileRef cur = tile_ref<FROM_MAG>(p, t);
+                uint16_t *const mag = s.mag2[k & 1];
+                uint32_t *const plane = s.plane2[k & 1];
+                const int jn = min(kTile, cur.len - cur.jbase);
+                // -------------------------------------------------------- P1 magnitudes
+#pragma unroll
+                for (int i = 0; i < kLoadsPerThread; i++) {
+                    const int gi = lane + 64 * i;
+                    if (gi < kWaveGroups)
+                        *(uint2 *)(mag + kWaveSlots * fw + 4 * gi) =
+                            FROM_MAG ? make_uint2(pre[i].x, pre[i].y) : mag4_of(pre[i]);
+                }
+                if (k + 1 < m) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t + gridDim.x), fw, lane, pre);
+                wave_lds_fence();  // this wave's own magnitudes, read back below by its other lanes
+                // -------------------------------------------------------- P2 sign planes
+                // item = (g, kw): residues 4g..4g+3, plane bits k = 8kw..8kw+7, i.e. samples
+                // 12k + 4g + {0..3} (+3 of look-ahead).  Bit k of plane (kind, r) is the sign taken
+                // at sample 12k + r.  Walking k downwards leaves bit (k & 7) of the byte = k.
+                if (jn > 0 && p.debug_stop != 1) {
+            if (lane < 63) {  // 63 items per front wave: 21 plane bytes x 3 residue groups
+                constexpr int R = kResPerItem, G = 12 / R;
+                const int g = lane % G, kw = 21 * fw + lane / G;
+                const uint16_t *base = mag + 96 * kw + R * g;  // 4-byte aligned (R even)
+                uint32_t acc[7][R];
+#pragma unroll
+                for (int q = 0; q < 7; q++)
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[q][r] = 0;
+#pragma unroll
+                for (int kk = 8; kk >= 0; --kk) {
+                    // m[0 .. R+2]: the R samples of this lane and three of look-ahead.  Explicit
+                    // 8-byte reads (the address is 8-byte aligned, no more): left to itself the
+                    // compiler merges dword reads into one 16-byte read, and an LDS access off its
+                    // natural alignment is replayed at 64 cycles (SQ_LDS_UNALIGNED_STALL).
+                    int m[R + 4];
+                    if constexpr (R == 4) {
+                        const uint2 lo = *(const uint2 *)(base + 12 * kk);
+                        const uint2 hi = *(const uint2 *)(base + 12 * kk + 4);
+                        m[0] = (int)(lo.x & 0xFFFFu);
+                        m[1] = (int)(lo.x >> 16);
+                        m[2] = (int)(lo.y & 0xFFFFu);
+                        m[3] = (int)(lo.y >> 16);
+                        m[4] = (int)(hi.x & 0xFFFFu);
+                        m[5] = (int)(hi.x >> 16);
+                        m[6] = (int)(hi.y & 0xFFFFu);
+                        m[7] = (int)(hi.y >> 16);
+                    } else {  // R == 2: 4-byte aligned, three separate dword reads
+                        typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+                        lds_u32_ptr src = (lds_u32_ptr)(base + 12 * kk);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            const uint32_t w = src[d];
+                            m[2 * d] = (int)(w & 0xFFFFu);
+                            m[2 * d + 1] = (int)(w >> 16);
+                        }
+                    }
+                    int e[R + 2];  // first differences m[s+1] - m[s]
+#pragma unroll
+                    for (int i = 0; i < R + 2; i++) e[i] = m[i + 1] - m[i];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int ea = e[r], eb = e[r + 1], ec = e[r + 2];
+                        if (kk < 8) {
+                            // slicer value D(ph) at this sample (demod_2400.rs:72-83), negated so that
+                            // "D > 0" is the sign bit: with a = m0-m1 = -e0, b = m1-m2 = -e1, c = m2-m3:
+                            //   D0 = 5a+2b  D1 = 4a+3b  D2 = 3a+4b  D3 = 2a+5b  D4 = a+6b+c
+                            const int n0 = __mul24(ea, 5) + (eb + eb);
+                            const int u = eb - ea;
+                            const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
+                            const int n4 = __mul24(eb, 6) + (ea + ec);
+                            acc[0][r] = push_sign(acc[0][r], n0);
+                            acc[1][r] = push_sign(acc[1][r], n1);
+                            acc[2][r] = push_sign(acc[2][r], n2);
+                            acc[3][r] = push_sign(acc[3][r], n3);
+                            acc[4][r] = push_sign(acc[4][r], n4);
+                        }
+                        // kk == 8 is one plane bit beyond the byte, for LT/GT only: it completes the
+                        // "advanced by one bit" copies that P3 addresses as residues 12..23
+                        acc[5][r] = push_sign(acc[5][r], -ea);  // LT: m[s] < m[s+1]
+                        acc[6][r] = push_sign(acc[6][r], ea);   // GT: m[s] > m[s+1]
+                    }
+                }
+                uint8_t *pb = (uint8_t *)plane;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int res = R * g + r;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) pb[(q * 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[q][r];
+                    // 9 bits: k = 8kw .. 8kw+8.  Residue res holds bits 0..7, residue res+12 (the
+                    // same plane advanced one bit) holds bits 1..8.
+                    pb[(kPlaneLT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[5][r];
+                    pb[(kPlaneGT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[6][r];
+                    pb[(kPlaneLT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[5][r] >> 1);
+                    pb[(kPlaneGT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[6][r] >> 1);
+                }
+            }
+                }
+            }
+        } else if (k >= 1) {
+            const uint32_t t = blockIdx.x + (k - 1) * gridDim.x;
+            const TileRef cur = tile_ref<FROM_MAG>(p, t);
+            const uint32_t chunk = cur.chunk;
+            const int jbase = cur.jbase;
+            const int jn = min(kTile, cur.len - cur.jbase);  // <= 0 for tiles past the end of a short chunk
+            const uint32_t par = (k - 1) & 1u;
+            const uint16_t *const mag = s.mag2[par];
+            const uint32_t *const plane = s.plane2[par];
+            // the tile before this one left its staged hits in the other copy: flush them
+            if (bw == 0) flush_hits(p, s, par ^ 1u, lane);
+            if (jn > 0 && p.debug_stop != 1 && p.debug_stop != 2) {
+    {
+            const int wave = bw;
+            uint32_t *const wpat = s.pat + wave * kPatPerWave;
+            uint32_t *const wcand = s.cand + wave * kCandPerWave;
+
+            // ---------------------------------------------------------------- P3 preamble patterns
+            // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
+            // (with 512 threads an item is half a dword, so that all eight waves own positions)
+            constexpr int kHalves = 1;
+            uint32_t b[5] = {0u, 0u, 0u, 0u, 0u};
+            const int ptid = btid, phalf = 0;
+            const int pres = ptid % 12, pw = ptid / 12;
+            if (ptid < kItems3) {
+                const int res = pres, w = pw;
+                const uint32_t *LT = plane + (kPlaneLT + res) * kPlaneDw + w;
+                const uint32_t *GT = plane + (kPlaneGT + res) * kPlaneDw + w;
+#define LTO(o) LT[(o) * kPlaneDw]  // p[o] < p[o+1]
+#define GTO(o) GT[(o) * kPlaneDw]  // p[o] > p[o+1]
+                // positions that are real j of this tile: kPad <= slot < kPad + jn
+                const int kmin = (kPad - res + 11) / 12, kmax = (kPad + jn - res + 11) / 12;
+                uint32_t ok = lowmask(kmax - 32 * w) & ~lowmask(kmin - 32 * w);
+                if (kHalves == 2) ok &= phalf ? 0xFFFF0000u : 0x0000FFFFu;
+                ok &= LTO(0) & GTO(12);                               // demod_2400.rs:221
+                const uint32_t A = GTO(1) & LTO(2);                   // p1>p2 p2<p3
+                const uint32_t C = LTO(8) & GTO(9);                   // p8<p9 p9>p10
+                const uint32_t E = GTO(4) & LTO(9) & GTO(10) & LTO(11);
+                const uint32_t b1 = ok & A & GTO(3) & C & LTO(10);                    // :227
+                const uint32_t b2 = ok & A & GTO(3) & C & LTO(11) & ~b1;              // :242
+                const uint32_t b3 = ok & A & GTO(4) & LTO(8) & GTO(10) & LTO(11) & ~(b1 | b2);  // :262
+                const uint32_t b4 = ok & GTO(1) & LTO(3) & E & ~(b1 | b2 | b3);       // :280
+                const uint32_t b5 = ok & GTO(2) & LTO(3) & E & ~(b1 | b2 | b3 | b4);  // :300
+#undef LTO
+#undef GTO
+                b[0] = b1;
+                b[1] = b2;
+                b[2] = b3;
+                b[3] = b4;
+                b[4] = b5;
+            }
+            const uint32_t slot0 = (uint32_t)(12 * 32 * pw + pres);
+            const uint32_t any_all = b[0] | b[1] | b[2] | b[3] | b[4];
+            // which branch matched, as three planes of a 3-bit code (0..4), so that compaction is one
+            // loop over the union instead of one per branch
+            const uint32_t code0 = b[1] | b[3], code1 = b[2] | b[3], code2 = b[4];
+            const uint32_t cnt_all = (uint32_t)__popc(any_all);
+            const uint32_t incl_all = wave_inclusive_scan(cnt_all);
+            const uint32_t total_all = (uint32_t)__builtin_amdgcn_readlane((int)incl_all, 63);
+            // all matches in one round when they fit the wave's region (the normal case: ~90 of
+            // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
+            const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
+            uint32_t ncand_w = 0;  // candidates waiting in wcand (wave-uniform)
+
+            // One loop, one copy of each stage: take the next round of matches when the previous one
+            // is used up, run one 64-lane pass of the gates, and run the trials whenever the
+            // candidate region could not take another pass's worth (or nothing else is left).
+            int round = 0;
+            uint32_t npat_w = 0, base = 0;
+            bool in_round = false;
+            for (;;) {
+                if (round < nrounds) {
+                    if (!in_round) {
+                        // ---- compaction of this round's matches into wpat: exclusive scan of the lane
+                        // counts (DPP, no LDS traffic), then every lane writes its own
+                        const uint32_t rmask = nrounds == 1 ? 0xFFFFFFFFu
+                                                            : (((1u << kRoundBits) - 1u) << (round * kRoundBits));
+                        uint32_t cnt = cnt_all, incl = incl_all;
+                        npat_w = total_all;
+                        if (nrounds != 1) {
+                            cnt = (uint32_t)__popc(any_all & rmask);
+                            incl = wave_inclusive_scan(cnt);
+                            npat_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        }
+                        if (npat_w == 0) {
+                            round++;
+                            continue;
+                        }
+                        uint32_t at = incl - cnt;
+                        uint32_t m = any_all & rmask;
+                        while (m) {
+                            const uint32_t bit = (uint32_t)__ffs(m) - 1u;
+                            m &= m - 1;
+                            const uint32_t k = ((code0 >> bit) & 1u) | (((code1 >> bit) & 1u) << 1) | (((code2 >> bit) & 1u) << 2);
+                            wpat[at++] = (slot0 + 12u * bit) | (k << 13);
+                        }
+                        wave_lds_fence();
+                        in_round = true;
+                        base = 0;
+                    }
+
+                    // ------------------------------------------------------------ P4 value gates
+                    // one lane per pattern match, kGateSlots matches per lane and pass (gate_eval)
+                    {
+                        uint32_t ent[kGateSlots];
+                        unsigned long long mask[kGateSlots];
+                        bool pass[kGateSlots];
+                        unsigned long long any = 0;
+#pragma unroll
+                        for (int q = 0; q < kGateSlots; q++) {
+                            const uint32_t idx = base + (uint32_t)(lane + 64 * q);
+                            ent[q] = wpat[min(idx, npat_w - 1u)];
+                            pass[q] = (gate_eval(mag, ent[q]) & (uint32_t)(idx < npat_w)) != 0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < kGateSlots; q++) any |= (mask[q] = __ballot(pass[q]));
+                        if (any) {
+#pragma unroll
+                            for (int q = 0; q < kGateSlots; q++) {
+                                if (pass[q]) wcand[ncand_w + mask_rank(mask[q])] = cand_entry(ent[q] & 0x1FFFu);
+                                ncand_w += (uint32_t)__popcll(mask[q]);
+                            }
+                        }
+                    }
+                    base += 64 * kGateSlots;
+                    if (base >= npat_w) {
+                        in_round = false;
+                        round++;
+                    }
+                    // room for another pass of the gates and more of them to come: not yet
+                    if (round < nrounds && ncand_w + 64 * kGateSlots <= (uint32_t)kCandPerWave) continue;
+                }
+                if (ncand_w == 0) {
+                    if (round >= nrounds) break;
+                    continue;
+                }
+                wave_lds_fence();
+                if (p.debug_stop == 4) {  // profiling: gates only
+                    ncand_w = 0;
+                    if (round >= nrounds) break;
+                    continue;
+                }
+
+                // ---------------------------------------------------------------- P5 trials
+                // lane = (candidate, try_phase), kTrialSlots trials per lane and pass (trial_eval).
+                {
+                    const uint32_t ntrial = ncand_w * 5u;
+                    cand_count += ncand_w;
+                    ncand_w = 0;
+                    for (uint32_t tb = 0; tb < ntrial; tb += 64 * kTrialSlots) {
+                        Trial tr[kTrialSlots];
+                        uint64_t entry[kTrialSlots];
+                        bool is_ap[kTrialSlots], is_hit[kTrialSlots], learn[kTrialSlots];
+                        unsigned long long ma[kTrialSlots];
+                        unsigned long long any_ap = 0, any_hit = 0, any_learn = 0;
+#pragma unroll
+                        for (int q = 0; q < kTrialSlots; q++) {
+                            const uint32_t t5 = tb + (uint32_t)(lane + 64 * q);
+                            trial_eval(s, plane, wcand, min(t5, ntrial - 1u), tr[q]);
+                            const uint32_t fl = t5 < ntrial ? tr[q].flags : 0u;
+                            is_ap[q] = (fl & 1u) != 0;
+                            is_hit[q] = (fl & 2u) != 0;
+                            learn[q] = (fl & 4u) != 0;
+                            // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
+                            const uint32_t j = (uint32_t)(jbase - kPad) + tr[q].cslot;
+                            entry[q] = ((uint64_t)((j >> 4) | (chunk << 13)) << 32) | (tr[q].h | (tr[q].code << 24) | (j << 28));
+                        }
+#pragma unroll
+                        for (int q = 0; q < kTrialSlots; q++) {
+                            any_ap |= (ma[q] = __ballot(is_ap[q]));
+                            any_hit |= __ballot(is_hit[q]);
+                            any_learn |= __ballot(learn[q]);
+                        }
+                        // AP entries: straight into this wave's own segment of the list (no atomic, no
+                        // shared counter: the fill count is a wave-uniform register)
+                        if (any_ap) {
+#pragma unroll
+                            for (int q = 0; q < kTrialSlots; q++) {
+                                const uint32_t mine = ap_count + mask_rank(ma[q]);
+                                if (is_ap[q] && mine < seg_cap) seg[mine] = entry[q];
+                                ap_count += (uint32_t)__popcll(ma[q]);
+                            }
+                        }
+                        if (any_hit) {  // rare
+#pragma unroll
+                            for (int q = 0; q < kTrialSlots; q++) stage_hit(p, s, is_hit[q], entry[q], lane, par);
+                        }
+                        if (any_learn) {  // rare: the host replay will add this address to the filter
+#pragma unroll
+                            for (int q = 0; q < kTrialSlots; q++)
+                                if (learn[q]) bitmap_set(p.bitmap, trial_addr(tr[q]));
+                        }
+                    }
+                    wave_lds_fence();  // wcand is reused by the next passes of the gates
+                }
+                if (round >= nrounds) break;
+            }
+            }
+            }
+        }
+        lds_barrier();  // buffer k & 1 is complete, buffer (k - 1) & 1 is free again
+    }
+    if (!front) {
+        if (bw == 0 && m) flush_hits(p, s, (m - 1) & 1u, lane);
+        // candidate counts were kept per wave (diagnostic): lane 0 of each wave adds its own
+        if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
+        if (lane == 0) {
+            if (ap_count > seg_cap) atomicOr(&p.ctr->overflow, 2u);
+            p.ctr->seg_ap[my_seg] = min(ap_count, seg_cap);
+        }
+    }
+}
+
+inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+// hipGetLastError is sticky across unrelated calls (the caller's too): start every launch clean
+inline void hip_clear() { (void)hipGetLastError(); }
+
+}  // namespace
+
+int launch_scan_pipe(const ScanParams &p, bool from_mag, void *stream)
+{
+    hip_clear();
+    const uint32_t tiles = p.n_chunks * kTilesPerChunk;
+    if (tiles == 0) return 0;
+    // persistent grid = what is resident at once (occupancy API x CUs), found once
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_pipe<false>, 2 * kThreads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            per_cu <= 0 || cus <= 0) {
+            per_cu = 2;
+            cus = 256;
+        }
+        resident = per_cu * cus;
+        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) resident = std::atoi(e) * cus;
+        if (resident > kApSegments) resident = kApSegments;  // four private AP segments (one per back wave) each
+        if (resident < 1) resident = 1;
+        if (std::getenv("ADSB_TIMELINE"))
+            std::fprintf(stderr, "k_scan_pipe: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
+    }
+    const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
+    if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
+        hipLaunchKernelGGL(k_scan_pipe<true>, dim3(blocks), dim3(2 * kThreads), 0, (hipStream_t)stream, p);
+    else if (p.ev_start && p.ev_stop)
+        hipExtLaunchKernelGGL(k_scan_pipe<false>, dim3(blocks), dim3(2 * kThreads), 0, (hipStream_t)stream,
+                              (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
+    else
+        hipLaunchKernelGGL(k_scan_pipe<false>, dim3(blocks), dim3(2 * kThreads), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+}  // namespace adsb
