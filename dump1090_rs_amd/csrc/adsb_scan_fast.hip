@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                     const int n0 = __mul24(ea, 5) + (eb + eb);
                     const int u = eb - ea;
                     const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
-                    const int n4 = __mul24(eb, 6) + (ea + ec);
+                    const int n4 = n3 + u + ec;  // a + 6b + c = (2a + 5b) + (b - a) + c: one add3
                     acc[0][r] = push_sign(acc[0][r], n0);
                     acc[1][r] = push_sign(acc[1][r], n1);
                     acc[2][r] = push_sign(acc[2][r], n2);
