@@ -59,9 +59,9 @@ constexpr int kThreads = ADSB_SCAN_THREADS;   // 256 (512 was measured: 7 % slow
 constexpr int kWavesPerSimd = kThreads == 512 ? 8 : 4;
 constexpr int kResPerItem = kThreads == 512 ? 2 : 4;  // residues one P2 lane walks
 constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
-constexpr int kPlaneLT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
-constexpr int kPlaneGT = 84;                  // 60..83: LT residues 0..23, 84..107: GT 0..23
-constexpr int kPlanes = 108;                  //   (residue r+12 = residue r advanced one bit)
+constexpr int kPlaneGT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
+constexpr int kPlanes = 84;                   // 60..83: GT ("m[s] > m[s+1]") residues 0..23
+                                              //   (residue r+12 = residue r advanced one bit)
 constexpr int kItems2 = (12 / kResPerItem) * kPlaneBytes;  // P2 items: (residue group, plane byte)
 constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
 static_assert(kItems2 <= kThreads && kItems3 <= 256, "one item per thread");
@@ -171,6 +171,8 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
     // without unaligned-access-mode (ADSB_NO_UNALIGNED below), or these would be merged into
     // 8/16-byte reads at a 2-byte aligned address, which the LDS replays at 64 cycles each.
     const uint16_t *pm = mag + (ent & 0x1FFFu);
+    const uint32_t br = (ent >> 13) & 7u;  // which branch's pattern matched, with "<=" for "<"
+    const int p0 = pm[0];
     const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
               p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
     const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
@@ -180,7 +182,7 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
         (unsigned long long)kBranchTerms[0] | ((unsigned long long)kBranchTerms[1] << 10) |
         ((unsigned long long)kBranchTerms[2] << 20) | ((unsigned long long)kBranchTerms[3] << 30) |
         ((unsigned long long)kBranchTerms[4] << 40);
-    const int terms = (int)(uint32_t)(kTermsPacked >> (10u * ((ent >> 13) & 7u)));
+    const int terms = (int)(uint32_t)(kTermsPacked >> (10u * br));
 #define TERM(bit) __builtin_amdgcn_sbfe(terms, (bit), 1)
     const int s39 = p3 + p9, s410 = p4 + p10;
     const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
@@ -188,7 +190,16 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
     const int noise = p6 + p7 + (p5 & TERM(8)) + (p8 & TERM(9));
 #undef TERM
     const int loud = max(max(max(p5, p6), max(p7, p8)), max(max(q14, q15), max(max(q16, q17), q18)));
-    return (uint32_t)(2 * sig >= 3 * noise) & (uint32_t)(loud < high);  // :129, :135-146
+    uint32_t pass = (uint32_t)(2 * sig >= 3 * noise) & (uint32_t)(loud < high);  // :129, :135-146
+    // The pattern stage has no "<" plane: it took p[o] <= p[o+1] for the four "<" of the branch
+    // (:221 and the branch's own three).  Equal neighbours are rare; when one of those four
+    // pairs is equal the reference may have taken a later branch or none, so that position is
+    // decided by the reference's own sequence of tests (preamble_gates, adsb_dev_common.h).
+    const int dx = br >= 3u ? p4 - p3 : p3 - p2;      // branches 4, 5: p3 < p4;  1-3: p2 < p3
+    const int dy = br >= 3u ? p10 - p9 : p9 - p8;     //               p9 < p10;      p8 < p9
+    const int dz = br == 0u ? p11 - p10 : p12 - p11;  // branch 1: p10 < p11;  others: p11 < p12
+    if (min(min(p1 - p0, dx), min(dy, dz)) <= 0) pass = (uint32_t)preamble_gates(pm);
+    return pass;
 }
 
 // candidate entry: slot | slot/12 << 13 | slot%12 << 23
@@ -470,9 +481,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
         constexpr int R = kResPerItem, G = 12 / R;
         const int g = tid % G, kw = tid / G;
         const uint16_t *base = s.mag + 96 * kw + R * g;  // 4-byte aligned (R even)
-        uint32_t acc[7][R];
+        uint32_t acc[6][R];
 #pragma unroll
-        for (int q = 0; q < 7; q++)
+        for (int q = 0; q < 6; q++)
 #pragma unroll
             for (int r = 0; r < R; r++) acc[q][r] = 0;
 #pragma unroll
@@ -523,10 +534,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                     acc[3][r] = push_sign(acc[3][r], n3);
                     acc[4][r] = push_sign(acc[4][r], n4);
                 }
-                // kk == 8 is one plane bit beyond the byte, for LT/GT only: it completes the
-                // "advanced by one bit" copies that P3 addresses as residues 12..23
-                acc[5][r] = push_sign(acc[5][r], -ea);  // LT: m[s] < m[s+1]
-                acc[6][r] = push_sign(acc[6][r], ea);   // GT: m[s] > m[s+1]
+                // kk == 8 is one plane bit beyond the byte, for GT only: it completes the "advanced
+                // by one bit" copies that P3 addresses as residues 12..23.  There is no "<" plane:
+                // P3 works with "<=" (the complement of ">") and the gates re-check strictness.
+                acc[5][r] = push_sign(acc[5][r], ea);   // GT: m[s] > m[s+1]
             }
         }
         uint8_t *pb = (uint8_t *)s.plane;
@@ -537,10 +548,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
             for (int q = 0; q < 5; q++) pb[(q * 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[q][r];
             // 9 bits: k = 8kw .. 8kw+8.  Residue res holds bits 0..7, residue res+12 (the
             // same plane advanced one bit) holds bits 1..8.
-            pb[(kPlaneLT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[5][r];
-            pb[(kPlaneGT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[6][r];
-            pb[(kPlaneLT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[5][r] >> 1);
-            pb[(kPlaneGT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[6][r] >> 1);
+            pb[(kPlaneGT + res) * (kPlaneDw * 4) + kw] = (uint8_t)acc[5][r];
+            pb[(kPlaneGT + 12 + res) * (kPlaneDw * 4) + kw] = (uint8_t)(acc[5][r] >> 1);
         }
     }
     ACCT(2);
@@ -571,10 +580,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     const int pres = ptid % 12, pw = ptid / 12;
     if (ptid < kItems3) {
         const int res = pres, w = pw;
-        const uint32_t *LT = s.plane + (kPlaneLT + res) * kPlaneDw + w;
         const uint32_t *GT = s.plane + (kPlaneGT + res) * kPlaneDw + w;
-#define LTO(o) LT[(o) * kPlaneDw]  // p[o] < p[o+1]
-#define GTO(o) GT[(o) * kPlaneDw]  // p[o] > p[o+1]
+#define GTO(o) GT[(o) * kPlaneDw]     // p[o] > p[o+1]
+#define LTO(o) (~GT[(o) * kPlaneDw])  // p[o] <= p[o+1]: a superset of the reference's "<"; the
+                                      // gates test the strict form of the branch they are handed
         // positions that are real j of this tile: kPad <= slot < kPad + jn
         const int kmin = (kPad - res + 11) / 12, kmax = (kPad + jn - res + 11) / 12;
         uint32_t ok = lowmask(kmax - 32 * w) & ~lowmask(kmin - 32 * w);
