@@ -202,6 +202,11 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
     return pass;
 }
 
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32: a ^ b ^ c in one op
+}
+
 // candidate entry: slot | slot/12 << 13 | slot%12 << 23
 __device__ __forceinline__ uint32_t cand_entry(uint32_t slot)
 {
@@ -250,15 +255,12 @@ __device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wca
     const uint32_t mk0 = lng ? 0x7FFFFFu : 0xFFFu, mk1 = lng ? 0x7FFFFFu : 0x7FFu, mk2 = lng ? 0x3FFFFFu : 0x7FFu;
     const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
     // sum_r x^(4-r) * F'(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
-    const char *tF = (const char *)s.tab;
+    const uint32_t *tF = s.tab;
     uint32_t g[5];
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
-        const uint32_t x4 = fm[r] << 2;  // byte offsets into the 256-entry tables
-        g[r] = *(const uint32_t *)(tF + (x4 & 0x3FCu)) ^ *(const uint32_t *)(tF + 1024 + ((x4 >> 8) & 0x3FCu)) ^
-               *(const uint32_t *)(tF + 2048 + ((x4 >> 16) & 0x3FCu));
-    }
-    const uint32_t hp = ((g[0] << 4) ^ (g[1] << 3) ^ (g[2] << 2)) ^ ((g[3] << 1) ^ g[4]);
+    for (int r = 0; r < 5; r++)  // one byte-select-and-shift per index, one three-way XOR per field
+        g[r] = xor3(tF[fm[r] & 0xFFu], tF[256 + ((fm[r] >> 8) & 0xFFu)], tF[512 + ((fm[r] >> 16) & 0xFFu)]);
+    const uint32_t hp = xor3(g[0] << 4, g[1] << 3, xor3(g[2] << 2, g[3] << 1, g[4]));
     const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
     o.h = h;
     o.code = tpi + 5u * lng;
