@@ -223,7 +223,7 @@ struct Trial {
     uint32_t h;      // x^51 * H reduced: short messages' CRC residual as is (adsb_tables.h)
     uint32_t code;   // try_phase - 4, + 5 for 112-bit messages
     uint32_t cslot;
-    uint32_t flags;  // 1: address/parity trial, 2: self-validating hit, 4: hit that adds its address
+    bool is_ap, is_hit, learn;  // address/parity trial; self-validating hit; hit that adds its address
 };
 
 __device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wcand, uint32_t t5, Trial &o)
@@ -234,14 +234,14 @@ __device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wca
     const uint32_t qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
     o.cslot = ce & 0x1FFFu;
     const uint32_t *ft = s.field + tpi * 60u + rs;
-    const char *plane_bytes = (const char *)s.plane;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
-        const uint32_t fe = ft[r * 12];
+        const uint32_t fe = ft[r * 12];       // LDS address of the plane row | bit offset << 16 (P0)
         const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
         // 4-byte aligned only: becomes one ds_read2_b32 (not an 8-byte read off its alignment,
         // which is replayed at 64 cycles -- ADSB_NO_UNALIGNED)
-        const uint32_t *pl = (const uint32_t *)(plane_bytes + (fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
+        typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+        lds_u32 pl = (lds_u32)(uintptr_t)((fe & 0xFFFFu) + ((qq >> 3) & 0x7Cu));
         const uint32_t lo = pl[0], hi = pl[1];
         o.f[r] = alignbit(hi, lo, qq);  // the shift is qq mod 32
     }
@@ -249,9 +249,11 @@ __device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wca
     // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
     const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) | ((f[3] & 1u) << 1) | (f[4] & 1u);
     const uint32_t lng = f[0] & 1u;  // DF >= 16: 112 bits
-    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise (mod.rs:51 looks at all 14
-    // bytes); 56 bits: n <= 55 -> k <= 11 for r = 0, k <= 10 otherwise
-    const uint32_t nonzero = (uint32_t)((((f[0] | f[1]) & 0x7FFFFFu) | ((f[2] | f[3] | f[4]) & 0x3FFFFFu)) != 0);
+    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise; 56 bits: n <= 55 -> k <= 11
+    // for r = 0, k <= 10 otherwise.  (The reference's all-zero-message test, mod.rs:51, is left
+    // to the host replay: an all-zero trial is DF 0 with residual 0, goes out as an address/
+    // parity entry, matches address 0 and is dropped there -- it cannot arise in bulk, zero
+    // samples match no preamble.)
     const uint32_t mk0 = lng ? 0x7FFFFFu : 0xFFFu, mk1 = lng ? 0x7FFFFFu : 0x7FFu, mk2 = lng ? 0x3FFFFFu : 0x7FFu;
     const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
     // sum_r x^(4-r) * F'(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
@@ -264,15 +266,16 @@ __device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wca
     const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
     o.h = h;
     o.code = tpi + 5u * lng;
-    // DF classes as bit sets indexed by DF (mod.rs:56-135)
-    const uint32_t ap = (0xFF310031u >> df) & 1u;           // 0,4,5,16,20,21,24..31: address/parity
-    const uint32_t d1718 = (0x00060000u >> df) & 1u;        // clean iff residual == 0
-    const uint32_t d11 = (0x00000800u >> df) & 1u;          // clean iff residual & 0xFFFF80 == 0
-    const uint32_t z = (uint32_t)(h == 0), z11 = (uint32_t)((h & 0xFFFF80u) == 0);
-    const uint32_t hit = (d1718 & z) | (d11 & z11);
+    // DF classes as bit sets indexed by DF (mod.rs:56-135).  Comparisons, so that the class
+    // logic lives in lane masks on the scalar unit rather than in VALU arithmetic.
+    const bool ap = ((0xFF310031u >> df) & 1u) != 0;        // 0,4,5,16,20,21,24..31: address/parity
+    const bool d1718 = ((0x00060000u >> df) & 1u) != 0;     // clean iff residual == 0
+    const bool d11 = df == 11u;                             // clean iff residual & 0xFFFF80 == 0
+    const bool z = h == 0, z11 = (h & 0xFFFF80u) == 0;
+    o.is_ap = ap;
+    o.is_hit = (d1718 && z) || (d11 && z11);
     // DF17 and DF11 with IID 0 add their address; DF18 adds addr | 1 << 25, never matched
-    const uint32_t learn = z & (((0x00020800u >> df) & 1u));
-    o.flags = nonzero * (ap | (hit << 1) | (learn << 2));
+    o.learn = z && (d11 || df == 17u);
 }
 
 __device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 8..31
@@ -418,8 +421,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
         const uint32_t v = p.tables[kTabR16Off + i];
         if (i < 16)
             s.r16[i] = v;
-        else
-            s.field[i - 16] = v;
+        else  // plane row byte offset -> its LDS address, so that the trial stage adds nothing
+            s.field[i - 16] = v + (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s.plane;
     }
     if (tid < kPlanes) s.plane[tid * kPlaneDw + kPlaneDw - 1] = 0;  // read slack
     if (tid < 2) s.nhit[tid] = 0;
@@ -716,10 +719,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 for (int q = 0; q < kTrialSlots; q++) {
                     const uint32_t t5 = tb + (uint32_t)(lane + 64 * q);
                     trial_eval(s, wcand, min(t5, ntrial - 1u), tr[q]);
-                    const uint32_t fl = t5 < ntrial ? tr[q].flags : 0u;
-                    is_ap[q] = (fl & 1u) != 0;
-                    is_hit[q] = (fl & 2u) != 0;
-                    learn[q] = (fl & 4u) != 0;
+                    const bool live = t5 < ntrial;
+                    is_ap[q] = live && tr[q].is_ap;
+                    is_hit[q] = live && tr[q].is_hit;
+                    learn[q] = live && tr[q].learn;
                     // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
                     const uint32_t j = (uint32_t)(jbase - kPad) + tr[q].cslot;
                     entry[q] = ((uint64_t)((j >> 4) | (chunk << 13)) << 32) | (tr[q].h | (tr[q].code << 24) | (j << 28));
