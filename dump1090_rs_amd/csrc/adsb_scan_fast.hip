@@ -228,12 +228,12 @@ struct Trial {
 
 __device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wcand, uint32_t t5, Trial &o)
 {
-    const uint32_t c = (t5 * 13108u) >> 16;  // t5 / 5 (t5 < 4000)
-    const uint32_t tpi = t5 - 5u * c;
+    const uint32_t c = __umul24(t5, 13108u) >> 16;  // t5 / 5 (t5 < 1280: a 24-bit multiply, not the slow 32-bit one)
+    const uint32_t tpi = t5 - __umul24(5u, c);
     const uint32_t ce = wcand[c];
     const uint32_t qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
     o.cslot = ce & 0x1FFFu;
-    const uint32_t *ft = s.field + tpi * 60u + rs;
+    const uint32_t *ft = s.field + __umul24(tpi, 60u) + rs;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const uint32_t fe = ft[r * 12];       // LDS address of the plane row | bit offset << 16 (P0)
@@ -590,7 +590,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
 #define LTO(o) (~GT[(o) * kPlaneDw])  // p[o] <= p[o+1]: a superset of the reference's "<"; the
                                       // gates test the strict form of the branch they are handed
         // positions that are real j of this tile: kPad <= slot < kPad + jn
-        const int kmin = (kPad - res + 11) / 12, kmax = (kPad + jn - res + 11) / 12;
+        // (x + 11) / 12 with a 24-bit multiply (x < 16384), not the 32-bit mul_hi the compiler would use
+        const int kmin = (int)(__umul24((uint32_t)(kPad - res + 11), 10923u) >> 17),
+                  kmax = (int)(__umul24((uint32_t)(kPad + jn - res + 11), 10923u) >> 17);
         uint32_t ok = lowmask(kmax - 32 * w) & ~lowmask(kmin - 32 * w);
         if (kHalves == 2) ok &= phalf ? 0xFFFF0000u : 0x0000FFFFu;
         ok &= LTO(0) & GTO(12);                               // demod_2400.rs:221
