@@ -1169,6 +1169,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.5 gfx950 scan=v4-wave-segments"; }
+const char *adsb_version(void) { return "adsb_hip 0.6 gfx950 scan=v5-le-planes"; }
 
 }  // extern "C"
