@@ -143,12 +143,6 @@ __device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped
     return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
 }
 
-// Which magnitudes enter high / base_signal / base_noise for each of check_preamble's five
-// branches (src/demod_2400.rs:227-317), one bit per term:
-//   high  = (p1 + p12 + A*(p3+p9) + B*p11 + C*(p4+p10) + D*p2) / 4
-//   sig   = E*p1 + F*(p3+p9) + G*p12 + H*(p4+p10)
-//   noise = p6 + p7 + I*p5 + J*p8                              bits: A=0 B=1 ... J=9
-constexpr uint32_t kBranchTerms[5] = {0x133u, 0x371u, 0x055u, 0x3D4u, 0x2CCu};
 
 struct alignas(16) FastLds {
     uint16_t mag[kAllocSlots];         // P1..P4
@@ -176,19 +170,22 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
     const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
               p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
     const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
-    // the branch's terms (kBranchTerms, 10 bits each, packed into one 64-bit constant) as
-    // 0 / -1 masks (signed 1-bit field extracts)
-    constexpr unsigned long long kTermsPacked =
-        (unsigned long long)kBranchTerms[0] | ((unsigned long long)kBranchTerms[1] << 10) |
-        ((unsigned long long)kBranchTerms[2] << 20) | ((unsigned long long)kBranchTerms[3] << 30) |
-        ((unsigned long long)kBranchTerms[4] << 40);
-    const int terms = (int)(uint32_t)(kTermsPacked >> (10u * br));
-#define TERM(bit) __builtin_amdgcn_sbfe(terms, (bit), 1)
+    // high / base_signal / base_noise of the five branches (:227-317), written around what they
+    // share: with X = p3+p9 (branches 1-3) or p4+p10 (branches 4, 5)
+    //   high  = (p1 + p12 + X + [1]p11 + [3](p4+p10) + [5]p2) / 4
+    //   sig   = X*not[3] + p1*not[5] + p12*not[1]
+    //   noise = p6 + p7 + [1,2,4]p5 + [2,4,5]p8
+    // five 0 / -1 masks per branch, 5 bits each in one constant: A=[1] B=[3] C=[5] G=[1,2,4] H=[2,4,5]
+    constexpr uint32_t kMasksPacked = 9u | (24u << 5) | (2u << 10) | (24u << 15) | (20u << 20);
+    const int mk = (int)(kMasksPacked >> (5u * br));
+#define MASK(bit) __builtin_amdgcn_sbfe(mk, (bit), 1)
+    const int mA = MASK(0), mB = MASK(1), mC = MASK(2), mG = MASK(3), mH = MASK(4);
+#undef MASK
     const int s39 = p3 + p9, s410 = p4 + p10;
-    const int high = (p1 + p12 + (s39 & TERM(0)) + (p11 & TERM(1)) + (s410 & TERM(2)) + (p2 & TERM(3))) >> 2;
-    const int sig = (p1 & TERM(4)) + (s39 & TERM(5)) + (p12 & TERM(6)) + (s410 & TERM(7));
-    const int noise = p6 + p7 + (p5 & TERM(8)) + (p8 & TERM(9));
-#undef TERM
+    const int X = br >= 3u ? s410 : s39;
+    const int high = (p1 + p12 + X + (p11 & mA) + (s410 & mB) + (p2 & mC)) >> 2;
+    const int sig = (X & ~mB) + (p1 & ~mC) + (p12 & ~mA);
+    const int noise = p6 + p7 + (p5 & mG) + (p8 & mH);
     const int loud = max(max(max(p5, p6), max(p7, p8)), max(max(q14, q15), max(max(q16, q17), q18)));
     uint32_t pass = (uint32_t)(2 * sig >= 3 * noise) & (uint32_t)(loud < high);  // :129, :135-146
     // The pattern stage has no "<" plane: it took p[o] <= p[o+1] for the four "<" of the branch
