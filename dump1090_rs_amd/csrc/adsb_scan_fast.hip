@@ -132,10 +132,10 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
     return (uint32_t)v;
 }
 
-// rank of this lane among the set bits of a wave mask
-__device__ __forceinline__ uint32_t mask_rank(unsigned long long m)
+// base + rank of this lane among the set bits of a wave mask (the base rides in mbcnt's addend)
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m, uint32_t base = 0u)
 {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
 }
 
 __device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped to 0..32
@@ -652,7 +652,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 while (m) {
                     const uint32_t bit = (uint32_t)__ffs(m) - 1u;
                     m &= m - 1;
-                    const uint32_t k = ((code0 >> bit) & 1u) | (((code1 >> bit) & 1u) << 1) | (((code2 >> bit) & 1u) << 2);
+                    // three single-bit extracts and two shift-ors (left to itself the compiler
+                    // shifts and masks each plane separately: eight ops)
+                    uint32_t k = __builtin_amdgcn_ubfe(code0, bit, 1u);
+                    k |= __builtin_amdgcn_ubfe(code1, bit, 1u) << 1;
+                    k |= __builtin_amdgcn_ubfe(code2, bit, 1u) << 2;
                     wpat[at++] = (slot0 + 12u * bit) | (k << 13);
                 }
                 wave_lds_fence();
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 if (any) {
 #pragma unroll
                     for (int q = 0; q < kGateSlots; q++) {
-                        if (pass[q]) wcand[ncand_w + mask_rank(mask[q])] = cand_entry(ent[q] & 0x1FFFu);
+                        if (pass[q]) wcand[mask_rank(mask[q], ncand_w)] = cand_entry(ent[q] & 0x1FFFu);
                         ncand_w += (uint32_t)__popcll(mask[q]);
                     }
                 }
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 if (any_ap) {
 #pragma unroll
                     for (int q = 0; q < kTrialSlots; q++) {
-                        const uint32_t mine = ap_count + mask_rank(ma[q]);
+                        const uint32_t mine = mask_rank(ma[q], ap_count);
                         if (is_ap[q] && mine < seg_cap) seg[mine] = entry[q];
                         ap_count += (uint32_t)__popcll(ma[q]);
                     }
