@@ -12,17 +12,20 @@
 //  P2 sign planes  every decision the reference can ever take on this tile is the sign of
 //                  a short integer correlation of neighbouring magnitudes:
 //                    slicer phase ph at sample s (demod_2400.rs:72-83)   5 kinds
-//                    m[s] < m[s+1], m[s] > m[s+1] (check_preamble :221-317) 2 kinds
-//                  All seven are taken for every sample.  A lane walks samples 12 apart
+//                    m[s] > m[s+1] (check_preamble :221-317)              1 kind
+//                  (check_preamble's "<" is taken as "<=", the complement of ">", and made
+//                  strict again in P4).  All six are taken for every sample.  A lane walks samples 12 apart
 //                  (bit n and bit n+5 of a message are 12 samples apart), four
 //                  neighbouring residues at a time so the first differences are shared,
 //                  and shifts each sign into an accumulator with one v_alignbit -- no
 //                  compare, no cross-lane traffic.  The accumulators are stored as bytes
 //                  of bit planes: plane (kind, s mod 12), bit s div 12.
-//  P3 preamble     check_preamble's five patterns are AND/OR of the LT/GT planes at fixed
-//                  offsets: one lane evaluates 32 positions j per instruction.
+//  P3 preamble     check_preamble's five patterns are AND/OR of the ">" planes and their
+//                  complements at fixed offsets: one lane evaluates 32 positions j per instruction.
 //  P4 gates        the ~4.5 % of positions that match a pattern get the value tests
-//                  (high/SNR/quiet, :129-146) from LDS magnitudes, one lane each.
+//                  (high/SNR/quiet, :129-146) from LDS magnitudes, one lane each, and the
+//                  strict form of the "<" tests of the branch they matched (equal neighbours:
+//                  the reference's own test sequence decides).
 //  P5 trials       for the ~1 % that survive, each (j, try_phase) is one lane: the five
 //                  bit classes n mod 5 of the message are five 23-bit fields cut out of the
 //                  sign planes with two dword loads and a funnel shift; DF and the CRC-24
