@@ -72,15 +72,7 @@ static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
 constexpr int kWaves = kThreads / 64;
 constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
 constexpr int kRoundBits = 4;                 // plane bits per round when they do not fit: 64 x 4 <= 256
-#ifndef ADSB_GATE_SLOTS
-#define ADSB_GATE_SLOTS 1
-#endif
-#ifndef ADSB_TRIAL_SLOTS
-#define ADSB_TRIAL_SLOTS 1
-#endif
-constexpr int kGateSlots = ADSB_GATE_SLOTS;   // pattern matches one lane gates per pass
-constexpr int kTrialSlots = ADSB_TRIAL_SLOTS; // trials one lane evaluates per pass
-constexpr int kCandPerWave = 64 + 64 * kGateSlots;  // a wave's candidates waiting for the trial stage
+constexpr int kCandPerWave = 128;             // a wave's candidates waiting for the trial stage
 static_assert(64 * kRoundBits <= kPatPerWave, "wave-private regions");
 constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
 
@@ -226,11 +218,8 @@ struct Trial {
     bool is_ap, is_hit, learn;  // address/parity trial; self-validating hit; hit that adds its address
 };
 
-__device__ __forceinline__ void trial_eval(const FastLds &s, const uint32_t *wcand, uint32_t t5, Trial &o)
+__device__ __forceinline__ void trial_eval(const FastLds &s, uint32_t ce, uint32_t tpi, Trial &o)
 {
-    const uint32_t c = __umul24(t5, 13108u) >> 16;  // t5 / 5 (t5 < 1280: a 24-bit multiply, not the slow 32-bit one)
-    const uint32_t tpi = t5 - __umul24(5u, c);
-    const uint32_t ce = wcand[c];
     const uint32_t qs = (ce >> 13) & 0x3FFu, rs = ce >> 23;
     o.cslot = ce & 0x1FFFu;
     const uint32_t *ft = s.field + __umul24(tpi, 60u) + rs;
@@ -378,6 +367,68 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
         pre[0].z |= v.z;
         pre[0].w |= v.w;
     }
+}
+
+// A lane writes its own matches (bits of m; the branch 0..4 of each from the three code planes)
+// into the wave's pattern region from index `at` on: slot | branch << 13.
+__device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint32_t code1, uint32_t code2,
+                                                uint32_t slot0, uint32_t *wpat, uint32_t at)
+{
+    while (m) {
+        const uint32_t bit = (uint32_t)__ffs(m) - 1u;
+        m &= m - 1;
+        // three single-bit extracts and two shift-ors (left to itself the compiler shifts and
+        // masks each plane separately: eight ops)
+        uint32_t k = __builtin_amdgcn_ubfe(code0, bit, 1u);
+        k |= __builtin_amdgcn_ubfe(code1, bit, 1u) << 1;
+        k |= __builtin_amdgcn_ubfe(code2, bit, 1u) << 2;
+        wpat[at++] = (slot0 + 12u * bit) | (k << 13);
+    }
+}
+
+// One 64-lane pass of the gates: `ent` is this lane's pattern match (valid lanes only count),
+// passing positions are appended to the wave's candidate region.
+__device__ __forceinline__ void gate_pass(const FastLds &s, uint32_t ent, bool valid, uint32_t *wcand,
+                                          uint32_t &ncand_w)
+{
+    const bool pass = (gate_eval(s.mag, ent) & (uint32_t)valid) != 0;
+    const unsigned long long mask = __ballot(pass);
+    if (mask) {
+        if (pass) wcand[mask_rank(mask, ncand_w)] = cand_entry(ent & 0x1FFFu);
+        ncand_w += (uint32_t)__popcll(mask);
+    }
+}
+
+// One 64-lane pass of the trials: lane = (candidate entry ce, try_phase 4 + tpi).
+__device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint32_t ce, uint32_t tpi, bool live,
+                                           int jbase, uint32_t chunk, uint64_t *seg, uint32_t seg_cap,
+                                           uint32_t &ap_count, int lane, uint32_t par)
+{
+    Trial tr;
+    trial_eval(s, ce, tpi, tr);
+    const bool is_ap = live && tr.is_ap, is_hit = live && tr.is_hit, learn = live && tr.learn;
+    // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
+    const uint32_t j = (uint32_t)(jbase - kPad) + tr.cslot;
+    const uint64_t entry = ((uint64_t)((j >> 4) | (chunk << 13)) << 32) | (tr.h | (tr.code << 24) | (j << 28));
+    // AP entries: straight into this wave's own segment of the list (no atomic, no shared
+    // counter: the fill count is a wave-uniform register)
+    const unsigned long long ma = __ballot(is_ap);
+    if (ma) {
+        const uint32_t mine = mask_rank(ma, ap_count);
+        if (is_ap && mine < seg_cap) seg[mine] = entry;
+        ap_count += (uint32_t)__popcll(ma);
+    }
+    if (__ballot(is_hit)) stage_hit(p, s, is_hit, entry, lane, par);  // rare
+    if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
+        if (learn) bitmap_set(p.bitmap, trial_addr(tr));
+    }
+}
+
+// t5 = 5 c + tpi for t5 < 3277 (24-bit multiply, not the slow 32-bit one)
+__device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
+{
+    c = __umul24(t5, 13108u) >> 16;
+    tpi = t5 - __umul24(5u, c);
 }
 
 // profiling aids, compiled in with -DADSB_KERNEL_ACCT only (they cost registers):
@@ -650,53 +701,25 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                     round++;
                     continue;
                 }
-                uint32_t at = incl - cnt;
-                uint32_t m = any_all & rmask;
-                while (m) {
-                    const uint32_t bit = (uint32_t)__ffs(m) - 1u;
-                    m &= m - 1;
-                    // three single-bit extracts and two shift-ors (left to itself the compiler
-                    // shifts and masks each plane separately: eight ops)
-                    uint32_t k = __builtin_amdgcn_ubfe(code0, bit, 1u);
-                    k |= __builtin_amdgcn_ubfe(code1, bit, 1u) << 1;
-                    k |= __builtin_amdgcn_ubfe(code2, bit, 1u) << 2;
-                    wpat[at++] = (slot0 + 12u * bit) | (k << 13);
-                }
+                compact_matches(any_all & rmask, code0, code1, code2, slot0, wpat, incl - cnt);
                 wave_lds_fence();
                 in_round = true;
                 base = 0;
             }
 
             // ------------------------------------------------------------ P4 value gates
-            // one lane per pattern match, kGateSlots matches per lane and pass (gate_eval)
+            // one lane per pattern match (gate_pass)
             {
-                uint32_t ent[kGateSlots];
-                unsigned long long mask[kGateSlots];
-                bool pass[kGateSlots];
-                unsigned long long any = 0;
-#pragma unroll
-                for (int q = 0; q < kGateSlots; q++) {
-                    const uint32_t idx = base + (uint32_t)(lane + 64 * q);
-                    ent[q] = wpat[min(idx, npat_w - 1u)];
-                    pass[q] = (gate_eval(s.mag, ent[q]) & (uint32_t)(idx < npat_w)) != 0;
-                }
-#pragma unroll
-                for (int q = 0; q < kGateSlots; q++) any |= (mask[q] = __ballot(pass[q]));
-                if (any) {
-#pragma unroll
-                    for (int q = 0; q < kGateSlots; q++) {
-                        if (pass[q]) wcand[mask_rank(mask[q], ncand_w)] = cand_entry(ent[q] & 0x1FFFu);
-                        ncand_w += (uint32_t)__popcll(mask[q]);
-                    }
-                }
+                const uint32_t idx = base + (uint32_t)lane;
+                gate_pass(s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, ncand_w);
             }
-            base += 64 * kGateSlots;
+            base += 64;
             if (base >= npat_w) {
                 in_round = false;
                 round++;
             }
             // room for another pass of the gates and more of them to come: not yet
-            if (round < nrounds && ncand_w + 64 * kGateSlots <= (uint32_t)kCandPerWave) continue;
+            if (round < nrounds && ncand_w + 64 <= (uint32_t)kCandPerWave) continue;
         }
         if (ncand_w == 0) {
             if (round >= nrounds) break;
@@ -710,54 +733,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
         }
 
         // ---------------------------------------------------------------- P5 trials
-        // lane = (candidate, try_phase), kTrialSlots trials per lane and pass (trial_eval).
+        // lane = (candidate, try_phase) (trial_pass)
         {
             const uint32_t ntrial = ncand_w * 5u;
             cand_count += ncand_w;
             ncand_w = 0;
-            for (uint32_t tb = 0; tb < ntrial; tb += 64 * kTrialSlots) {
-                Trial tr[kTrialSlots];
-                uint64_t entry[kTrialSlots];
-                bool is_ap[kTrialSlots], is_hit[kTrialSlots], learn[kTrialSlots];
-                unsigned long long ma[kTrialSlots];
-                unsigned long long any_ap = 0, any_hit = 0, any_learn = 0;
-#pragma unroll
-                for (int q = 0; q < kTrialSlots; q++) {
-                    const uint32_t t5 = tb + (uint32_t)(lane + 64 * q);
-                    trial_eval(s, wcand, min(t5, ntrial - 1u), tr[q]);
-                    const bool live = t5 < ntrial;
-                    is_ap[q] = live && tr[q].is_ap;
-                    is_hit[q] = live && tr[q].is_hit;
-                    learn[q] = live && tr[q].learn;
-                    // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
-                    const uint32_t j = (uint32_t)(jbase - kPad) + tr[q].cslot;
-                    entry[q] = ((uint64_t)((j >> 4) | (chunk << 13)) << 32) | (tr[q].h | (tr[q].code << 24) | (j << 28));
-                }
-#pragma unroll
-                for (int q = 0; q < kTrialSlots; q++) {
-                    any_ap |= (ma[q] = __ballot(is_ap[q]));
-                    any_hit |= __ballot(is_hit[q]);
-                    any_learn |= __ballot(learn[q]);
-                }
-                // AP entries: straight into this wave's own segment of the list (no atomic, no
-                // shared counter: the fill count is a wave-uniform register)
-                if (any_ap) {
-#pragma unroll
-                    for (int q = 0; q < kTrialSlots; q++) {
-                        const uint32_t mine = mask_rank(ma[q], ap_count);
-                        if (is_ap[q] && mine < seg_cap) seg[mine] = entry[q];
-                        ap_count += (uint32_t)__popcll(ma[q]);
-                    }
-                }
-                if (any_hit) {  // rare
-#pragma unroll
-                    for (int q = 0; q < kTrialSlots; q++) stage_hit(p, s, is_hit[q], entry[q], lane, par);
-                }
-                if (any_learn) {  // rare: the host replay will add this address to the filter
-#pragma unroll
-                    for (int q = 0; q < kTrialSlots; q++)
-                        if (learn[q]) bitmap_set(p.bitmap, trial_addr(tr[q]));
-                }
+            for (uint32_t tb = 0; tb < ntrial; tb += 64) {
+                const uint32_t t5 = tb + (uint32_t)lane;
+                uint32_t c, tpi;
+                split5(min(t5, ntrial - 1u), c, tpi);
+                trial_pass(p, s, wcand[c], tpi, t5 < ntrial, jbase, chunk, seg, seg_cap, ap_count, lane, par);
             }
             wave_lds_fence();  // wcand is reused by the next passes of the gates
         }
