@@ -72,13 +72,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the demod_2400 path has no CPU fallback")
+    # (ADSB_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than
+    # ranks: ranks then share devices and the timing reduction goes over CPU tensors)
+    backend = os.environ.get("ADSB_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from dump1090_rs_amd import Context, synth
     from dump1090_rs_amd._lib import AdsbMsg
@@ -159,7 +167,7 @@ def main():
 
     if dist is not None:
         from dump1090_rs_amd import sharding
-        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device=dev)
+        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device=dev if backend == "nccl" else "cpu")
 
     total_samples = n * args.steps * world
     msps = total_samples / elapsed / 1e6
@@ -331,7 +339,8 @@ def stream_bench(args, torch, dist, rank, world, local_rank):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         from dump1090_rs_amd import sharding
-        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device=torch.device("cuda", local_rank))
+        gloo = os.environ.get("ADSB_BENCH_BACKEND", "nccl") != "nccl"
+        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device="cpu" if gloo else torch.device("cuda", local_rank))
     from dump1090_rs_amd import _lib
     msps = n * args.steps * world / elapsed / 1e6
     scan_avg_s = scan_ms / args.steps / 1e3
