@@ -487,15 +487,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     c->max_chunks = max_chunks;
     if (const char *ds = std::getenv("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     if (const char *st = std::getenv("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
-    // lists sized for ~5x the rate pure noise produces (2.3 % of samples become
-    // address/parity entries); denser input falls back to per-chunk passes
-    // Fast-scan AP list: kApSegments private segments, sized for ~5x the rate pure noise
-    // produces (2.3 % of samples become address/parity entries), never less than one
-    // tile's staging buffer so that a single-chunk pass always fits.  Denser input falls
-    // back to per-chunk passes.  dap (simple kernel) holds a whole chunk's worst
-    // case: every j sliced, five trials each.
-    // (a pass of n buffers runs min(17 n, 1024) workgroups of four waves: a small context only
-    // gets the segments it can ever use)
+    // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
+    // of n buffers runs min(17 n, 1024) workgroups of four waves, so a small context only gets
+    // the segments it can ever use), each sized for ~5x the rate pure noise produces (2.3 % of
+    // samples become address/parity entries).  Denser input falls back to buffer-by-buffer
+    // passes through the reference-shaped kernel, whose list (dap) and the hit list hold one
+    // buffer's worst case: every position sliced, five trials each.
     const uint64_t used_segs = 4 * std::min<uint64_t>(kApSegments, max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
     c->seg_cap = (uint32_t)std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + used_segs - 1) / used_segs);
     c->ap_cap = (uint32_t)(used_segs * c->seg_cap);
