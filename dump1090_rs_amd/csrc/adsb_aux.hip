@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             unsigned long long half[2];
+            bool mybit[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int nbit = lane + 64 * h;
@@ -192,9 +193,20 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
                     const int sidx = pos / 5;
                     bit = slice_value(&win[wave][sidx], pos - 5 * sidx) > 0;
                 }
+                mybit[h] = bit;
                 // lane n holds message bit n; the message is MSB-first
                 half[h] = __brevll(__ballot(bit));
             }
+            // the CRC residual, so that the host replay does not have to walk the bytes: XOR over
+            // the set bits n of x^(bits-1-n) mod g (adsb_tables.h: build_bit_residuals), bits =
+            // 112 when DF >= 16 (message bit 0 set), else 56
+            const bool lng = (half[0] >> 63) != 0;
+            const uint32_t *tb = p.tables + kTabBitsOff;
+            uint32_t crc = 0;
+            if (mybit[0] && (lng || lane < 56)) crc = tb[(lng ? 0 : 112) + lane];
+            if (mybit[1] && lng) crc ^= tb[64 + lane];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) crc ^= __shfl_xor(crc, off);
             unsigned long long pw = 0;
             if (lane < 33) {
                 const unsigned long long m = win[wave][lane];
@@ -204,14 +216,14 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             for (int off = 32; off > 0; off >>= 1) pw += __shfl_down(pw, off);
             if (lane == 0) {
                 TrialRecord r;
-                r.power = pw;
+                r.power = pw | ((unsigned long long)crc << 40);  // pw < 2^38
                 r.chunk = (uint32_t)chunk;
                 r.j_tp = j | (tp << 24);
 #pragma unroll
                 for (int k = 0; k < 8; k++) r.msg[k] = (uint8_t)(half[0] >> (56 - 8 * k));
 #pragma unroll
                 for (int k = 0; k < 6; k++) r.msg[8 + k] = (uint8_t)(half[1] >> (56 - 8 * k));
-                r.pad = 0;
+                r.pad = 1;  // `power` carries the residual
                 stage[q] = r;
             }
             __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next hit

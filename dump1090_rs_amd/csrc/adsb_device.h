@@ -48,11 +48,12 @@ constexpr uint64_t kMaxChunks = 1ull << 19;  // per device pass (256 GiB of IQ)
 
 // One trial message handed to the host replay (32 bytes).
 struct TrialRecord {
-    uint64_t power;     // sum of the 33 squared magnitudes from j+19 (demod_2400.rs:191-196)
+    uint64_t power;     // bits 0..39: sum of the 33 squared magnitudes from j+19 (demod_2400.rs:
+                        // 191-196; < 2^38).  With pad == 1, bits 40..63: the CRC residual of msg
     uint32_t chunk;
     uint32_t j_tp;      // j | try_phase << 24
     uint8_t msg[14];
-    uint16_t pad;
+    uint16_t pad;       // 1: `power` carries the residual (records built on the device), 0: it does not
 };
 static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 
@@ -91,7 +92,8 @@ struct Summary {
 // GF(2) tables, 256 u32 each (adsb_tables.h): F'0 F'1 F'2 | X56_0..2
 constexpr int kTabF = 0, kTabX56 = 3, kTabCount = 6;
 // after them in the same buffer: R16 (16 u32, adsb_tables.h) and the field table (300 u32)
-constexpr int kTabR16Off = kTabCount * 256, kTabFieldOff = kTabR16Off + 16, kTabWords = kTabFieldOff + 300;
+constexpr int kTabR16Off = kTabCount * 256, kTabFieldOff = kTabR16Off + 16, kTabBitsOff = kTabFieldOff + 300,
+              kTabWords = kTabBitsOff + 168;  // + per-bit residual constants (build_bit_residuals)
 
 struct ScanParams {
     const void *src;        // IQ as {re,im} int16 pairs, or u16 magnitudes (from_mag)

@@ -183,14 +183,16 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
         best.len = ADSB_MODES_SHORT_MSG_BYTES;
         for (; i < n && (order[i].key >> 8) == pos; i++) {
             const TrialRecord &r = rec[order[i].idx];
-            const Score s = score_modes_message(filter, crc, r.msg);
+            // records built on the device bring the CRC residual along (pad == 1)
+            const Score s = r.pad == 1 ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg)
+                                       : score_modes_message(filter, crc, r.msg);
             if (!s.some || s.value <= best.score) continue;
             std::memcpy(best.msg, r.msg, 14);
             best.len = (uint8_t)s.len;
             best.score = s.value;
             best.try_phase = (uint8_t)(r.j_tp >> 24);
             // demod_2400.rs:191-198: signal_len = 14*12/5 = 33
-            const double signal_power = (double)r.power / 65535.0 / 65535.0;
+            const double signal_power = (double)(r.power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
             best.signal_level = signal_power / 33.0;
         }
         if (best.score < 0) continue;
@@ -535,9 +537,11 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
             std::vector<uint32_t> tab = build_gf_tables();
-            const std::vector<uint32_t> r16 = build_r16(), ft = build_field_table(fast_plane_bytes());
+            const std::vector<uint32_t> r16 = build_r16(), ft = build_field_table(fast_plane_bytes()),
+                                        bits = build_bit_residuals();
             tab.insert(tab.end(), r16.begin(), r16.end());
             tab.insert(tab.end(), ft.begin(), ft.end());
+            tab.insert(tab.end(), bits.begin(), bits.end());
             HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
                                  hipMemcpyHostToDevice));
         }

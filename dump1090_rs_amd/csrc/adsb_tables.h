@@ -82,6 +82,20 @@ inline std::vector<uint32_t> build_r16()
     return r;
 }
 
+// Per-bit residual constants for the records kernel: the residual of a message is the XOR of
+// x^(bits-1-n) mod g over its set bits n (src/crc.rs:263-282 is M(x) mod g, see above).
+// [0..112): x^(111-n) for 112-bit messages; [112..168): x^(55-n) for 56-bit ones.
+inline std::vector<uint32_t> build_bit_residuals()
+{
+    std::vector<uint32_t> t(168, 0);
+    uint32_t p = 1;
+    for (int e = 0; e < 112; e++, p = gf_mulx(p)) {
+        t[111 - e] = p;
+        if (e < 56) t[112 + 55 - e] = p;
+    }
+    return t;
+}
+
 // Field addressing of the fast scan's trial phase.  Message bit n = 5k + r of trial phase
 // tp = 4 + tpi at a preamble whose LDS slot is 12*qs + rs sits in sign plane
 // (ph, res), bit qs + carry + k, with

@@ -100,8 +100,9 @@ struct Score {
     int32_t value;
 };
 
-// src/mode_s/mod.rs:34-139 on a 14-byte trial message.
-inline Score score_modes_message(IcaoFilter &filter, const Crc24 &crc, const uint8_t msg[14])
+// src/mode_s/mod.rs:34-139 on a 14-byte trial message whose CRC residual (over its own length:
+// 14 bytes for DF >= 16, else 7) is already known.
+inline Score score_modes_message(IcaoFilter &filter, uint32_t residual, const uint8_t msg[14])
 {
     const uint32_t df = msg[0] >> 3;                            // :41
     const int len = (df & 0x10) ? 14 : 7;                       // :42-46
@@ -113,10 +114,10 @@ inline Score score_modes_message(IcaoFilter &filter, const Crc24 &crc, const uin
     int32_t v = -2;
     switch (df) {
     case 0: case 4: case 5:                                     // :56-72
-        v = filter.test(crc.residual(msg, len)) ? 1000 : -1;
+        v = filter.test(residual) ? 1000 : -1;
         break;
     case 11: {                                                  // :73-90
-        const uint32_t c = crc.residual(msg, len);
+        const uint32_t c = residual;
         const bool known = filter.test(addr);
         if ((c & 0xFFFF80u) != 0) {
             v = -2;
@@ -133,7 +134,7 @@ inline Score score_modes_message(IcaoFilter &filter, const Crc24 &crc, const uin
         break;
     }
     case 17: case 18: {                                         // :91-109
-        const uint32_t c = crc.residual(msg, len);
+        const uint32_t c = residual;
         if (c != 0) {
             v = -2;
         } else if (filter.test(addr)) {
@@ -146,12 +147,18 @@ inline Score score_modes_message(IcaoFilter &filter, const Crc24 &crc, const uin
     }
     case 16: case 20: case 21:                                  // :110-120
     case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:  // :121-135
-        v = filter.test(crc.residual(msg, 14)) ? 1000 : -2;
+        v = filter.test(residual) ? 1000 : -2;
         break;
     default:
         v = -2;                                                 // :136
     }
     return {true, len, v};
+}
+
+// ... computing the residual here (src/crc.rs:263-282)
+inline Score score_modes_message(IcaoFilter &filter, const Crc24 &crc, const uint8_t msg[14])
+{
+    return score_modes_message(filter, crc.residual(msg, (msg[0] & 0x80) ? 14 : 7), msg);
 }
 
 }  // namespace adsb

@@ -166,11 +166,14 @@ int adsb_format_raw(const adsb_msg *msg, char *out, size_t out_size);
 
 /* One trial message as the device hands it to the host replay. */
 typedef struct {
-    uint64_t power;   /* sum of the 33 squared magnitudes from j+19 (demod_2400.rs:191-196) */
+    uint64_t power;   /* bits 0..39: sum of the 33 squared magnitudes from j+19 (demod_2400.rs:
+                       * 191-196; below 2^38); bits 40..63: see pad */
     uint32_t chunk;
     uint32_t j_tp;    /* j | try_phase << 24 */
     uint8_t msg[ADSB_MODES_LONG_MSG_BYTES];
-    uint16_t pad;
+    uint16_t pad;     /* 0: nothing more.  1 (records from adsb_shard_finish): bits 40..63 of
+                       * `power` hold the CRC residual of msg over its own length (src/crc.rs:
+                       * 263-282), which spares adsb_replay_records the walk over the bytes */
 } adsb_trial;
 
 /* Carry-over mode -- opt-in and NOT the reference's semantics.  dump1090_rs starts every
