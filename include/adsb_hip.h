@@ -95,8 +95,12 @@ typedef struct {
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks);
 void adsb_destroy(adsb_ctx *ctx);
 
-/* Launch on the caller's HIP stream (e.g. torch's current stream) instead of the
- * context's own.  Pass NULL to go back to the private stream. */
+/* Order the context's work behind the caller's HIP stream (e.g. torch's current stream)
+ * instead of the context's own: whatever that stream has been given before a call (the
+ * kernels or copies that produce the IQ) is complete before the pass reads its input.  The
+ * passes themselves run on the context's internal streams; their results are handed over
+ * by the blocking call or by adsb_collect, not through the stream.  Pass NULL to go back to
+ * the private stream. */
 int adsb_set_stream(adsb_ctx *ctx, void *hip_stream);
 /* HIP-event timing of the kernels: 0 = off, 1 = ms_scan only (default; two events),
  * 2 = also ms_match / ms_records / ms_total_device (an event costs the
