@@ -393,7 +393,7 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bo
            hipEvent_t input_done = nullptr)
 {
     const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
-    if (n_chunks == 0 || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+    if (n_chunks == 0 || n_chunks > kMaxChunks || n_chunks > c->max_chunks) return ADSB_ERR_INVALID;
     Slot &sl = c->slot[c->submitted % kSlots];
     if (sl.busy || c->shard_active) return ADSB_ERR_BUSY;
     int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks, inline_tail, false, true, false,
@@ -421,8 +421,10 @@ int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<
         return ADSB_OK;
     }
     adsb_stats total{};
-    // device passes are limited to kMaxChunks chunks (entry packing): longer streams go in pieces
-    const uint64_t piece = kMaxChunks * (uint64_t)kChunkSamples;
+    // a device pass takes at most max_chunks buffers (what the context's lists were sized for;
+    // never more than kMaxChunks: entry packing): longer streams go in pieces, which is what
+    // consecutive calls would be -- buffers are independent but for the filter
+    const uint64_t piece = std::min<uint64_t>(kMaxChunks, c->max_chunks) * (uint64_t)kChunkSamples;
     for (uint64_t off = 0; off < n_samples; off += piece) {
         const uint64_t n = std::min<uint64_t>(piece, n_samples - off);
         std::vector<adsb_msg> part;
@@ -754,7 +756,8 @@ int adsb_submit_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples)
 {
     if (!c || !d_iq || n_samples == 0) return ADSB_ERR_INVALID;
     if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
-    if ((n_samples + kChunkSamples - 1) / kChunkSamples > kMaxChunks) return ADSB_ERR_INVALID;
+    if ((n_samples + kChunkSamples - 1) / kChunkSamples > std::min<uint64_t>(kMaxChunks, c->max_chunks))
+        return ADSB_ERR_INVALID;  // more buffers than the context was created for
     HIP_TRY(c, hipSetDevice(c->device));
     return submit(c, d_iq, false, n_samples);
 }

@@ -141,7 +141,10 @@ int adsb_demod_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_sa
  * filter and returns its messages, so results come back in submission order and the
  * host replay of pass i overlaps the device scan of pass i+1.  adsb_icao_flush applies
  * to the passes submitted after it.  The synchronous calls return ADSB_ERR_BUSY while
- * anything is pending.  device_iq must stay valid and unchanged until its collect. */
+ * anything is pending.  device_iq must stay valid and unchanged until its collect.  One
+ * submission holds at most the max_chunks buffers the context was created for
+ * (ADSB_ERR_INVALID beyond that; adsb_demod_iq_device cuts longer inputs into such passes
+ * itself). */
 int adsb_submit_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples);
 int adsb_collect(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 int adsb_pending(const adsb_ctx *ctx);

@@ -581,3 +581,24 @@ def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
                        capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "80 cases identical" in r.stdout
+
+
+def test_inputs_longer_than_the_context_was_sized_for(hip_lib, oracle_mod):
+    """A context created for 2 buffers: the blocking device call cuts a 5-buffer input into passes
+    it can hold (same frames, filter carried along); one submission of more than 2 is refused."""
+    import torch
+    from dump1090_rs_amd import Context
+    from dump1090_rs_amd._lib import AdsbError, ADSB_ERR_INVALID
+    n = 5 * 131072 - 321
+    iq = synth.make_iq(n, n_bursts=60, seed=606, n_icao=8, df11_every=5)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    dev = torch.from_numpy(iq).cuda()
+    with Context(0, 2) as c:
+        c.icao_flush()
+        assert_same(c.demod_iq_device(dev.data_ptr(), n), want)
+        c.icao_flush()
+        assert_same(c.demod_iq(iq), want)
+        with pytest.raises(AdsbError) as e:
+            c.submit_iq_device(dev.data_ptr(), 3 * 131072)
+        assert e.value.status == ADSB_ERR_INVALID
+        assert c.pending() == 0
