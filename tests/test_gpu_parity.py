@@ -602,3 +602,52 @@ def test_inputs_longer_than_the_context_was_sized_for(hip_lib, oracle_mod):
             c.submit_iq_device(dev.data_ptr(), 3 * 131072)
         assert e.value.status == ADSB_ERR_INVALID
         assert c.pending() == 0
+
+
+def test_abi_misuse_is_refused_not_crashed(hip_lib):
+    """Bad arguments and calls out of order come back as negative statuses (never an abort,
+    never a device fault), and the context stays usable afterwards."""
+    import torch
+    from dump1090_rs_amd._lib import AdsbMsg
+    L = hip_lib
+    h = C.c_void_p()
+    assert L.adsb_create(C.byref(h), 0, 2) == 0
+    n = C.c_size_t()
+    out = (AdsbMsg * 16)()
+    dev = torch.zeros((3 * 131072, 2), dtype=torch.int16, device="cuda")
+    ptr = dev.data_ptr()
+    INVALID, BUSY, CAPACITY = -1, -7, -5
+    assert L.adsb_demod_iq_device(h, None, 100, out, 16, C.byref(n)) == INVALID
+    assert L.adsb_demod_iq_device(h, C.c_void_p(ptr + 4), 1000, out, 16, C.byref(n)) == INVALID     # not 16-byte aligned
+    assert L.adsb_demod_iq_device(h, C.c_void_p(ptr), 1000, None, 16, C.byref(n)) == INVALID
+    assert L.adsb_demod_iq_device(h, C.c_void_p(ptr), 0, out, 16, C.byref(n)) == 0 and n.value == 0  # empty stream: no frames
+    assert L.adsb_collect(h, out, 16, C.byref(n)) == INVALID                                          # nothing pending
+    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 3 * 131072) == INVALID                         # > max_chunks
+    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 0) == INVALID
+    assert L.adsb_shard_finish(h, None, 0, None, 0, C.byref(n)) == INVALID                            # no shard parked
+    assert L.adsb_ring_submit(h, 100) == INVALID                                                      # no ring yet
+    assert L.adsb_ring_create(h, 3 * 131072) == INVALID                                               # > max_chunks
+    assert L.adsb_ring_create(h, 131072) == 0
+    assert L.adsb_ring_create(h, 131072) == INVALID                                                   # once only
+    assert L.adsb_ring_submit(h, 131073) == INVALID
+    # two in flight, the third is refused; blocking calls are refused while passes are pending
+    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
+    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
+    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == BUSY
+    assert L.adsb_demod_iq_device(h, C.c_void_p(ptr), 1000, out, 16, C.byref(n)) == BUSY
+    assert L.adsb_set_carry_over(h, 1) == BUSY
+    assert L.adsb_pending(h) == 2
+    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and n.value == 0
+    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 0
+    # too small an output array: the count comes back, the first `cap` entries are written
+    iq = synth.make_iq(131072, n_bursts=20, seed=3)
+    t = torch.from_numpy(iq).cuda()
+    assert L.adsb_icao_flush(h) == 0
+    assert L.adsb_demod_iq_device(h, C.c_void_p(t.data_ptr()), 131072, out, 2, C.byref(n)) == CAPACITY and n.value > 2
+    need = n.value
+    big = (AdsbMsg * need)()
+    assert L.adsb_icao_flush(h) == 0
+    assert L.adsb_demod_iq_device(h, C.c_void_p(t.data_ptr()), 131072, big, need, C.byref(n)) == 0 and n.value == need
+    assert bytes(big[0].msg) == bytes(out[0].msg) and bytes(big[1].msg) == bytes(out[1].msg)
+    L.adsb_destroy(h)
+    L.adsb_destroy(None)
