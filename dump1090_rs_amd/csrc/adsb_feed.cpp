@@ -14,6 +14,7 @@
 // The ICAO filter is never flushed, as in the reference's loop.  No GPU -> exits non-zero.
 #include <arpa/inet.h>
 #include <cerrno>
+#include <chrono>
 #include <csignal>
 #include <cstdio>
 #include <cstdlib>
@@ -171,6 +172,7 @@ int main(int argc, char **argv)
         return ADSB_OK;
     };
 
+    const auto t_start = std::chrono::steady_clock::now();
     bool eof = false;
     while (!eof) {
         int16_t *buf = nullptr;
@@ -197,7 +199,9 @@ int main(int argc, char **argv)
     }
     while (adsb_pending(ctx) > 0)
         if ((st = drain_one()) != ADSB_OK) return die(ctx, "adsb_collect", st);
-    std::fprintf(stderr, "adsb_feed: %llu samples, %llu frames\n", total_samples, total_frames);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::fprintf(stderr, "adsb_feed: %llu samples, %llu frames in %.3f s (%.1f Msamples/s)\n", total_samples,
+                 total_frames, secs, secs > 0 ? total_samples / secs / 1e6 : 0.0);
     if (in != stdin) std::fclose(in);
     adsb_destroy(ctx);
     return 0;

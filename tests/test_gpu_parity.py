@@ -435,7 +435,7 @@ def test_feed_tool_prints_and_serves_reference_raw_lines(hip_lib, oracle_mod, go
         err = feed.stderr.read().decode()
         assert feed.wait(timeout=120) == 0, err
         assert out.splitlines() == lines
-        assert f"{len(stream)} samples, {len(lines)} frames" in err
+        assert f"{len(stream)} samples, {len(lines)} frames in " in err
         client.settimeout(5)
         got = b""
         while True:
