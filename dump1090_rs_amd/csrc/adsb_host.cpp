@@ -33,6 +33,7 @@ struct Slot {
     // on the stream): *_dev are the device-side addresses of the same allocations
     Summary *h_sum = nullptr, *h_sum_dev = nullptr;
     TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;  // hits_cap entries
+    uint32_t hits_cap = 0;  // entries in d_hits / h_rec (the fallback's lists are larger than the slot's own)
     // device side of the slot: its own counters, AP list and hit list, so that the match /
     // records tail of this pass (tail stream) can run while the next pass's scan (scan
     // stream) fills the other slot's
@@ -80,9 +81,16 @@ struct adsb_ctx {
     // the input: each scan waits for the point `stream` had reached at submit.
     hipStream_t scan_stream[2] = {nullptr, nullptr};
     hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
-    uint64_t *d_dap = nullptr;
     uint32_t *d_tables = nullptr;
-    uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0, dap_cap = 0;
+    uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;
+    // Lists that hold the worst case of one buffer (every position sliced, five trials each), for
+    // the buffer-by-buffer fallback through the reference-shaped kernel.  58 MB, most of it pinned
+    // host memory: allocated the first time a pass overflows the normal lists -- a receiver's
+    // stream never gets there, and a process with hundreds of small contexts stays small.
+    struct Fallback {
+        uint64_t *d_hits = nullptr, *d_dap = nullptr;
+        TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;
+    } fb;
 
     Slot slot[kSlots];
     uint64_t submitted = 0, collected = 0;
@@ -202,6 +210,31 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
     }
 }
 
+int ensure_fallback(adsb_ctx *c)
+{
+    auto &fb = c->fb;
+    if (fb.h_rec_dev) return ADSB_OK;
+    if (!fb.d_hits) HIP_TRY(c, hipMalloc((void **)&fb.d_hits, (size_t)kWorstPerChunk * sizeof(uint64_t)));
+    if (!fb.d_dap) HIP_TRY(c, hipMalloc((void **)&fb.d_dap, (size_t)kWorstPerChunk * sizeof(uint64_t)));
+    if (!fb.h_rec)
+        HIP_TRY(c, hipHostMalloc((void **)&fb.h_rec, (size_t)kWorstPerChunk * sizeof(TrialRecord), hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void **)&fb.h_rec_dev, fb.h_rec, 0));
+    return ADSB_OK;
+}
+
+// `sl` with the worst-case lists in place of its own: what a one-buffer fallback pass runs on
+// (same counters, AP list, summary, events and carry as the pass it redoes).
+int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp)
+{
+    if (int rc = ensure_fallback(c)) return rc;
+    tmp = sl;
+    tmp.d_hits = c->fb.d_hits;
+    tmp.h_rec = c->fb.h_rec;
+    tmp.h_rec_dev = c->fb.h_rec_dev;
+    tmp.hits_cap = kWorstPerChunk;
+    return ADSB_OK;
+}
+
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
@@ -219,12 +252,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;
-    p.hits_cap = c->hits_cap;
+    p.hits_cap = sl.hits_cap;
     p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
     p.seg_cap = c->seg_cap;
-    p.dap = c->d_dap;
-    p.dap_cap = c->dap_cap;
+    p.dap = c->fb.d_dap;  // only the reference-shaped kernel writes it (force_simple: fallback_slot() came first)
+    p.dap_cap = c->fb.d_dap ? kWorstPerChunk : 0;
     p.tables = c->d_tables;
     p.ctr = sl.d_ctr;
     p.summary = sl.h_sum_dev;
@@ -257,7 +290,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // odd slots scan on the second stream, unless something orders consecutive passes (the
     // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
     static const bool one_scan_stream = std::getenv("ADSB_ONE_SCAN_STREAM") != nullptr;
-    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (&sl - c->slot) == 1;
+    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && &sl == &c->slot[1];
     hipStream_t ss = c->scan_stream[second ? 1 : 0];
     // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
     hipEvent_t ready = input_done;
@@ -290,7 +323,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (p.clean_bitmap && fast) {
         // this pass's records kernel clears the bitmap the previous passes matched against: not
         // before the pass still in flight (whichever stream its tail is on) is through with it
-        Slot &other = c->slot[1 - (&sl - c->slot)];
+        Slot &other = c->slot[&sl == &c->slot[1] ? 0 : 1];
         if (other.busy) HIP_TRY(c, hipStreamWaitEvent(ts, other.done, 0));
     }
     if (!inline_tail) {
@@ -356,17 +389,21 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         st.retries++;
         for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
-        Slot tmp = sl;
-        rc = enqueue_pass(c, tmp, sl.src, true, sl.n_samples, 1, false, false, false, true);
+        const bool keep_flush = c->flush_pending;
+        c->flush_pending = false;
+        Slot tmp;
+        rc = fallback_slot(c, sl, tmp);
+        if (rc == 0) rc = enqueue_pass(c, tmp, sl.src, true, sl.n_samples, 1, false, false, false, true);
         if (rc == 0) rc = finish_pass(c, tmp, 0, st, out);
+        c->flush_pending = keep_flush;
     } else if (rc > 0) {
         st.retries++;
         for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
         const bool keep_flush = c->flush_pending;
         c->flush_pending = false;
-        Slot tmp = sl;  // same host buffers and events, one chunk at a time
-        rc = 0;
+        Slot tmp;  // same counters, summary and events; one chunk at a time into the worst-case lists
+        rc = fallback_slot(c, sl, tmp);
         for (uint64_t ch = 0; ch < sl.n_chunks && rc == 0; ch++) {
             const uint64_t off = ch * kChunkSamples;
             const uint64_t n = std::min<uint64_t>(kChunkSamples, sl.n_samples - off);
@@ -500,8 +537,9 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     const uint64_t used_segs = 4 * std::min<uint64_t>(kApSegments, max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
     c->seg_cap = (uint32_t)std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + used_segs - 1) / used_segs);
     c->ap_cap = (uint32_t)(used_segs * c->seg_cap);
-    c->dap_cap = kWorstPerChunk;
-    c->hits_cap = (uint32_t)std::min<uint64_t>(kWorstPerChunk + max_chunks * 1024, 0xFFFFFFF0u);
+    // hit list: ~5x what a busy airspace produces (a frame leaves 3-4 trial records; 1000 frames/s
+    // are ~55 per buffer); more than that is the fallback's business too
+    c->hits_cap = (uint32_t)(4096 + max_chunks * 1024);
 
     int rc = ADSB_OK;
     auto body = [&]() -> int {
@@ -527,6 +565,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapAllocWords * sizeof(uint32_t)));
         for (Slot &sl : c->slot) {
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
+            sl.hits_cap = c->hits_cap;
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipEventCreateWithFlags(&sl.scanned, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -535,7 +574,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         HIP_TRY(c, hipMalloc((void **)&c->d_carry_next, kCarrySamples * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_dap, (size_t)c->dap_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
             std::vector<uint32_t> tab = build_gf_tables();
@@ -613,7 +651,9 @@ void adsb_destroy(adsb_ctx *c)
         (void)hipStreamSynchronize(c->tail_stream);
         (void)hipStreamDestroy(c->tail_stream);
     }
-    if (c->d_dap) (void)hipFree(c->d_dap);
+    if (c->fb.d_hits) (void)hipFree(c->fb.d_hits);
+    if (c->fb.d_dap) (void)hipFree(c->fb.d_dap);
+    if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &r : c->ring) {
         if (r.copied) (void)hipEventDestroy(r.copied);
@@ -909,16 +949,21 @@ namespace {
 
 // One 131072-sample buffer of a parked shard through the reference-shaped kernel, whose lists
 // hold the worst case of a buffer: scan (+ match) + records, synchronously.  The records land
-// in the slot's host buffer with chunk = 0; *n_out = how many.
+// in the fallback's host buffer (c->fb.h_rec) with chunk = 0; *n_out = how many.
 int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, uint32_t *clean, size_t *n_out)
 {
     Slot &sl = c->slot[0];
+    if (int rc = ensure_fallback(c)) return rc;
     const uint64_t off = ch * kChunkSamples;
     p.src = (const uint32_t *)p.src + off;
     p.n_samples = std::min<uint64_t>(kChunkSamples, p.n_samples - off);
     p.n_chunks = 1;
     p.keep_counters = 0;
     p.clean_bitmap = clean;
+    p.hits = c->fb.d_hits;
+    p.hits_cap = kWorstPerChunk;
+    p.dap = c->fb.d_dap;
+    p.dap_cap = kWorstPerChunk;
     sl.seq = c->next_seq++;
     if (c->next_seq == 0) c->next_seq = 1;
     sl.h_sum->seq = 0;
@@ -926,7 +971,7 @@ int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, ui
     if (int e = launch_scan_simple(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan_simple");
     if (with_match)
         if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
-    if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+    if (int e = launch_records(p, false, c->fb.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq || sl.h_sum->overflow) {
         c->last_error = "shard: a single buffer overflowed the worst-case lists";
@@ -973,12 +1018,12 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;
-    p.hits_cap = c->hits_cap;
+    p.hits_cap = sl.hits_cap;
     p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
     p.seg_cap = c->seg_cap;
-    p.dap = c->d_dap;
-    p.dap_cap = c->dap_cap;
+    p.dap = nullptr;  // the reference-shaped kernel's list: shard_chunk_pass() fills it in
+    p.dap_cap = 0;
     p.tables = c->d_tables;
     p.ctr = sl.d_ctr;
     p.summary = sl.h_sum_dev;
@@ -1012,7 +1057,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
         for (uint64_t ch = 0; ch < n_chunks; ch++) {
             size_t k = 0;
             if (int rc = shard_chunk_pass(c, p, ch, false, nullptr, &k)) return rc;
-            learned_addresses(c, sl.h_rec, k, addrs);
+            learned_addresses(c, c->fb.h_rec, k, addrs);
         }
     } else {
         learned_addresses(c, sl.h_rec, n_hits, addrs);
@@ -1052,8 +1097,31 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
         if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, c->stream))
             return fail(c, (hipError_t)e, "launch_set_addresses");
     }
-    if (c->shard_by_chunk) {
-        c->shard_by_chunk = false;
+    bool by_chunk = c->shard_by_chunk;
+    c->shard_by_chunk = false;
+    size_t n = 0;
+    if (!by_chunk && p.n_chunks) {
+        sl.seq = c->next_seq++;
+        if (c->next_seq == 0) c->next_seq = 1;
+        sl.h_sum->seq = 0;
+        p.seq = sl.seq;
+        if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
+        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
+            c->last_error = "shard finish completed without publishing its summary";
+            return ADSB_ERR_HIP;
+        }
+        // the matched address/parity trials did not fit the hit list (a large union of addresses
+        // over a dense shard): buffer by buffer, like a shard whose scan overflowed.  (The
+        // records kernel has zeroed the counters and cleaned the retired bitmap on its way out.)
+        if (sl.h_sum->overflow) {
+            by_chunk = true;
+            p.clean_bitmap = nullptr;
+        }
+        n = sl.h_sum->n_hits;
+    }
+    if (by_chunk) {
         std::vector<TrialRecord> all;
         uint64_t cand = 0, ap = 0;
         for (uint64_t ch = 0; ch < p.n_chunks; ch++) {
@@ -1061,7 +1129,7 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
             uint32_t *clean = ch + 1 == p.n_chunks ? p.clean_bitmap : nullptr;
             if (int rc = shard_chunk_pass(c, p, ch, true, clean, &k)) return rc;
             for (size_t i = 0; i < k; i++) {
-                TrialRecord r = sl.h_rec[i];
+                TrialRecord r = c->fb.h_rec[i];
                 r.chunk = (uint32_t)ch;
                 all.push_back(r);
             }
@@ -1080,25 +1148,6 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
         const size_t k = std::min(cap, all.size());
         if (k) std::memcpy(records_out, all.data(), k * sizeof(adsb_trial));
         return all.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-    }
-    sl.seq = c->next_seq++;
-    if (c->next_seq == 0) c->next_seq = 1;
-    sl.h_sum->seq = 0;
-    p.seq = sl.seq;
-    size_t n = 0;
-    if (p.n_chunks) {
-        if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
-        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
-            c->last_error = "shard finish completed without publishing its summary";
-            return ADSB_ERR_HIP;
-        }
-        if (sl.h_sum->overflow) {
-            c->last_error = "shard too dense for the device lists: use smaller shards";
-            return ADSB_ERR_HIP;
-        }
-        n = sl.h_sum->n_hits;
     }
     adsb_stats st{};
     st.n_samples = p.n_samples;

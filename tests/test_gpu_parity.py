@@ -399,6 +399,32 @@ def test_sharded_capture_two_phases_equal_single_stream(hip_lib, oracle_mod):
             c.close()
 
 
+def test_shard_finish_with_a_huge_address_union_overflows_into_the_exact_fallback(hip_lib, oracle_mod):
+    """Three quarters of the 24-bit address space handed to adsb_shard_finish: most of the
+    shard's address/parity trials now match the superset bitmap, far more than the hit list
+    holds, so the finish goes buffer by buffer through the worst-case lists (allocated on this
+    first use).  The replay through the real filter still gives the single-stream result."""
+    import torch
+    from dump1090_rs_amd import Context
+    from dump1090_rs_amd.context import replay_records
+
+    n = 4 * 131072 - 4321
+    iq = synth.make_iq(n, n_bursts=40, seed=99)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    dev = torch.from_numpy(iq).cuda()
+    rng = np.random.default_rng(3)
+    union = np.flatnonzero(rng.random(1 << 24) < 0.75).astype(np.uint32)
+    with Context(0, 4) as c:
+        c.icao_flush()
+        c.shard_scan(dev.data_ptr(), n)
+        records = c.shard_finish(union)
+        assert c.stats()["retries"] == 1 and len(records) > 4096 + 4 * 1024
+        assert_same(replay_records(records), want)
+        # the context is as good as new afterwards
+        c.icao_flush()
+        assert_same(c.demod_iq_device(dev.data_ptr(), n), want)
+
+
 def test_feed_tool_prints_and_serves_reference_raw_lines(hip_lib, oracle_mod, golden, fixture_iq):
     """adsb_feed = the loop of dump1090_rs/src/main.rs:154-201 over a pipe: the three reference
     captures back to back on stdin (file order, im first) -> "*hex;" lines on stdout and on a
