@@ -81,7 +81,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--max-chunks", type=int, default=8, help="captures of 1..N buffers (ring slots stay 2 buffers)")
+    ap.add_argument("--max-chunks", type=int, default=8, help="captures of 1..N buffers (ring slots: min(2, N) buffers)")
     ap.add_argument("--only", type=int, default=-1, help="replay just this case of the seed")
     ap.add_argument("--api", default="", help="with --only: force this entry point")
     ap.add_argument("--ringcuts", action="store_true", help="with --only: cut every 2 buffers, as the ring does")
@@ -94,7 +94,8 @@ def main():
 
     rng = np.random.default_rng(args.seed)
     ctx = Context(0, args.max_chunks)
-    ctx.ring_create(2 * CHUNK)
+    ring_chunks = min(2, args.max_chunks)
+    ctx.ring_create(ring_chunks * CHUNK)
     shard_ctx = [Context(0, args.max_chunks), Context(0, args.max_chunks)]
     t0 = time.time()
     modes = {}
@@ -115,7 +116,7 @@ def main():
         # cut the stream into 1-3 calls (filter and carry persist across them)
         cuts = sorted(set([0, n] + [int(x) // 4 * 4 for x in cut_draw]))
         if args.ringcuts:
-            cuts = list(range(0, n, 2 * CHUNK)) + [n]
+            cuts = list(range(0, n, ring_chunks * CHUNK)) + [n]
         orc = binding.Oracle()
         carry = np.zeros((326, 2), np.int16)
         wants = []
@@ -143,8 +144,8 @@ def main():
                 gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
                 pend -= 1
         elif api == "ring":
-            # the ring takes at most 2 buffers per slot: cut accordingly (oracle redone to match)
-            cuts = list(range(0, n, 2 * CHUNK)) + [n]
+            # the ring takes at most ring_chunks buffers per slot: cut accordingly (oracle redone to match)
+            cuts = list(range(0, n, ring_chunks * CHUNK)) + [n]
             orc = binding.Oracle()
             carry = np.zeros((326, 2), np.int16)
             wants = []
