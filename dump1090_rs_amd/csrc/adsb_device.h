@@ -63,7 +63,7 @@ static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 // counter saturates near 90 atomics/us on this chip, and even an LDS counter is a round
 // trip per trial pass).  The simple kernel appends to a second list, `dap`, through one
 // shared counter: it is the slow path anyway.
-constexpr int kApSegments = 1024;
+constexpr int kApSegments = 1280;
 constexpr int kApWaveSegs = 4 * kApSegments;  // one per wave of a persistent workgroup
 
 // Device counters block (one per context).
@@ -139,6 +139,7 @@ int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
 // set); only needed once per context: afterwards every pass cleans up for the next one
 int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream);
 int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
+int scan_resident_blocks();  // workgroups of the fast scan's persistent grid (<= kApSegments)
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);

@@ -529,12 +529,13 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     if (const char *ds = std::getenv("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     if (const char *st = std::getenv("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
     // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
-    // of n buffers runs min(17 n, 1024) workgroups of four waves, so a small context only gets
+    // of n buffers runs min(17 n, resident grid) workgroups of four waves, so a small context only gets
     // the segments it can ever use), each sized for ~5x the rate pure noise produces (2.3 % of
     // samples become address/parity entries).  Denser input falls back to buffer-by-buffer
     // passes through the reference-shaped kernel, whose list (dap) and the hit list hold one
     // buffer's worst case: every position sliced, five trials each.
-    const uint64_t used_segs = 4 * std::min<uint64_t>(kApSegments, max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
+    (void)hipSetDevice(device);  // scan_resident_blocks() asks the current device
+    const uint64_t used_segs = 4 * std::min<uint64_t>((uint64_t)scan_resident_blocks(), max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
     c->seg_cap = (uint32_t)std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + used_segs - 1) / used_segs);
     c->ap_cap = (uint32_t)(used_segs * c->seg_cap);
     // hit list: ~5x what a busy airspace produces (a frame leaves 3-4 trial records; 1000 frames/s
@@ -555,9 +556,17 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             // (Which of the three levels each stream gets made no measurable difference.)
             int least = 0, greatest = 0;
             HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, least));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, (least + greatest) / 2));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, greatest));
+            int pt = least, p0 = (least + greatest) / 2, p1 = greatest;
+            if (const char *e = std::getenv("ADSB_STREAM_PRIO")) {  // measurement aid: "tail,scan0,scan1" as 0 (least) .. 2
+                int a = 0, b = 1, d = 2;
+                if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
+                    const int lv[3] = {least, (least + greatest) / 2, greatest};
+                    pt = lv[a % 3], p0 = lv[b % 3], p1 = lv[d % 3];
+                }
+            }
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, pt));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, p0));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, p1));
             if (std::getenv("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
         }
         for (auto &e : c->input_ready)

@@ -59,15 +59,21 @@ using namespace fastgeo;
 #define ADSB_SCAN_THREADS 256
 #endif
 constexpr int kThreads = ADSB_SCAN_THREADS;   // 256 (512 was measured: 7 % slower)
-constexpr int kWavesPerSimd = kThreads == 512 ? 8 : 4;
-constexpr int kResPerItem = kThreads == 512 ? 2 : 4;  // residues one P2 lane walks
+#ifndef ADSB_SCAN_OCC
+#define ADSB_SCAN_OCC 4
+#endif
+#ifndef ADSB_SCAN_RES
+#define ADSB_SCAN_RES 4
+#endif
+constexpr int kWavesPerSimd = kThreads == 512 ? 8 : ADSB_SCAN_OCC;  // = workgroups per CU
+constexpr int kResPerItem = kThreads == 512 ? 2 : ADSB_SCAN_RES;  // residues one P2 lane walks
 constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
 constexpr int kPlaneGT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
 constexpr int kPlanes = 84;                   // 60..83: GT ("m[s] > m[s+1]") residues 0..23
                                               //   (residue r+12 = residue r advanced one bit)
 constexpr int kItems2 = (12 / kResPerItem) * kPlaneBytes;  // P2 items: (residue group, plane byte)
 constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
-static_assert(kItems2 <= kThreads && kItems3 <= 256, "one item per thread");
+static_assert(kItems3 <= 256, "one P3 item per thread");
 static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
 constexpr int kWaves = kThreads / 64;
 constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
@@ -145,8 +151,8 @@ struct alignas(16) FastLds {
     uint32_t tab[3 * 256];             // F'0 F'1 F'2 (adsb_tables.h)
     uint32_t r16[16];                  // x^24..x^27 reduction
     uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
-    uint32_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
-    uint32_t cand[kWaves * kCandPerWave];  // per wave: slot | slot/12 << 13 | slot%12 << 23
+    uint16_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
+    uint16_t cand[kWaves * kCandPerWave];  // per wave: slot (cand_entry() expands it for the trial stage)
     uint64_t hit[kHitCap];
     uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
 };
@@ -372,7 +378,7 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
 // A lane writes its own matches (bits of m; the branch 0..4 of each from the three code planes)
 // into the wave's pattern region from index `at` on: slot | branch << 13.
 __device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint32_t code1, uint32_t code2,
-                                                uint32_t slot0, uint32_t *wpat, uint32_t at)
+                                                uint32_t slot0, uint16_t *wpat, uint32_t at)
 {
     while (m) {
         const uint32_t bit = (uint32_t)__ffs(m) - 1u;
@@ -382,19 +388,19 @@ __device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint
         uint32_t k = __builtin_amdgcn_ubfe(code0, bit, 1u);
         k |= __builtin_amdgcn_ubfe(code1, bit, 1u) << 1;
         k |= __builtin_amdgcn_ubfe(code2, bit, 1u) << 2;
-        wpat[at++] = (slot0 + 12u * bit) | (k << 13);
+        wpat[at++] = (uint16_t)((slot0 + 12u * bit) | (k << 13));
     }
 }
 
 // One 64-lane pass of the gates: `ent` is this lane's pattern match (valid lanes only count),
 // passing positions are appended to the wave's candidate region.
-__device__ __forceinline__ void gate_pass(const FastLds &s, uint32_t ent, bool valid, uint32_t *wcand,
+__device__ __forceinline__ void gate_pass(const FastLds &s, uint32_t ent, bool valid, uint16_t *wcand,
                                           uint32_t &ncand_w)
 {
     const bool pass = (gate_eval(s.mag, ent) & (uint32_t)valid) != 0;
     const unsigned long long mask = __ballot(pass);
     if (mask) {
-        if (pass) wcand[mask_rank(mask, ncand_w)] = cand_entry(ent & 0x1FFFu);
+        if (pass) wcand[mask_rank(mask, ncand_w)] = (uint16_t)(ent & 0x1FFFu);
         ncand_w += (uint32_t)__popcll(mask);
     }
 }
@@ -533,9 +539,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     // item = (g, kw): residues 4g..4g+3, plane bits k = 8kw..8kw+7, i.e. samples
     // 12k + 4g + {0..3} (+3 of look-ahead).  Bit k of plane (kind, r) is the sign taken
     // at sample 12k + r.  Walking k downwards leaves bit (k & 7) of the byte = k.
-    if (tid < kItems2) {
+    for (int item = tid; item < kItems2; item += kThreads) {
         constexpr int R = kResPerItem, G = 12 / R;
-        const int g = tid % G, kw = tid / G;
+        const int g = item % G, kw = item / G;
         const uint16_t *base = s.mag + 96 * kw + R * g;  // 4-byte aligned (R even)
         uint32_t acc[6][R];
 #pragma unroll
@@ -624,8 +630,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     // the trial stage whenever their region fills.
     {
     const int wave = tid >> 6;
-    uint32_t *const wpat = s.pat + wave * kPatPerWave;
-    uint32_t *const wcand = s.cand + wave * kCandPerWave;
+    uint16_t *const wpat = s.pat + wave * kPatPerWave;
+    uint16_t *const wcand = s.cand + wave * kCandPerWave;
 
     // ---------------------------------------------------------------- P3 preamble patterns
     // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 const uint32_t t5 = tb + (uint32_t)lane;
                 uint32_t c, tpi;
                 split5(min(t5, ntrial - 1u), c, tpi);
-                trial_pass(p, s, wcand[c], tpi, t5 < ntrial, jbase, chunk, seg, seg_cap, ap_count, lane, par);
+                trial_pass(p, s, cand_entry(wcand[c]), tpi, t5 < ntrial, jbase, chunk, seg, seg_cap, ap_count, lane, par);
             }
             wave_lds_fence();  // wcand is reused by the next passes of the gates
         }
@@ -792,12 +798,9 @@ inline void hip_clear() { (void)hipGetLastError(); }
 
 }  // namespace
 
-int launch_scan(const ScanParams &p, bool from_mag, void *stream)
+// persistent grid = what is resident at once (occupancy API x CUs), found once
+int scan_resident_blocks()
 {
-    hip_clear();
-    const uint32_t tiles = p.n_chunks * kTilesPerChunk;
-    if (tiles == 0) return 0;
-    // persistent grid = what is resident at once (occupancy API x CUs), found once
     static int resident = 0;
     if (resident == 0) {
         int dev = 0, per_cu = 0, cus = 0;
@@ -815,6 +818,15 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
         if (std::getenv("ADSB_TIMELINE"))
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
     }
+    return resident;
+}
+
+int launch_scan(const ScanParams &p, bool from_mag, void *stream)
+{
+    hip_clear();
+    const uint32_t tiles = p.n_chunks * kTilesPerChunk;
+    if (tiles == 0) return 0;
+    const int resident = scan_resident_blocks();
     const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
     // With events, the launch itself carries them (hipExtLaunchKernelGGL): the dispatch
     // packet's own begin/end timestamps, no barrier packets in the stream around it.
