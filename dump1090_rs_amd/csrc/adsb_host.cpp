@@ -1231,6 +1231,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.6 gfx950 scan=v5-le-planes"; }
+const char *adsb_version(void) { return "adsb_hip 0.7 gfx950 scan=v5-le-planes-xcd"; }
 
 }  // extern "C"

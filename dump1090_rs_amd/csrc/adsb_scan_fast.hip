@@ -490,7 +490,18 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this wave
 
     uint4 pre[kLoadsPerThread];
-    if (blockIdx.x < n_tiles) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, blockIdx.x), tid, pre);
+    // Which tiles this workgroup walks.  Blocks b, b + 8, b + 16, ... run on the same XCD (observed
+    // placement, used for speed only), so each XCD gets one contiguous eighth of the tiles and its
+    // blocks walk it side by side: the 368 samples two neighbouring tiles share are then read from
+    // HBM once and found in that XCD's L2 by the neighbour.  Any other grid: plain round robin.
+    uint32_t t_first = blockIdx.x, t_end = n_tiles, t_stride = gridDim.x;
+    if ((gridDim.x & 7u) == 0 && n_tiles >= gridDim.x) {
+        const uint32_t x = blockIdx.x & 7u;
+        t_first = ((x * n_tiles) >> 3) + (blockIdx.x >> 3);
+        t_end = ((x + 1u) * n_tiles) >> 3;
+        t_stride = gridDim.x >> 3;
+    }
+    if (t_first < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t_first), tid, pre);
 
     // Workgroups that share a CU start a fraction of a tile period apart, so that the
     // VALU-dense phases of one overlap the latency-bound phases of the others instead of
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
 #endif
 
     uint32_t iter = 0;
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x, iter++) {
+    for (uint32_t t = t_first; t < t_end; t += t_stride, iter++) {
     const TileRef cur = tile_ref<FROM_MAG>(p, t);
     STAMP(0);
     const uint32_t chunk = cur.chunk;
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
         const int g = tid + i * kThreads;
         if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = FROM_MAG ? make_uint2(pre[i].x, pre[i].y) : mag4_of(pre[i]);
     }
-    if (t + gridDim.x < n_tiles) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t + gridDim.x), tid, pre);
+    if (t + t_stride < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t + t_stride), tid, pre);
     ACCT(0);
     lds_barrier();
     // every thread is past the previous tile's epilogue: its counters can be zeroed for the next
