@@ -812,8 +812,8 @@ inline void hip_clear() { (void)hipGetLastError(); }
 // persistent grid = what is resident at once (occupancy API x CUs), found once
 int scan_resident_blocks()
 {
-    static int resident = 0;
-    if (resident == 0) {
+    // (a function-local static: initialised once, also when two threads create contexts at once)
+    static const int resident = [] {
         int dev = 0, per_cu = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast<false>, kThreads, 0) != hipSuccess ||
@@ -822,13 +822,14 @@ int scan_resident_blocks()
             per_cu = 2;
             cus = 256;
         }
-        resident = per_cu * cus;
-        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) resident = std::atoi(e) * cus;
-        if (resident > kApSegments) resident = kApSegments;  // four private AP segments (one per wave) each
-        if (resident < 1) resident = 1;
+        int r = per_cu * cus;
+        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) r = std::atoi(e) * cus;
+        if (r > kApSegments) r = kApSegments;  // four private AP segments (one per wave) each
+        if (r < 1) r = 1;
         if (std::getenv("ADSB_TIMELINE"))
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
-    }
+        return r;
+    }();
     return resident;
 }
 
