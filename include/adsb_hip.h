@@ -91,7 +91,11 @@ typedef struct {
 
 /* Create a context on HIP device `device` (>= 0), sized to demodulate up to
  * `max_chunks` 131072-sample buffers per call (host-pointer calls stage through
- * a device buffer of that size; device-pointer calls only size the lists). */
+ * a device buffer of that size; device-pointer calls only size the lists).
+ * Device memory: ~7.5 MB for max_chunks = 1 (three 2 MiB address bitmaps and the
+ * lists of two passes in flight), ~150 MB for 512; input denser than the lists are
+ * sized for (several times a busy airspace) is still demodulated exactly, buffer
+ * by buffer through worst-case lists allocated on first use (stats.retries). */
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks);
 void adsb_destroy(adsb_ctx *ctx);
 
