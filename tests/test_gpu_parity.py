@@ -182,6 +182,23 @@ def test_sparse_synthetic_64_chunks(ctx, oracle_mod):
     assert len(want) >= 60
 
 
+@pytest.mark.parametrize("n_chunks,cut", [(75, 4321), (61, 0), (131, 77777)])
+def test_tile_order_covers_every_tile_when_counts_do_not_divide(hip_lib, oracle_mod, n_chunks, cut):
+    """Passes with at least as many tiles as the persistent grid has workgroups walk the tiles in
+    XCD-aware order (eight contiguous ranges, floor(x * tiles / 8) boundaries): buffer counts that
+    are not multiples of 8, a ragged last buffer, a burst in every buffer -- every frame must come
+    out once, in order."""
+    from dump1090_rs_amd import Context
+    n = n_chunks * 131072 - cut
+    iq = synth.make_iq(n, n_bursts=2 * n_chunks, seed=1000 + n_chunks)
+    want, st = oracle_mod.Oracle().demod_iq(iq, threads=8)
+    with Context(0, n_chunks) as c:
+        c.icao_flush()
+        assert_same(c.demod_iq(iq), want)
+        assert c.stats()["n_candidates"] == st.quiet_pass and c.stats()["retries"] == 0
+    assert len({w["chunk"] for w in want}) > n_chunks * 0.8
+
+
 def test_dense_synthetic_all_message_kinds(ctx, oracle_mod):
     """~40 bursts per chunk from 7 addresses, every 3rd a DF11: 750/1000/1400/1600/1800
     transitions and address/parity matches all occur."""
