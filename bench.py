@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- headline benchmark of the demod_2400 hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sparse|dense]

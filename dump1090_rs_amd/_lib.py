@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
     L.adsb_submit_iq_device.argtypes = [vp, vp, sz]
     L.adsb_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_pending.argtypes = [vp]
+    L.adsb_fetch_messages.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_ring_create.argtypes = [vp, sz]
     L.adsb_ring_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.adsb_ring_submit.argtypes = [vp, sz]
@@ -121,6 +122,7 @@ def lib() -> C.CDLL:
                  "adsb_to_mag", "adsb_demodulate2400", "adsb_demod_iq", "adsb_demod_iq_device",
                  "adsb_read_test_data", "adsb_get_stats", "adsb_replay_records",
                  "adsb_selftest_mag_digest", "adsb_submit_iq_device", "adsb_collect", "adsb_pending",
+                 "adsb_fetch_messages",
                  "adsb_ring_create", "adsb_ring_acquire", "adsb_ring_submit", "adsb_shard_scan",
                  "adsb_shard_finish"):
         getattr(L, name).restype = C.c_int

@@ -138,18 +138,20 @@ class Context:
         return out
 
     def _collect(self, call, what: str, cap: int) -> List[ModeSMessage]:
-        while True:
+        buf = (AdsbMsg * cap)()
+        n = C.c_size_t()
+        st = call(buf, cap, C.byref(n))
+        if st == _lib.ADSB_ERR_CAPACITY:
+            # the pass is consumed (the filter has advanced): never repeat the call, fetch its list
+            cap = n.value
             buf = (AdsbMsg * cap)()
-            n = C.c_size_t()
-            st = call(buf, cap, C.byref(n))
-            if st == _lib.ADSB_ERR_CAPACITY:
-                raise AdsbError(st, f"{what}: output of {n.value} messages exceeds cap {cap}")
-            self._check(st, what)
-            return [
-                ModeSMessage(bytes(m.msg), int(m.len), float(m.signal_level), int(m.score),
-                             int(m.j), int(m.try_phase), int(m.chunk))
-                for m in buf[: n.value]
-            ]
+            st = self._L.adsb_fetch_messages(self._h, buf, cap, C.byref(n))
+        self._check(st, what)
+        return [
+            ModeSMessage(bytes(m.msg), int(m.len), float(m.signal_level), int(m.score),
+                         int(m.j), int(m.try_phase), int(m.chunk))
+            for m in buf[: n.value]
+        ]
 
     def demodulate2400(self, mag: MagnitudeBuffer, cap: int = 4096) -> List[ModeSMessage]:
         data = np.ascontiguousarray(mag.data, dtype=np.uint16)

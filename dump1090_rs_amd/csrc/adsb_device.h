@@ -19,7 +19,32 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
+// Measurement switches (tools/*.sh: ADSB_DEBUG_STOP, ADSB_STAGGER, ADSB_SCAN_BLOCKS_PER_CU,
+// ADSB_STREAM_PRIO, ADSB_NO_EXT_EVENTS, ADSB_ONE_SCAN_STREAM, ADSB_DONE_FENCE, ADSB_TIMELINE) exist
+// only in a library built with -DADSB_TUNING (-DADSB_KERNEL_ACCT implies it): the release build
+// reads nothing from the environment, so no stray variable can change what it computes.
+#if defined(ADSB_KERNEL_ACCT) && !defined(ADSB_TUNING)
+#define ADSB_TUNING 1
+#endif
+#ifdef ADSB_TUNING
+#define ADSB_STOP_AT(p, n) ((p).debug_stop == (n))
+#else
+#define ADSB_STOP_AT(p, n) false
+#endif
+
 namespace adsb {
+
+inline const char *tuning_env(const char *name)
+{
+#ifdef ADSB_TUNING
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 constexpr int kChunkSamples = 131072;  // MODES_MAG_BUF_SAMPLES, src/lib.rs:22
 constexpr int kLead = 326;             // TRAILING_SAMPLES, src/lib.rs:24

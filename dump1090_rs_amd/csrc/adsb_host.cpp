@@ -121,6 +121,10 @@ struct adsb_ctx {
     Crc24 crc;
     adsb_stats stats{};
     std::string last_error;
+    // the messages of a call whose `out` was too small (ADSB_ERR_CAPACITY): the pass is consumed
+    // and the filter has moved on, so they are kept for adsb_fetch_messages
+    std::vector<adsb_msg> undelivered;
+    bool has_undelivered = false;
 };
 
 namespace {
@@ -217,7 +221,7 @@ int ensure_fallback(adsb_ctx *c)
     if (!fb.d_hits) HIP_TRY(c, hipMalloc((void **)&fb.d_hits, (size_t)kWorstPerChunk * sizeof(uint64_t)));
     if (!fb.d_dap) HIP_TRY(c, hipMalloc((void **)&fb.d_dap, (size_t)kWorstPerChunk * sizeof(uint64_t)));
     if (!fb.h_rec)
-        HIP_TRY(c, hipHostMalloc((void **)&fb.h_rec, (size_t)kWorstPerChunk * sizeof(TrialRecord), hipHostMallocMapped));
+        HIP_TRY(c, hipHostMalloc((void **)&fb.h_rec, (size_t)kWorstPerChunk * sizeof(TrialRecord), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(c, hipHostGetDevicePointer((void **)&fb.h_rec_dev, fb.h_rec, 0));
     return ADSB_OK;
 }
@@ -280,7 +284,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.seq = sl.seq;
     // level 1: the scan launch stamps its own begin/end (no extra packets on the stream);
     // level 2: classic event records between all kernels
-    static const bool ext_events = !std::getenv("ADSB_NO_EXT_EVENTS");
+    static const bool ext_events = !tuning_env("ADSB_NO_EXT_EVENTS");
     const bool fast = !from_mag && !force_simple;
     p.ev_start = ext_events && prof == 1 && fast ? sl.ev[0] : nullptr;
     p.ev_stop = ext_events && prof == 1 && fast ? sl.ev[1] : nullptr;
@@ -289,7 +293,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     const bool classic = prof > 1 || (prof == 1 && (!fast || !ext_events));
     // odd slots scan on the second stream, unless something orders consecutive passes (the
     // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
-    static const bool one_scan_stream = std::getenv("ADSB_ONE_SCAN_STREAM") != nullptr;
+    static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
     const bool second = fast && !p.carry && advance_carry && !one_scan_stream && &sl == &c->slot[1];
     hipStream_t ss = c->scan_stream[second ? 1 : 0];
     // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
@@ -373,6 +377,30 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     return 0;
 }
 
+// The overflow fallback re-runs a pass against the bitmap in use NOW.  Passes submitted after the
+// overflowed one may have rotated the bitmaps (an icao_flush in between) and the retired one has been
+// cleared, so the addresses the filter held before this pass would be missing from the superset:
+// put them back.  At this point the host filter is exactly the state that preceded the pass (later
+// passes have not been replayed yet), and extra bits only widen the superset for later passes.
+int reseed_bitmap_from_filter(adsb_ctx *c)
+{
+    std::vector<uint32_t> addrs;
+    for (uint32_t a : c->filter.table())
+        if (a != 0 && a <= 0xFFFFFFu) addrs.push_back(a);  // DF18 entries (addr | 1 << 25) match no 24-bit residual
+    if (addrs.empty()) return ADSB_OK;
+    if (addrs.size() > c->addrs_cap) {
+        if (c->d_addrs) (void)hipFree(c->d_addrs);
+        c->d_addrs = nullptr;
+        c->addrs_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_addrs, IcaoFilter::kSize * sizeof(uint32_t)));
+        c->addrs_cap = IcaoFilter::kSize;
+    }
+    HIP_TRY(c, hipMemcpy(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->d_bitmap[c->cur_bitmap], c->scan_stream[0]))
+        return fail(c, (hipError_t)e, "launch_set_addresses");
+    return ADSB_OK;
+}
+
 // Finish the oldest submission: replay it, or -- when a device list overflowed (far
 // denser input than the lists were sized for) -- drain the stream and go chunk by
 // chunk, where the worst case always fits.  Bitmap bits set by the aborted pass or by
@@ -393,6 +421,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         c->flush_pending = false;
         Slot tmp;
         rc = fallback_slot(c, sl, tmp);
+        if (rc == 0) rc = reseed_bitmap_from_filter(c);
         if (rc == 0) rc = enqueue_pass(c, tmp, sl.src, true, sl.n_samples, 1, false, false, false, true);
         if (rc == 0) rc = finish_pass(c, tmp, 0, st, out);
         c->flush_pending = keep_flush;
@@ -404,6 +433,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         c->flush_pending = false;
         Slot tmp;  // same counters, summary and events; one chunk at a time into the worst-case lists
         rc = fallback_slot(c, sl, tmp);
+        if (rc == 0) rc = reseed_bitmap_from_filter(c);
         for (uint64_t ch = 0; ch < sl.n_chunks && rc == 0; ch++) {
             const uint64_t off = ch * kChunkSamples;
             const uint64_t n = std::min<uint64_t>(kChunkSamples, sl.n_samples - off);
@@ -487,14 +517,20 @@ int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<
     return ADSB_OK;
 }
 
-int deliver(adsb_ctx *c, const std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap,
+int deliver(adsb_ctx *c, std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap,
             size_t *n_out)
 {
     c->stats.n_messages = msgs.size();
     const size_t n = std::min(cap, msgs.size());
     if (n && out) std::memcpy(out, msgs.data(), n * sizeof(adsb_msg));
     if (n_out) *n_out = msgs.size();
-    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+    c->has_undelivered = msgs.size() > cap;
+    if (!c->has_undelivered) {
+        c->undelivered.clear();
+        return ADSB_OK;
+    }
+    c->undelivered.swap(msgs);  // the pass is consumed: keep what it produced (adsb_fetch_messages)
+    return ADSB_ERR_CAPACITY;
 }
 
 int ensure_stage(adsb_ctx *c, size_t bytes)
@@ -526,8 +562,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     if (!c) return ADSB_ERR_NOMEM;
     c->device = device;
     c->max_chunks = max_chunks;
-    if (const char *ds = std::getenv("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
-    if (const char *st = std::getenv("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
+    if (const char *ds = tuning_env("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
+    if (const char *st = tuning_env("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
     // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
     // of n buffers runs min(17 n, resident grid) workgroups of four waves, so a small context only gets
     // the segments it can ever use), each sized for ~5x the rate pure noise produces (2.3 % of
@@ -557,7 +593,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             int least = 0, greatest = 0;
             HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
             int pt = least, p0 = (least + greatest) / 2, p1 = greatest;
-            if (const char *e = std::getenv("ADSB_STREAM_PRIO")) {  // measurement aid: "tail,scan0,scan1" as 0 (least) .. 2
+            if (const char *e = tuning_env("ADSB_STREAM_PRIO")) {  // measurement aid: "tail,scan0,scan1" as 0 (least) .. 2
                 int a = 0, b = 1, d = 2;
                 if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
                     const int lv[3] = {least, (least + greatest) / 2, greatest};
@@ -567,7 +603,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, pt));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, p0));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, p1));
-            if (std::getenv("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
+            if (tuning_env("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
         }
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -595,16 +631,19 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                                  hipMemcpyHostToDevice));
         }
         for (Slot &sl : c->slot) {
-            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocMapped));
+            // (mapped + coherent: the records kernel's write-through stores are visible to the host
+            // when its completion event fires, whatever the runtime's default for pinned memory)
+            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocMapped | hipHostMallocCoherent));
             HIP_TRY(c, hipHostMalloc((void **)&sl.h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
-                                     hipHostMallocMapped));
+                                     hipHostMallocMapped | hipHostMallocCoherent));
             HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_sum_dev, sl.h_sum, 0));
             HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_rec_dev, sl.h_rec, 0));
             // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
             for (auto &e : sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
-            HIP_TRY(c, hipEventCreateWithFlags(&sl.done, std::getenv("ADSB_DONE_FENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
+            const bool fenced = tuning_env("ADSB_DONE_FENCE") != nullptr;  // measurement aid only
+            HIP_TRY(c, hipEventCreateWithFlags(&sl.done, fenced ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
         }
-        if (std::getenv("ADSB_TIMELINE")) {
+        if (tuning_env("ADSB_TIMELINE")) {
             // 1: stamps of 8 blocks x 8 tiles; 2 (with ADSB_DEBUG_STOP=100): per-wave phase totals
             HIP_TRY(c, hipMalloc((void **)&c->d_timeline, kTimelineWords * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemset(c->d_timeline, 0, kTimelineWords * sizeof(unsigned long long)));
@@ -823,6 +862,15 @@ int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
 }
 
 int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->collected) : 0; }
+
+int adsb_fetch_messages(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
+{
+    if (!c || (!out && cap) || !c->has_undelivered) return ADSB_ERR_INVALID;
+    const size_t n = std::min(cap, c->undelivered.size());
+    if (n) std::memcpy(out, c->undelivered.data(), n * sizeof(adsb_msg));
+    if (n_out) *n_out = c->undelivered.size();
+    return c->undelivered.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
 
 int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
 {

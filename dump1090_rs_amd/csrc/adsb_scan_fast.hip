@@ -442,7 +442,7 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
 #ifdef ADSB_KERNEL_ACCT
 #define STAMP(slot)                                                                          \
     do {                                                                                     \
-        if (p.timeline && p.debug_stop != 100 && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
+        if (p.timeline && !ADSB_STOP_AT(p, 100) && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
             p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
     } while (0)
 
@@ -506,14 +506,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     // Workgroups that share a CU start a fraction of a tile period apart, so that the
     // VALU-dense phases of one overlap the latency-bound phases of the others instead of
     // all of them marching through the same phase together.
+#ifdef ADSB_TUNING
     if (p.stagger_ticks) {
         const uint32_t k = (blockIdx.x * 4u) / gridDim.x;  // 0..3: which quarter of the grid
         const unsigned long long until = clock64() + (unsigned long long)k * p.stagger_ticks;
         while ((unsigned long long)clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
+#endif
 
 #ifdef ADSB_KERNEL_ACCT
-    const bool acct = p.debug_stop == 100 && p.timeline != nullptr;
+    const bool acct = ADSB_STOP_AT(p, 100) && p.timeline != nullptr;
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
 #endif
 
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     if (tid == 0) s.nhit[par ^ 1u] = 0;
     ACCT(1);
     STAMP(1);
-    if (jn <= 0 || p.debug_stop == 1) {
+    if (jn <= 0 || ADSB_STOP_AT(p, 1)) {
         lds_barrier();
         continue;
     }
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     lds_barrier();
     ACCT(3);
     STAMP(2);
-    if (p.debug_stop == 2) continue;
+    if (ADSB_STOP_AT(p, 2)) continue;
 
     // ================================================================ P3..P5, wave-private
     // From here to the end of the tile every wave works alone on the positions of its own
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
     const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
     uint32_t ncand_w = 0;  // candidates waiting in wcand (wave-uniform)
-    if (p.debug_stop == 3) goto tile_end;  // profiling: patterns only
+    if (ADSB_STOP_AT(p, 3)) goto tile_end;  // profiling: patterns only
 
     // One loop, one copy of each stage: take the next round of matches when the previous one
     // is used up, run one 64-lane pass of the gates, and run the trials whenever the
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
             continue;
         }
         wave_lds_fence();
-        if (p.debug_stop == 4) {  // profiling: gates only
+        if (ADSB_STOP_AT(p, 4)) {  // profiling: gates only
             ncand_w = 0;
             if (round >= nrounds) break;
             continue;
@@ -771,7 +773,7 @@ tile_end:
     lds_barrier();
     ACCT(5);
     STAMP(5);
-    if (p.debug_stop == 5) {
+    if (ADSB_STOP_AT(p, 5)) {
         lds_barrier();
         continue;
     }
@@ -823,10 +825,10 @@ int scan_resident_blocks()
             cus = 256;
         }
         int r = per_cu * cus;
-        if (const char *e = std::getenv("ADSB_SCAN_BLOCKS_PER_CU")) r = std::atoi(e) * cus;
+        if (const char *e = tuning_env("ADSB_SCAN_BLOCKS_PER_CU")) r = std::atoi(e) * cus;
         if (r > kApSegments) r = kApSegments;  // four private AP segments (one per wave) each
         if (r < 1) r = 1;
-        if (std::getenv("ADSB_TIMELINE"))
+        if (tuning_env("ADSB_TIMELINE"))
             std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
         return r;
     }();

@@ -52,7 +52,10 @@ typedef enum {
     ADSB_ERR_TOO_LONG = -4,  /* more than 131072 samples handed to a one-buffer call:
                                 the reference panics here (src/lib.rs:48) */
     ADSB_ERR_CAPACITY = -5,  /* `out` too small; *n_out holds the required count and the
-                                first `cap` messages were written */
+                                first `cap` messages were written.  The pass itself is done (the
+                                filter has advanced, as after demodulate2400 returned its Vec):
+                                do not repeat the call -- adsb_fetch_messages hands out the whole
+                                list, which the context keeps until its next demod call */
     ADSB_ERR_NOMEM = -6,
     ADSB_ERR_BUSY = -7       /* submissions pending where none are allowed, or too many in flight */
 } adsb_status;
@@ -152,6 +155,12 @@ int adsb_demod_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_sa
 int adsb_submit_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples);
 int adsb_collect(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 int adsb_pending(const adsb_ctx *ctx);
+
+/* The complete message list of the most recent call that returned ADSB_ERR_CAPACITY
+ * (adsb_demodulate2400, adsb_demod_iq[_device], adsb_collect): that call already ran the pass and
+ * updated the filter, so repeating it would score against a different filter; this returns what it
+ * produced.  The list is kept until the next of those calls.  ADSB_ERR_INVALID when nothing is held. */
+int adsb_fetch_messages(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 
 /* Streaming ring for a host that produces IQ (an SDR read loop, dump1090_rs/src/main.rs:
  * 154-167): two pinned host buffers of `samples_per_slot` samples with a device staging

@@ -15,6 +15,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def _have_gpu() -> bool:
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a box without a GPU skips the gpu tests instead of failing in adsb_create."""
+    expr = config.getoption("-m") or ""
+    if _have_gpu() or ("gpu" in expr and "not gpu" not in expr):
+        return  # asked for explicitly (the GPU box): run, and fail loudly if the device is missing
+    skip = pytest.mark.skip(reason="no HIP device: gpu tests run on the MI355X box (-m gpu)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return json.loads((GOLDEN / "reference_frames.json").read_text())

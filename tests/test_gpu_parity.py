@@ -291,6 +291,78 @@ def test_list_overflow_falls_back_and_stays_exact(hip_lib, oracle_mod):
         assert_same(c.demod_iq(iq), want)
 
 
+def test_overflow_fallback_after_a_later_flush_keeps_earlier_addresses(hip_lib, oracle_mod):
+    """Pass i overflows the lists while pass i+1, submitted after an icao_flush, is already in
+    flight: the bitmaps have rotated and the retired one has been cleared by then, so the
+    fallback has to put the addresses the filter held before pass i back into the superset --
+    or the address/parity frames of pass i that rely on them vanish."""
+    import torch
+    from dump1090_rs_amd import Context
+    n = 131072
+    icao = 0x3C6589
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")      # scores only while icao is known
+    host = [synth.noise_numpy(n, seed=900 + k) for k in range(3)]
+    synth.add_bursts(host[0], [synth.Burst(5 * (30000 * k + 777) + k, 21000, k, synth.df17_frame(icao, k))
+                               for k in range(1, 4)])
+    # pass 1: a periodic stretch that overflows a one-buffer context's lists, DF4s in the clean part
+    a, b = 40000, 125000
+    host[1][a:b, 0] = np.tile(np.array(ADVERSARIAL_PERIODS[0], dtype=np.int16), (b - a) // 8 + 1)[: b - a]
+    host[1][a:b, 1] = 0
+    synth.add_bursts(host[1], [synth.Burst(5 * (9000 * k + 333) + k, 21000, k, df4) for k in range(1, 4)])
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want = [orc.demod_iq(host[0], cap=1 << 18)[0], orc.demod_iq(host[1], cap=1 << 18)[0]]
+    orc.icao_flush()
+    want.append(orc.demod_iq(host[2], cap=1 << 18)[0])
+    assert sum(w["buffer"] == df4 for w in want[1]) >= 2
+    bufs = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    with Context(0, 1) as c:
+        c.icao_flush()
+        c.submit_iq_device(bufs[0].data_ptr(), n)
+        assert_same(c.collect(cap=1 << 18), want[0])
+        c.submit_iq_device(bufs[1].data_ptr(), n)
+        c.icao_flush()
+        c.submit_iq_device(bufs[2].data_ptr(), n)
+        got1 = c.collect(cap=1 << 18)
+        assert c.stats()["retries"] > 0                  # the scenario really went through the fallback
+        assert_same(got1, want[1])
+        assert_same(c.collect(cap=1 << 18), want[2])
+
+
+def test_output_array_too_small_loses_nothing_and_does_not_rerun_the_pass(hip_lib, oracle_mod, fixture_iq, golden):
+    """ADSB_ERR_CAPACITY: the pass is consumed and the filter has advanced (like demodulate2400
+    having returned its Vec), so the list is fetched, never recomputed -- a recomputation would
+    score against the advanced filter (1400 -> 1800, extra address/parity frames)."""
+    import ctypes as C
+    from dump1090_rs_amd import Context
+    from dump1090_rs_amd._lib import AdsbMsg, ADSB_ERR_CAPACITY, ADSB_ERR_INVALID
+    fx = golden["fixtures"][2]
+    iq = fixture_iq[fx["file"]]
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want1, _ = orc.demod_iq(iq)
+    want2, _ = orc.demod_iq(iq)        # second time over the same capture: the filter knows the addresses
+    assert [w["score"] for w in want1] != [w["score"] for w in want2]
+    with Context(0, 1) as c:
+        L, h = c._L, c._h
+        n = C.c_size_t()
+        buf = (AdsbMsg * 64)()
+        assert L.adsb_fetch_messages(h, buf, 64, C.byref(n)) == ADSB_ERR_INVALID   # nothing held
+        c.icao_flush()
+        a = np.ascontiguousarray(iq)
+        assert L.adsb_demod_iq(h, a.ctypes.data, a.shape[0], buf, 2, C.byref(n)) == ADSB_ERR_CAPACITY
+        assert n.value == len(want1)
+        assert [bytes(m.msg)[: m.len] for m in buf[:2]] == [w["buffer"] for w in want1[:2]]
+        assert L.adsb_fetch_messages(h, buf, 3, C.byref(n)) == ADSB_ERR_CAPACITY and n.value == len(want1)
+        assert L.adsb_fetch_messages(h, buf, 64, C.byref(n)) == 0 and n.value == len(want1)
+        assert [(m.j, m.try_phase, m.score, bytes(m.msg)[: m.len]) for m in buf[: n.value]] == \
+            [(w["j"], w["try_phase"], w["score"], w["buffer"]) for w in want1]
+        # the Python wrapper does the same by itself, and the filter advanced exactly once
+        assert_same(c.demod_iq(iq, cap=1), want2)
+
+
 # ----------------------------------------------------------------------------- pipelined API
 def test_submit_collect_matches_blocking_calls_and_orders_flushes(ctx, oracle_mod):
     """adsb_submit_iq_device / adsb_collect: two passes in flight, results in submission

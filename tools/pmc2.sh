@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; N=$1; shift; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }; N=$1; shift; cd /tmp; export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_LDS_[A-Z_]*\|SQ_INST_CYCLES_[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_WAIT_INST_[A-Z_]*\|SQ_INSTS_[A-Z_]*" | sort -u | tr '\n' ' ' | head -c 1500; echo
 i=0
 for set in "$@"; do
