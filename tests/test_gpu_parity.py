@@ -307,7 +307,8 @@ def test_overflow_fallback_after_a_later_flush_keeps_earlier_addresses(hip_lib, 
                                for k in range(1, 4)])
     # pass 1: a periodic stretch that overflows a one-buffer context's lists, DF4s in the clean part
     a, b = 40000, 125000
-    host[1][a:b, 0] = np.tile(np.array(ADVERSARIAL_PERIODS[0], dtype=np.int16), (b - a) // 8 + 1)[: b - a]
+    per = np.array(ADVERSARIAL_PERIODS[1], dtype=np.int16)     # 3.4 address/parity trials per position
+    host[1][a:b, 0] = np.tile(per, (b - a) // len(per) + 1)[: b - a]
     host[1][a:b, 1] = 0
     synth.add_bursts(host[1], [synth.Burst(5 * (9000 * k + 333) + k, 21000, k, df4) for k in range(1, 4)])
     orc = oracle_mod.Oracle()
