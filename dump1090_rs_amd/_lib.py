@@ -43,7 +43,7 @@ class AdsbStats(C.Structure):
         ("ms_records", C.c_float),
         ("ms_total_device", C.c_float),
         ("retries", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("ms_scan_exclusive", C.c_float),
     ]
 
 

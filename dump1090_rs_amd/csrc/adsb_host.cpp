@@ -43,12 +43,14 @@ struct Slot {
                                    // (kept until the slot is reused: the overflow fallback re-reads it)
     hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
     uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
+    uint64_t scan_seq = 0;  // running number of the pass (ms_scan_exclusive: was the previous scan the previous pass?)
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int profiled = 0;  // profiling level the pass was enqueued with
 };
 
-constexpr int kSlots = 2;  // ADSB_MAX_IN_FLIGHT
+constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 3: the device never waits for the host between passes
+constexpr int kBitmaps = kSlots + 1;
 
 constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup
 
@@ -66,11 +68,12 @@ struct adsb_ctx {
     void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
     size_t stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
-    // Three address bitmaps in rotation: icao_flush moves on to the next (clean) one, the
-    // retired one is cleared by that pass's records kernel and comes back into use two
-    // flushes later -- by then the pass that cleared it has long been collected, so neither
-    // a reset launch nor a cross-stream wait is ever needed.
-    uint32_t *d_bitmap[3] = {nullptr, nullptr, nullptr};
+    // Address bitmaps in rotation (one more than passes in flight): icao_flush moves on to the
+    // next (clean) one, the retired one is cleared by that pass's records kernel and comes back
+    // into use kSlots flushes later -- a pass that far ahead cannot even be submitted before the
+    // pass that cleared it has been collected, so neither a reset launch nor a cross-stream wait
+    // is ever needed.
+    uint32_t *d_bitmap[kBitmaps] = {};
     int cur_bitmap = 0;
     hipStream_t tail_stream = nullptr;  // match + records of pass i run here, beside scan i+1
     // The scans run on two internal streams, alternating between consecutive pipelined passes:
@@ -93,6 +96,12 @@ struct adsb_ctx {
     } fb;
 
     Slot slot[kSlots];
+    // start / stop events of the scans, in a ring one longer than the passes in flight: when pass N
+    // is collected the stop event of pass N-1 is still its own (ms_scan_exclusive)
+    hipEvent_t scan_ev[kSlots + 1][2] = {};
+    hipEvent_t last_stop = nullptr;  // stop event of the pass collected last, and its number
+    uint64_t last_scan_seq = 0;
+    uint64_t scan_counter = 0;
     uint64_t submitted = 0, collected = 0;
     uint32_t next_seq = 1;
 
@@ -252,7 +261,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.clean_bitmap = nullptr;
     if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the next clean one
         p.clean_bitmap = c->d_bitmap[c->cur_bitmap];
-        c->cur_bitmap = (c->cur_bitmap + 1) % 3;
+        c->cur_bitmap = (c->cur_bitmap + 1) % kBitmaps;
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;
@@ -280,6 +289,9 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     const int prof = sl.profiled;
     sl.seq = c->next_seq++;
     if (c->next_seq == 0) c->next_seq = 1;
+    sl.scan_seq = ++c->scan_counter;
+    sl.ev[0] = c->scan_ev[sl.scan_seq % (kSlots + 1)][0];
+    sl.ev[1] = c->scan_ev[sl.scan_seq % (kSlots + 1)][1];
     sl.h_sum->seq = 0;  // the records kernel overwrites it, last, with sl.seq
     p.seq = sl.seq;
     // level 1: the scan launch stamps its own begin/end (no extra packets on the stream);
@@ -294,7 +306,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // odd slots scan on the second stream, unless something orders consecutive passes (the
     // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
     static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
-    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && &sl == &c->slot[1];
+    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (c->submitted & 1u) != 0;
     hipStream_t ss = c->scan_stream[second ? 1 : 0];
     // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
     hipEvent_t ready = input_done;
@@ -327,8 +339,8 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (p.clean_bitmap && fast) {
         // this pass's records kernel clears the bitmap the previous passes matched against: not
         // before the pass still in flight (whichever stream its tail is on) is through with it
-        Slot &other = c->slot[&sl == &c->slot[1] ? 0 : 1];
-        if (other.busy) HIP_TRY(c, hipStreamWaitEvent(ts, other.done, 0));
+        for (Slot &other : c->slot)
+            if (&other != &sl && other.busy) HIP_TRY(c, hipStreamWaitEvent(ts, other.done, 0));
     }
     if (!inline_tail) {
         HIP_TRY(c, hipEventRecord(sl.scanned, ss));
@@ -361,6 +373,17 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
         st.ms_scan += ms;
+        // the part of it after the previous pass's scan had ended (that pass's events are intact:
+        // its slot is not reused before this pass is collected)
+        float excl = ms;
+        if (c->last_stop && c->last_scan_seq + 1 == sl.scan_seq) {
+            // time since the previous scan ended, when that is shorter than this scan's own duration
+            float tail = 0;
+            if (hipEventElapsedTime(&tail, c->last_stop, sl.ev[1]) == hipSuccess && tail >= 0 && tail < excl) excl = tail;
+        }
+        st.ms_scan_exclusive += excl;
+        c->last_stop = sl.ev[1];
+        c->last_scan_seq = sl.scan_seq;
         if (sl.profiled > 1) {  // per-kernel split of the tail (events cost a few us each)
             HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
             st.ms_match += ms;
@@ -507,6 +530,7 @@ int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<
         total.n_ap_entries += c->stats.n_ap_entries;
         total.n_records += c->stats.n_records;
         total.ms_scan += c->stats.ms_scan;
+        total.ms_scan_exclusive += c->stats.ms_scan_exclusive;
         total.ms_match += c->stats.ms_match;
         total.ms_records += c->stats.ms_records;
         total.ms_total_device += c->stats.ms_total_device;
@@ -639,10 +663,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_sum_dev, sl.h_sum, 0));
             HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_rec_dev, sl.h_rec, 0));
             // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
-            for (auto &e : sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+            for (int k = 2; k < 5; k++) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev[k], hipEventDisableSystemFence));
             const bool fenced = tuning_env("ADSB_DONE_FENCE") != nullptr;  // measurement aid only
             HIP_TRY(c, hipEventCreateWithFlags(&sl.done, fenced ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
         }
+        for (auto &pair : c->scan_ev)
+            for (auto &e : pair) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
         if (tuning_env("ADSB_TIMELINE")) {
             // 1: stamps of 8 blocks x 8 tiles; 2 (with ADSB_DEBUG_STOP=100): per-wave phase totals
             HIP_TRY(c, hipMalloc((void **)&c->d_timeline, kTimelineWords * sizeof(unsigned long long)));
@@ -650,7 +676,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         // both bitmaps clean and both counter blocks zero to start with; from then on each
         // pass cleans up for the next (the first pass needs no flush of its own)
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < kBitmaps; k++)
             if (int e = launch_reset(c->slot[k % kSlots].d_ctr, c->d_bitmap[k], c->stream))
                 return fail(c, (hipError_t)e, "launch_reset");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -672,9 +698,12 @@ void adsb_destroy(adsb_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    for (Slot &sl : c->slot) {
-        for (auto &e : sl.ev)
+    for (auto &pair : c->scan_ev)
+        for (auto &e : pair)
             if (e) (void)hipEventDestroy(e);
+    for (Slot &sl : c->slot) {
+        for (int k = 2; k < 5; k++)
+            if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.scanned) (void)hipEventDestroy(sl.scanned);
         if (sl.d_ctr) (void)hipFree(sl.d_ctr);
@@ -936,6 +965,7 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
         total.n_ap_entries += c->stats.n_ap_entries;
         total.n_records += c->stats.n_records;
         total.ms_scan += c->stats.ms_scan;
+        total.ms_scan_exclusive += c->stats.ms_scan_exclusive;
         total.ms_match += c->stats.ms_match;
         total.ms_records += c->stats.ms_records;
         total.ms_total_device += c->stats.ms_total_device;
@@ -1069,7 +1099,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     uint32_t *retired = nullptr;
     if (c->flush_pending) {
         retired = c->d_bitmap[c->cur_bitmap];
-        c->cur_bitmap = (c->cur_bitmap + 1) % 3;
+        c->cur_bitmap = (c->cur_bitmap + 1) % kBitmaps;
         c->filter.flush();
         c->flush_pending = false;
     }

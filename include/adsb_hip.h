@@ -60,7 +60,7 @@ typedef enum {
     ADSB_ERR_BUSY = -7       /* submissions pending where none are allowed, or too many in flight */
 } adsb_status;
 
-#define ADSB_MAX_IN_FLIGHT 2
+#define ADSB_MAX_IN_FLIGHT 3
 
 typedef struct adsb_ctx adsb_ctx;
 
@@ -89,14 +89,17 @@ typedef struct {
     float ms_records;       /* record builder kernel */
     float ms_total_device;  /* first launch -> last kernel end */
     uint32_t retries;       /* device-list overflow fallbacks taken */
-    uint32_t reserved;
+    float ms_scan_exclusive; /* the part of ms_scan after the previous pass's scan had finished: consecutive
+                              * pipelined scans overlap (the next one's workgroups fill the CUs as the previous
+                              * grid drains), so the sum of ms_scan over passes counts the overlap twice while
+                              * the sum of ms_scan_exclusive is the device time the scans took altogether */
 } adsb_stats;
 
 /* Create a context on HIP device `device` (>= 0), sized to demodulate up to
  * `max_chunks` 131072-sample buffers per call (host-pointer calls stage through
  * a device buffer of that size; device-pointer calls only size the lists).
  * Device memory: ~7.5 MB for max_chunks = 1 (three 2 MiB address bitmaps and the
- * lists of two passes in flight), ~150 MB for 512; input denser than the lists are
+ * lists of three passes in flight), ~220 MB for 512; input denser than the lists are
  * sized for (several times a busy airspace) is still demodulated exactly, buffer
  * by buffer through worst-case lists allocated on first use (stats.retries). */
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks);
