@@ -23,21 +23,26 @@ namespace adsb {
 // subnormal or overflows: X = rn(im^2 + rn(re^2)) is 0 or in [1, 2^31]), so the
 // two divisions fold into the last constant: 65535 * 2^-15 is a 16-bit value.
 //
-// sqrt must be the correctly rounded one (IEEE), as Rust's f32::sqrt is.  HIP's
-// __fsqrt_rn is the raw v_sqrt_f32 (1 ulp) -- not good enough: it flips the u16
-// result for about one sample in 10^5.  The fix-up is the neighbour test LLVM uses
-// for IEEE sqrtf, without the subnormal scaling and class checks x never needs: with
-// s = v_sqrt_f32(x), the correctly rounded root is s, or its lower neighbour s_dn if
-// s_dn*s >= x, or its upper neighbour s_up if s_up*s < x (the products stand for the
-// squared midpoints).  Both tests are sign bits of a fused s_n*s - x, so the result's
-// bit pattern is  bits(s) - 1 + sign(s_dn*s - x) + sign(s_up*s - x)  with no compare
-// or select.  For x = 0: s = 0, s_dn is a NaN with the sign bit set (+1) and
-// s_up*s - x = +0 (+0), so bits(s) stays 0.
+// sqrt must be the correctly rounded one (IEEE), as Rust's f32::sqrt is.  The raw v_sqrt_f32
+// (1 ulp) is not good enough: it flips the u16 result for about one sample in 10^5.  The root
+// is built from ONE transcendental instead: with y = v_rsq_f32(x) (1 ulp),
+//     s = x * y          within 2 ulp of the root
+//     h = y / 2
+//     d = fma(-s, s, x)  the remainder x - s^2, rounded once
+//     r = fma(d, h, s)   the correctly rounded root
+// (Markstein's final correction step).  That r is the IEEE root for EVERY f32 x in [1, 2^31] --
+// a superset of what im^2 + rn(re^2) can be -- is not taken on trust: tools/sqrt_markstein.hip
+// compares it with the neighbour-test construction LLVM uses for sqrtf over all 260 046 849
+// values (0 differences), and tests/test_gpu_parity.py sweeps the same range through mag_tail2
+// against the CPU.  For x = 0: y = inf, s = NaN, and the NaN runs through to the float->u32
+// conversion, which turns it into 0 (V_CVT_U32_F32: "NaN is converted to 0") -- the magnitude of
+// a zero sample; the conversion is written as the instruction itself because a C++ cast of NaN
+// to an integer is undefined.
 //
 // Everything is done on pairs so the multiplies and fused multiply-adds are
 // v_pk_mul_f32 / v_pk_fma_f32 (two samples per instruction) and the saturating cast +
-// pack is one v_cvt_pk_u16_u32.  tests/test_gpu_parity.py sweeps every f32 x in
-// {0} U [1, 2^31] through mag_tail2 against the CPU.
+// pack is one v_cvt_pk_u16_u32: 8 VALU instructions per sample from the IQ dword to the packed
+// u16 (the neighbour-test form took 12.5).
 // ---------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -47,21 +52,27 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
     return __builtin_elementwise_fma(a, b, c);
 }
 
+// truncating, saturating float -> u32 with NaN -> 0 (the instruction's own definition)
+__device__ __forceinline__ uint32_t cvt_u32_sat(float v)
+{
+    uint32_t u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(v));
+    return u;
+}
+
 // two X = im^2 + rn(re^2) -> two magnitudes packed as u16 (low half = first)
 __device__ __forceinline__ uint32_t mag_tail2(f32x2 x)
 {
-    const f32x2 s = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
-    const u32x2 sb = __builtin_bit_cast(u32x2, s);
-    // (v_sqrt_f32 errs low for 15 % of the x in range and high for 15049 of them: both
-    // neighbours are needed -- dropping the rare one is caught by the exhaustive sweep)
-    const u32x2 dnb = sb - 1u, upb = sb + 1u;
-    const f32x2 qdn = pk_fma(__builtin_bit_cast(f32x2, dnb), s, -x);  // >= 0: root is s_dn
-    const f32x2 qup = pk_fma(__builtin_bit_cast(f32x2, upb), s, -x);  // <  0: root is s_up
-    const u32x2 rb = dnb + (__builtin_bit_cast(u32x2, qup) >> 31) + (__builtin_bit_cast(u32x2, qdn) >> 31);
+    const f32x2 y = {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    const f32x2 s = x * y;
+    const f32x2 hk = {0.5f, 0.5f};
+    const f32x2 h = y * hk;
+    const f32x2 d = pk_fma(-s, s, x);
+    const f32x2 r = pk_fma(d, h, s);  // == sqrt_rn(x) for x in [1, 2^31]; NaN for x = 0
     const f32x2 c = {65535.0f / 32768.0f, 65535.0f / 32768.0f}, half = {0.5f, 0.5f};
-    const f32x2 o = pk_fma(__builtin_bit_cast(f32x2, rb), c, half);
-    // o >= 0.5; the u32 conversion truncates, the pack saturates at 65535 (Rust `as u16`)
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16((uint32_t)o.x, (uint32_t)o.y));
+    const f32x2 o = pk_fma(r, c, half);
+    // o >= 0.5 or NaN; the u32 conversion truncates, the pack saturates at 65535 (Rust `as u16`)
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(o.x), cvt_u32_sat(o.y)));
 }
 
 // two IQ dwords {re (low half), im (high half)} -> two magnitudes packed as u16
