@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
     L.adsb_last_error.argtypes = [vp]
     L.adsb_last_error.restype = C.c_char_p
     L.adsb_version.restype = C.c_char_p
+    L.adsb_host_sorts.argtypes = [vp]
+    L.adsb_host_sorts.restype = C.c_uint64
     for name in ("adsb_create", "adsb_set_stream", "adsb_set_profiling", "adsb_icao_flush",
                  "adsb_to_mag", "adsb_demodulate2400", "adsb_demod_iq", "adsb_demod_iq_device",
                  "adsb_read_test_data", "adsb_get_stats", "adsb_replay_records",

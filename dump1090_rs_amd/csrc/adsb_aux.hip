@@ -100,12 +100,87 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
             if (e[k] == ~0ull || !((coarse[(c[k] & 4095u) >> 5] >> (c[k] & 31)) & 1u)) continue;
             if ((p.bitmap[c[k] >> 5] >> (c[k] & 31)) & 1u) {  // rare: one atomic each
                 const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
-                if (idx < p.hits_cap)
+                if (idx < p.hits_cap) {
                     p.hits[idx] = e[k];
-                else
+                    if (p.order_cnt) atomicAdd(&p.order_cnt[entry_chunk(e[k])], 1u);
+                } else {
                     atomicOr(&p.ctr->overflow, 1u);
+                }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// order.  The hit list is filled in whatever order workgroups finish; the host replay needs
+// (buffer, j, try_phase) order (demodulate2400 walks j upwards and tries phases 4..8 at each,
+// src/demod_2400.rs:121,158).  Sorting it here is a counting sort by buffer followed by a rank
+// sort inside each buffer's handful of hits: a busy airspace leaves tens of hits per buffer, and
+// keys are unique (a trial is either self-validating or address/parity, never both).
+//   producers       whoever stores a hit also counts it for its buffer (order_cnt)
+//   k_order_prefix  one workgroup: exclusive prefix of the counts (order_base)
+//   k_order_scatter one thread per hit: into its buffer's bucket in order_tmp; the counts run
+//                   back down to zero, which is how the next pass must find them
+//   k_order_rank    one thread per hit: rank among its buffer's hits -> final place in p.hits
+// A pass whose lists overflowed is redone by the host anyway: its counts are only zeroed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t order_key(uint64_t e)
+{
+    return ((e >> 28) << 3) | (uint64_t)(entry_code(e) % 5u);  // (chunk, j) | try_phase - 4
+}
+
+__global__ __launch_bounds__(1024) void k_order_prefix(ScanParams p)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    const uint32_t tid = threadIdx.x;
+    if (p.ctr->overflow) {  // (uniform) nothing will be ordered: leave the counts clean
+        for (uint32_t c = tid; c <= p.n_chunks; c += 1024) p.order_cnt[c] = 0;
+        return;
+    }
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 <= p.n_chunks; c0 += 1024) {
+        const uint32_t c = c0 + tid;
+        const uint32_t v = c < p.n_chunks ? p.order_cnt[c] : 0u;
+        part[tid] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = tid >= off ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        if (c <= p.n_chunks) p.order_base[c] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_order_scatter(ScanParams p)
+{
+    if (p.ctr->overflow) return;
+    const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t e = p.hits[i];
+        const uint32_t c = (uint32_t)entry_chunk(e);
+        p.order_tmp[p.order_base[c] + atomicSub(&p.order_cnt[c], 1u) - 1u] = e;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_order_rank(ScanParams p)
+{
+    if (p.ctr->overflow) return;
+    const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t e = p.order_tmp[i];
+        const uint32_t c = (uint32_t)entry_chunk(e);
+        const uint32_t lo = p.order_base[c], hi = p.order_base[c + 1];
+        const uint64_t key = order_key(e);
+        uint32_t rank = 0;
+        for (uint32_t k = lo; k < hi; k++) rank += order_key(p.order_tmp[k]) < key;
+        p.hits[lo + rank] = e;
     }
 }
 
@@ -129,6 +204,25 @@ __device__ __forceinline__ void host_store128(void *p, u32x4_t v)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// src/icao_filter.rs:19-43 (u64 intermediates, & 4095), so that the host replay does not hash
+__device__ __forceinline__ uint32_t icao_hash_dev(uint32_t a)
+{
+    unsigned long long h = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        h += (a >> (8 * k)) & 0xFFu;
+        h += h << 10;
+        h ^= h >> 6;
+    }
+    h += h << 3;
+    h ^= h >> 11;
+    h += h << 15;
+    return (uint32_t)h & 4095u;
+}
+
+#ifndef ADSB_REC_BLOCKS_PER_CHUNK
+#define ADSB_REC_BLOCKS_PER_CHUNK 1
+#endif
 constexpr int kRecWindow = 296;   // magnitudes a trial can touch: data[j+19 .. j+290], rounded up
 constexpr int kRecBatch = 64;     // records a block stages before writing them out together
 
@@ -168,16 +262,25 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
                 const int len = chunk_len(p.n_samples, chunk);
                 const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
                 const bool lead = p.carry != nullptr && (chunk > 0 || p.lead_from_src);
-                for (int k = lane; k < kRecWindow; k += 64) {
+                // (all five loads of a lane are issued before the first magnitude: one latency, not five)
+                uint32_t w[(kRecWindow + 63) / 64];
+#pragma unroll
+                for (int q5 = 0; q5 < (kRecWindow + 63) / 64; q5++) {
+                    const int k = lane + 64 * q5;
                     const int s = (int)j + 19 + k - kLead;  // IQ sample behind data[j+19+k]
-                    uint32_t w = 0;
+                    w[q5] = 0;
+                    if (k >= kRecWindow) continue;
                     if (s >= 0 && s < len)
-                        w = iq[s];
+                        w[q5] = iq[s];
                     else if (s < 0 && lead)                 // carry-over mode: the samples before
-                        w = *(iq + s);
+                        w[q5] = *(iq + s);
                     else if (s < 0 && p.carry != nullptr)
-                        w = p.carry[s + kCarrySamples];
-                    win[wave][k] = (uint16_t)mag_of_dword(w);
+                        w[q5] = p.carry[s + kCarrySamples];
+                }
+#pragma unroll
+                for (int q5 = 0; q5 < (kRecWindow + 63) / 64; q5++) {
+                    const int k = lane + 64 * q5;
+                    if (k < kRecWindow) win[wave][k] = (uint16_t)mag_of_dword(w[q5]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -223,7 +326,12 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
                 for (int k = 0; k < 8; k++) r.msg[k] = (uint8_t)(half[0] >> (56 - 8 * k));
 #pragma unroll
                 for (int k = 0; k < 6; k++) r.msg[8 + k] = (uint8_t)(half[1] >> (56 - 8 * k));
-                r.pad = 1;  // `power` carries the residual
+                // `power` carries the residual (bit 0); bits 4..15: icao_hash of what this DF will ask
+                // the filter about (bit 1) -- the residual for the address/parity DFs, else the address
+                const uint32_t df = (uint32_t)(half[0] >> 59);
+                const bool ap = ((0xFF310031u >> df) & 1u) != 0;
+                const uint32_t addr = (uint32_t)(half[0] >> 32) & 0xFFFFFFu;
+                r.pad = (uint16_t)(3u | (icao_hash_dev(ap ? crc : addr) << 4));
                 stage[q] = r;
             }
             __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next hit
@@ -352,12 +460,27 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
     hip_clear();
     // contiguous runs of hits per block (the count lives on the device): enough blocks that a
     // dense pass (tens of hits per chunk) still has only a few hits per wave
-    uint32_t blocks = p.n_chunks + 8;
-    if (blocks > 2048) blocks = 2048;
+    // (the count lives on the device: sized for a dense pass -- ~35 hits per buffer -- to leave a wave
+    // one or two hits; on sparse input most blocks find nothing and leave at once)
+    uint32_t blocks = ADSB_REC_BLOCKS_PER_CHUNK * p.n_chunks + 8;
+    if (blocks > 4096) blocks = 4096;
     if (from_mag)
         hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     else
         hipLaunchKernelGGL(k_records<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_order_hits(const ScanParams &p, void *stream)
+{
+    hip_clear();
+    if (!p.order_cnt || !p.order_base || !p.order_tmp) return 0;
+    hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+    // the count lives on the device: grid-stride loops over whatever there is
+    uint32_t blocks = (p.hits_cap + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_order_rank, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

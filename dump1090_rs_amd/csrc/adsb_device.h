@@ -74,11 +74,12 @@ constexpr uint64_t kMaxChunks = 1ull << 19;  // per device pass (256 GiB of IQ)
 // One trial message handed to the host replay (32 bytes).
 struct TrialRecord {
     uint64_t power;     // bits 0..39: sum of the 33 squared magnitudes from j+19 (demod_2400.rs:
-                        // 191-196; < 2^38).  With pad == 1, bits 40..63: the CRC residual of msg
+                        // 191-196; < 2^38).  With pad bit 0, bits 40..63: the CRC residual of msg
     uint32_t chunk;
     uint32_t j_tp;      // j | try_phase << 24
     uint8_t msg[14];
-    uint16_t pad;       // 1: `power` carries the residual (records built on the device), 0: it does not
+    uint16_t pad;       // bit 0: `power` carries the residual (records built on the device); bit 1: bits 4..15 are
+                        // icao_hash of the value the DF asks the filter about (residual or address)
 };
 static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 
@@ -148,6 +149,11 @@ struct ScanParams {
     // previous call), or from src[-kCarrySamples..] when lead_from_src is set.
     const uint32_t *carry;
     uint32_t lead_from_src;
+    // device-side ordering of the hit list (k_order_bucket / k_order_rank; null: the host sorts):
+    // per-buffer hit counts (n_chunks + 1, all zero between passes), their exclusive prefix
+    // (n_chunks + 1) and a second list of hits_cap entries
+    uint32_t *order_cnt, *order_base;
+    uint64_t *order_tmp;
 };
 
 // The address bitmap: 2^24 bits, followed by a 4096-bit summary (bit a & 4095 is set when any
@@ -168,6 +174,9 @@ int scan_resident_blocks();  // workgroups of the fast scan's persistent grid (<
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);
+// sort the hit list by (buffer, j, try_phase) on the device, so that the records come out in the
+// order the host replays them in (src/demod_2400.rs:121,158: ascending j, then try_phase)
+int launch_order_hits(const ScanParams &p, void *stream);
 // OR a list of 24-bit addresses into a bitmap (addresses learned by other shards)
 int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream);
 // next[i] = sample (n - kCarrySamples + i) of the stream: from d_src, or from `prev` where the

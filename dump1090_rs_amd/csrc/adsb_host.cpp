@@ -39,6 +39,10 @@ struct Slot {
     // stream) fills the other slot's
     Counters *d_ctr = nullptr;
     uint64_t *d_ap = nullptr, *d_hits = nullptr;
+    // device-side ordering of the hit list: per-buffer counts and their prefix (max_chunks + 1
+    // each), and the second list the counting sort scatters into
+    uint32_t *d_order_cnt = nullptr, *d_order_base = nullptr;
+    uint64_t *d_order_tmp = nullptr;
     uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
                                    // (kept until the slot is reused: the overflow fallback re-reads it)
     hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
@@ -132,6 +136,7 @@ struct adsb_ctx {
     std::string last_error;
     // the messages of a call whose `out` was too small (ADSB_ERR_CAPACITY): the pass is consumed
     // and the filter has moved on, so they are kept for adsb_fetch_messages
+    uint64_t host_sorts = 0;  // passes whose records the host had to put in order itself
     std::vector<adsb_msg> undelivered;
     bool has_undelivered = false;
 };
@@ -158,25 +163,32 @@ int fail(adsb_ctx *c, hipError_t e, const char *what)
 // Ordered replay (src/demod_2400.rs:149-207 with mode_s scoring): records sorted by
 // (chunk, j, try_phase); per (chunk, j) the best trial by strictly-greater score
 // starting from -2 wins and is emitted when its score is >= 0.
-void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
-            std::vector<adsb_msg> &out)
+inline uint64_t replay_key(const TrialRecord &r)
 {
-    // order = (chunk, j, try_phase); the records stay where they are (they may sit in mapped
-    // host memory), only 16-byte (key, index) pairs are sorted
+    return (uint64_t)r.chunk << 32 | (uint64_t)(r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24);
+}
+
+void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out, uint64_t *host_sorts = nullptr)
+{
+    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
+    // else is put in order here -- the records stay where they are (they may sit in mapped host
+    // memory), only 16-byte (key, index) pairs are sorted.
     struct Ref {
         uint64_t key;
         uint32_t idx;
     };
-    std::vector<Ref> order(n);
     bool sorted = true;
-    uint64_t all_or = 0;
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t jt = rec[i].j_tp;
-        order[i] = {(uint64_t)rec[i].chunk << 32 | (uint64_t)(jt & 0xFFFFFFu) << 8 | (jt >> 24), (uint32_t)i};
-        sorted = sorted && (i == 0 || order[i - 1].key <= order[i].key);
-        all_or |= order[i].key;
-    }
+    for (size_t i = 1; i < n && sorted; i++) sorted = replay_key(rec[i - 1]) <= replay_key(rec[i]);
+    std::vector<Ref> order;
     if (!sorted) {
+        if (host_sorts) ++*host_sorts;
+        order.resize(n);
+        uint64_t all_or = 0;
+        for (size_t i = 0; i < n; i++) {
+            order[i] = {replay_key(rec[i]), (uint32_t)i};
+            all_or |= order[i].key;
+        }
         // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
         // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
         std::vector<Ref> tmp(n);
@@ -196,30 +208,36 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
         }
         if (src != order.data()) order.swap(tmp);
     }
+    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i].idx]; };
     size_t i = 0;
     while (i < n) {
-        const uint64_t pos = order[i].key >> 8;  // (chunk, j)
-        adsb_msg best{};
-        best.score = -2;
-        best.len = ADSB_MODES_SHORT_MSG_BYTES;
-        for (; i < n && (order[i].key >> 8) == pos; i++) {
-            const TrialRecord &r = rec[order[i].idx];
-            // records built on the device bring the CRC residual along (pad == 1)
-            const Score s = r.pad == 1 ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg)
-                                       : score_modes_message(filter, crc, r.msg);
-            if (!s.some || s.value <= best.score) continue;
-            std::memcpy(best.msg, r.msg, 14);
-            best.len = (uint8_t)s.len;
-            best.score = s.value;
-            best.try_phase = (uint8_t)(r.j_tp >> 24);
-            // demod_2400.rs:191-198: signal_len = 14*12/5 = 33
-            const double signal_power = (double)(r.power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
-            best.signal_level = signal_power / 33.0;
+        const uint64_t pos = replay_key(at(i)) >> 8;  // (chunk, j)
+        const TrialRecord *best = nullptr;
+        Score best_score{false, (int)ADSB_MODES_SHORT_MSG_BYTES, -2};
+        for (; i < n; i++) {
+            const TrialRecord &r = at(i);
+            if ((replay_key(r) >> 8) != pos) break;
+            // records built on the device bring the CRC residual along (pad bit 0) and the filter
+            // hash of the value their DF asks about (pad bit 1, hash in bits 4..15)
+            const Score s = (r.pad & 1) ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg,
+                                                              (r.pad & 2) ? (int)(r.pad >> 4) : -1)
+                                        : score_modes_message(filter, crc, r.msg);
+            if (!s.some || s.value <= best_score.value) continue;
+            best = &r;
+            best_score = s;
         }
-        if (best.score < 0) continue;
-        best.j = (uint32_t)(pos & 0xFFFFFFu);
-        best.chunk = chunk_offset + (pos >> 24);
-        out.push_back(best);
+        if (!best || best_score.value < 0) continue;
+        adsb_msg m{};
+        std::memcpy(m.msg, best->msg, 14);
+        m.len = (uint8_t)best_score.len;
+        m.score = best_score.value;
+        m.try_phase = (uint8_t)(best->j_tp >> 24);
+        // demod_2400.rs:191-198: signal_len = 14*12/5 = 33 (the same three divisions, in this order)
+        const double signal_power = (double)(best->power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
+        m.signal_level = signal_power / 33.0;
+        m.j = (uint32_t)(pos & 0xFFFFFFu);
+        m.chunk = chunk_offset + (pos >> 24);
+        out.push_back(m);
     }
 }
 
@@ -279,6 +297,13 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.timeline = c->d_timeline;
     p.carry = c->carry_over && !from_mag ? sl.d_carry : nullptr;
     p.lead_from_src = lead_from_src ? 1u : 0u;
+    // Passes of many buffers hand their hits over in (buffer, j, try_phase) order, so that the host
+    // only scores; a small pass is all launch overhead and its few records sort in no time on the
+    // host, and the worst-case lists of the fallback are the host's business too.
+    const bool order_on_device = !force_simple && n_chunks > kInlineTailChunks && sl.hits_cap == c->hits_cap;
+    p.order_cnt = order_on_device ? sl.d_order_cnt : nullptr;
+    p.order_base = order_on_device ? sl.d_order_base : nullptr;
+    p.order_tmp = order_on_device ? sl.d_order_tmp : nullptr;
 
     sl.src = d_src;
     sl.from_mag = from_mag;
@@ -348,6 +373,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     }
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
     if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
+    if (int e = launch_order_hits(p, ts)) return fail(c, (hipError_t)e, "launch_order_hits");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
     // the records kernel writes the records and the summary into the slot's mapped host
     // memory with write-through stores; `done` only has to say the kernel has drained
@@ -396,7 +422,8 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     st.n_candidates += sl.h_sum->n_cand_total;
     st.n_ap_entries += sl.h_sum->n_ap_total;
     st.n_records += n;
-    replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out);
+    static const bool skip_replay = tuning_env("ADSB_SKIP_REPLAY") != nullptr;  // measurement aid (tuning build only)
+    if (!skip_replay) replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out, &c->host_sorts);
     return 0;
 }
 
@@ -637,6 +664,10 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             sl.hits_cap = c->hits_cap;
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_cnt, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(sl.d_order_cnt, 0, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_base, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_tmp, (size_t)c->hits_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipEventCreateWithFlags(&sl.scanned, hipEventDisableTiming | hipEventDisableSystemFence));
             HIP_TRY(c, hipMalloc((void **)&sl.d_carry, kCarrySamples * sizeof(uint32_t)));
             HIP_TRY(c, hipMemset(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t)));
@@ -709,6 +740,9 @@ void adsb_destroy(adsb_ctx *c)
         if (sl.d_ctr) (void)hipFree(sl.d_ctr);
         if (sl.d_hits) (void)hipFree(sl.d_hits);
         if (sl.d_ap) (void)hipFree(sl.d_ap);
+        if (sl.d_order_cnt) (void)hipFree(sl.d_order_cnt);
+        if (sl.d_order_base) (void)hipFree(sl.d_order_base);
+        if (sl.d_order_tmp) (void)hipFree(sl.d_order_tmp);
         if (sl.d_carry) (void)hipFree(sl.d_carry);
         if (sl.h_sum) (void)hipHostFree(sl.h_sum);
         if (sl.h_rec) (void)hipHostFree(sl.h_rec);
@@ -1284,6 +1318,8 @@ int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
     *w = 0;
     return (int)need;
 }
+
+uint64_t adsb_host_sorts(const adsb_ctx *c) { return c ? c->host_sorts : 0; }
 
 int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 {

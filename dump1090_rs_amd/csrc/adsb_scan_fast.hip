@@ -295,10 +295,12 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool 
             s.hit[at] = entry;
         } else {  // more hits in one tile than the staging holds: one by one
             const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
-            if (gi < p.hits_cap)
+            if (gi < p.hits_cap) {
                 p.hits[gi] = entry;
-            else
+                if (p.order_cnt) atomicAdd(&p.order_cnt[entry_chunk(entry)], 1u);
+            } else {
                 atomicOr(&p.ctr->overflow, 1u);
+            }
         }
     }
 }
@@ -788,6 +790,7 @@ tile_end:
             if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
         } else {
             for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
+            if (tid == 0 && p.order_cnt) atomicAdd(&p.order_cnt[chunk], nhit);  // a tile's hits share its buffer
         }
     }
     ACCT(6);

@@ -39,9 +39,10 @@ class IcaoFilter {
         return static_cast<uint32_t>(h) & (kSize - 1);
     }
 
-    void add(uint32_t addr)                           // :46-62
+    void add(uint32_t addr) { add(addr, hash(addr)); }  // :46-62
+    // `start` = hash(addr), when the caller already has it (the device computes it per record)
+    void add(uint32_t addr, uint32_t start)
     {
-        const uint32_t start = hash(addr);
         uint32_t h = start;
         do {
             if (table_[h] == addr) return;
@@ -54,9 +55,9 @@ class IcaoFilter {
         // full: the reference prints "icao24 hash table full" and inserts nothing
     }
 
-    bool test(uint32_t addr) const                    // :65-97
+    bool test(uint32_t addr) const { return test(addr, hash(addr)); }  // :65-97
+    bool test(uint32_t addr, uint32_t start) const
     {
-        const uint32_t start = hash(addr);
         uint32_t h = start;
         while (table_[h] != 0 && table_[h] != addr) {
             h = (h + 1) & (kSize - 1);
@@ -102,30 +103,34 @@ struct Score {
 
 // src/mode_s/mod.rs:34-139 on a 14-byte trial message whose CRC residual (over its own length:
 // 14 bytes for DF >= 16, else 7) is already known.
-inline Score score_modes_message(IcaoFilter &filter, uint32_t residual, const uint8_t msg[14])
+// `hash`: icao_hash of the value this message's DF asks the filter about (the residual for the
+// address/parity DFs, the address for DF11/17/18) when the device supplied it, else -1.
+inline Score score_modes_message(IcaoFilter &filter, uint32_t residual, const uint8_t msg[14], int hash = -1)
 {
     const uint32_t df = msg[0] >> 3;                            // :41
     const int len = (df & 0x10) ? 14 : 7;                       // :42-46
-    bool any = false;
-    for (int i = 0; i < 14; i++) any |= msg[i] != 0;            // :51-53
-    if (!any) return {false, len, 0};
+    uint64_t w0, w1;                                            // :51-53 all 14 bytes zero -> None
+    std::memcpy(&w0, msg, 8);
+    std::memcpy(&w1, msg + 6, 8);
+    if ((w0 | w1) == 0) return {false, len, 0};
 
     const uint32_t addr = uint32_t(msg[1]) << 16 | uint32_t(msg[2]) << 8 | msg[3];
     int32_t v = -2;
     switch (df) {
     case 0: case 4: case 5:                                     // :56-72
-        v = filter.test(residual) ? 1000 : -1;
+        v = filter.test(residual, hash >= 0 ? (uint32_t)hash : IcaoFilter::hash(residual)) ? 1000 : -1;
         break;
     case 11: {                                                  // :73-90
         const uint32_t c = residual;
-        const bool known = filter.test(addr);
+        const uint32_t h = hash >= 0 ? (uint32_t)hash : IcaoFilter::hash(addr);
+        const bool known = filter.test(addr, h);
         if ((c & 0xFFFF80u) != 0) {
             v = -2;
         } else if ((c & 0x7f) == 0) {
             if (known) {
                 v = 1600;
             } else {
-                filter.add(addr);
+                filter.add(addr, h);
                 v = 750;
             }
         } else {
@@ -135,19 +140,20 @@ inline Score score_modes_message(IcaoFilter &filter, uint32_t residual, const ui
     }
     case 17: case 18: {                                         // :91-109
         const uint32_t c = residual;
+        const uint32_t h = hash >= 0 ? (uint32_t)hash : IcaoFilter::hash(addr);  // the hash takes 24 bits
         if (c != 0) {
             v = -2;
-        } else if (filter.test(addr)) {
+        } else if (filter.test(addr, h)) {
             v = 1800;
         } else {
-            filter.add(df == 17 ? addr : (addr | IcaoFilter::kAdsbNt));
+            filter.add(df == 17 ? addr : (addr | IcaoFilter::kAdsbNt), h);
             v = 1400;
         }
         break;
     }
     case 16: case 20: case 21:                                  // :110-120
     case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:  // :121-135
-        v = filter.test(residual) ? 1000 : -2;
+        v = filter.test(residual, hash >= 0 ? (uint32_t)hash : IcaoFilter::hash(residual)) ? 1000 : -2;
         break;
     default:
         v = -2;                                                 // :136

@@ -194,9 +194,11 @@ typedef struct {
     uint32_t chunk;
     uint32_t j_tp;    /* j | try_phase << 24 */
     uint8_t msg[ADSB_MODES_LONG_MSG_BYTES];
-    uint16_t pad;     /* 0: nothing more.  1 (records from adsb_shard_finish): bits 40..63 of
-                       * `power` hold the CRC residual of msg over its own length (src/crc.rs:
-                       * 263-282), which spares adsb_replay_records the walk over the bytes */
+    uint16_t pad;     /* 0: nothing more.  Records from adsb_shard_finish set bit 0: bits 40..63 of
+                       * `power` hold the CRC residual of msg over its own length (src/crc.rs:263-282),
+                       * which spares adsb_replay_records the walk over the bytes; and bit 1: bits 4..15
+                       * hold icao_hash (src/icao_filter.rs:19-43) of the value the message's DF asks the
+                       * filter about -- the residual for DF 0,4,5,16,20,21,24-31, else the address */
 } adsb_trial;
 
 /* Carry-over mode -- opt-in and NOT the reference's semantics.  dump1090_rs starts every
@@ -250,6 +252,10 @@ int adsb_selftest_mag_digest(adsb_ctx *ctx, uint32_t first_bits, uint32_t count,
                              uint64_t *sum_out, uint64_t *xor_out);
 
 int adsb_get_stats(const adsb_ctx *ctx, adsb_stats *out);
+/* Diagnostic: how many collected passes handed the host their trial records out of
+ * (buffer, j, try_phase) order, so that the host replay had to sort them first.  Passes of more
+ * than 16 buffers are put in order on the device; small passes and the overflow fallback are not. */
+uint64_t adsb_host_sorts(const adsb_ctx *ctx);
 const char *adsb_strerror(int status);
 /* Text of the last HIP failure on this context ("" if none). */
 const char *adsb_last_error(const adsb_ctx *ctx);

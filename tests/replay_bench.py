@@ -20,7 +20,7 @@ rec=alltr[sel]
 reps=int(17000/len(rec))+1
 big=np.concatenate([rec]*reps)
 for i in range(reps): big['chunk'][i*len(rec):(i+1)*len(rec)] += 32*i
-rng=np.random.default_rng(1); big=big[rng.permutation(len(big))]
+rng=np.random.default_rng(1); big=big[rng.permutation(len(big))] if "--shuffle" in sys.argv else big[np.lexsort((big["j_tp"]>>24, big["j_tp"]&0xFFFFFF, big["chunk"]))]
 out=(AdsbMsg*(1<<20))(); nout=C.c_size_t()
 for _ in range(3):
     table=np.zeros(4096,np.uint32); r=big.copy()

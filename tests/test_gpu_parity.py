@@ -273,8 +273,10 @@ def test_full_256mib_buffer_bit_exact(hip_lib, oracle_mod, n_bursts):
         c.icao_flush()
         got = c.demod_iq_device(t.data_ptr(), n, cap=1 << 20)
         s = c.stats()
+        host_sorts = c._L.adsb_host_sorts(c._h)
     assert_same(got, want)
     assert s["n_candidates"] == st.quiet_pass and s["retries"] == 0
+    assert host_sorts == 0     # the device handed the records over in replay order
     injected = {b.frame for b in synth.plan_bursts(n, n_bursts)}
     assert len(injected & {w["buffer"] for w in want}) >= 0.95 * len(injected)
 
