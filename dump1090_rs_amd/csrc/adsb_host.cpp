@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -137,6 +138,9 @@ struct adsb_ctx {
     // the messages of a call whose `out` was too small (ADSB_ERR_CAPACITY): the pass is consumed
     // and the filter has moved on, so they are kept for adsb_fetch_messages
     uint64_t host_sorts = 0;  // passes whose records the host had to put in order itself
+#ifdef ADSB_TUNING
+    double t_wait = 0, t_replay = 0, t_enqueue = 0;  // host seconds (ADSB_HOST_TIMES prints them at destroy)
+#endif
     std::vector<adsb_msg> undelivered;
     bool has_undelivered = false;
 };
@@ -388,7 +392,13 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
 // (caller re-runs in smaller pieces), 0 on success, < 0 on error.
 int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out)
 {
+#ifdef ADSB_TUNING
+    const auto tw0 = std::chrono::steady_clock::now();
+#endif
     HIP_TRY(c, hipEventSynchronize(sl.done));
+#ifdef ADSB_TUNING
+    c->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+#endif
     if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
         c->last_error = "pass completed without publishing its summary";
         return ADSB_ERR_HIP;
@@ -423,7 +433,13 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     st.n_ap_entries += sl.h_sum->n_ap_total;
     st.n_records += n;
     static const bool skip_replay = tuning_env("ADSB_SKIP_REPLAY") != nullptr;  // measurement aid (tuning build only)
+#ifdef ADSB_TUNING
+    const auto tr0 = std::chrono::steady_clock::now();
+#endif
     if (!skip_replay) replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out, &c->host_sorts);
+#ifdef ADSB_TUNING
+    c->t_replay += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+#endif
     return 0;
 }
 
@@ -513,8 +529,14 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bo
     if (n_chunks == 0 || n_chunks > kMaxChunks || n_chunks > c->max_chunks) return ADSB_ERR_INVALID;
     Slot &sl = c->slot[c->submitted % kSlots];
     if (sl.busy || c->shard_active) return ADSB_ERR_BUSY;
+#ifdef ADSB_TUNING
+    const auto te0 = std::chrono::steady_clock::now();
+#endif
     int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks, inline_tail, false, true, false,
                           input_done);
+#ifdef ADSB_TUNING
+    c->t_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
+#endif
     if (rc) return rc;
     sl.busy = true;
     c->submitted++;
@@ -727,6 +749,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
 void adsb_destroy(adsb_ctx *c)
 {
     if (!c) return;
+#ifdef ADSB_TUNING
+    if (tuning_env("ADSB_HOST_TIMES"))
+        std::fprintf(stderr, "host times over %llu passes: enqueue %.1f us, wait %.1f us, replay %.1f us per pass\n",
+                     (unsigned long long)c->collected, 1e6 * c->t_enqueue / (c->collected ? c->collected : 1),
+                     1e6 * c->t_wait / (c->collected ? c->collected : 1), 1e6 * c->t_replay / (c->collected ? c->collected : 1));
+#endif
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto &pair : c->scan_ev)
