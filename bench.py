@@ -1,28 +1,33 @@
 """bench.py -- headline benchmark of the demod_2400 hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sparse|dense]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sparse|dense|stream|shard]
 
-A step = one pass of the hot path (icao_flush + to_mag + demodulate2400 per
-131072-sample buffer, the unit of reference benches/demod_benchmark.rs:7-12) over one
-256 MiB synthetic 2.4 MSPS i16 IQ buffer (512 buffers' worth) that is already resident
-in HBM: scan kernel -> match kernel -> record kernel -> D2H of the trial records ->
-ordered host replay -> ModeSMessage list on the host.  Nothing is skipped inside
-the timed region.  The bench rotates over several distinct 256 MiB buffers so that a
-step never re-reads data the 256 MiB Infinity Cache still holds.
+A step = one pass of the hot path over one 256 MiB synthetic 2.4 MSPS i16 IQ buffer (512
+131072-sample buffers) that is already resident in HBM: ONE icao_flush per step, then what the
+reference does per buffer (to_mag + demodulate2400, benches/demod_benchmark.rs:10-11) for all 512
+-- scan kernel -> match -> order -> records -> ordered host replay -> ModeSMessage list on the host.
+Nothing is skipped inside the timed region.  The bench rotates over several distinct 256 MiB
+buffers so that a step never re-reads data the 256 MiB Infinity Cache still holds.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank demodulates its
-own buffers as an independent stream -- the path shards by buffer with no data-path
-collective (BASELINE.json north_star); torch.distributed is used for the barrier
-and the max-over-ranks time only.  Weak scaling: per-GPU work is fixed.
+--gpus N > 1: one rank per GPU.  A plain `python bench.py --gpus N` starts the N ranks itself
+(torch.distributed.run, before this process has touched a GPU); under torch.distributed.run it
+is simply rank RANK.  Every rank demodulates its own buffers as an independent stream -- the path
+shards by buffer with no data-path collective (BASELINE.json north_star); torch.distributed is
+used for the barrier and the max-over-ranks time only.  Weak scaling: per-GPU work is fixed.
+--workload shard (BASELINE config 4): ONE capture of N x 512 buffers cut into contiguous ranges,
+one per rank; the merged frame list is checked against the single-stream result.
 
-Prints ONE JSON line on rank 0.
+At N = 1 the line also carries, under "also", short legs for the other BASELINE configs
+(1: the reference's `cargo bench` case, 3: streaming ring, 5: dense input), each with its own
+parity flag.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,344 +39,66 @@ if str(ROOT) not in sys.path:
 CHUNK = 131072
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 BYTES_PER_SAMPLE = 4   # algorithmic bytes: one i16 IQ pair read per sample
+PUBLISHED_CONFIG1_MS = 3.6950  # reference README.md:107, bench "01", Intel i7-7700K, 1 thread
+DTYPE = "i16 IQ -> f32 magnitude (exact) -> u16/i32 integer"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["sparse", "dense", "stream"], default="sparse",
+    ap.add_argument("--workload", choices=["sparse", "dense", "stream", "shard"], default="sparse",
                     help="sparse: 64 DF17 bursts per 256 MiB (BASELINE config 2); "
                          "dense: 5000 bursts (config 5); stream: host-resident IQ through the "
-                         "pinned double-buffered ring, H2D inside the timed region (config 3)")
-    ap.add_argument("--chunks", type=int, default=512, help="131072-sample buffers per step")
+                         "pinned double-buffered ring, H2D inside the timed region (config 3); "
+                         "shard: one capture of N x --chunks buffers cut into contiguous ranges (config 4)")
+    ap.add_argument("--chunks", type=int, default=512, help="131072-sample buffers per step (and per GPU)")
     ap.add_argument("--buffers", type=int, default=3, help="distinct IQ buffers rotated over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short legs for BASELINE configs 1, 3 and 5")
     ap.add_argument("--timed-profiling", type=int, default=1,
                     help="HIP-event level inside the timed region (1 = scan kernel stamped by its "
                          "own launch; 0 = none, then roofline numbers come from the untimed repeat)")
     ap.add_argument("--depth", type=int, default=3,
                     help="passes in flight in the pipelined form (<= ADSB_MAX_IN_FLIGHT = 3): with 3 the "
                          "next scan is always queued on the device while the host collects")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test (no GPU, no measurement): the ranks rendezvous over gloo, "
+                         "barrier, and rank 0 prints a line that says so")
     ap.add_argument("--sync", action="store_true",
-                    help="one blocking adsb_demod_iq_device call per step instead of the two-deep "
+                    help="one blocking adsb_demod_iq_device call per step instead of the "
                          "submit/collect pipeline")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                     "(one rank per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the demod_2400 path has no CPU fallback")
-    # (ADSB_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than
-    # ranks: ranks then share devices and the timing reduction goes over CPU tensors)
-    backend = os.environ.get("ADSB_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-
-    from dump1090_rs_amd import Context, synth
-    from dump1090_rs_amd._lib import AdsbMsg
-
-    if args.workload == "stream":
-        return stream_bench(args, torch, dist, rank, world, local_rank)
-
-    n = args.chunks * CHUNK
-    n_bursts = 64 if args.workload == "sparse" else 5000
-    n_bursts = max(1, n_bursts * args.chunks // 512)
-    dev = torch.device("cuda", local_rank)
-    # distinct data per rank and per buffer: seed differs
-    bufs = [synth.make_iq_torch(n, n_bursts=n_bursts, seed=synth.SEED_DEFAULT + 1000 * rank + b, device=dev)
-            for b in range(args.buffers)]
-    torch.cuda.synchronize()
-
-    ctx = Context(device=local_rank, max_chunks=args.chunks)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    cap = 1 << 20
-    out = (AdsbMsg * cap)()
-
-    def run_steps(first: int, count: int, level: int):
-        """`count` steps starting at step index `first`.  Returns (frames, summed stats).
-        A step is icao_flush (benches/demod_benchmark.rs:9) + the whole pass over one buffer.
-        Pipelined form: step i is submitted before step i-1 is collected, so the host part
-        of one step (wait, copy-back, ordered replay) overlaps the device scan of the next;
-        every step's full work still happens inside the loop."""
-        ctx.set_profiling(level)
-        tot = {"ms_scan": 0.0, "ms_scan_exclusive": 0.0, "ms_match": 0.0, "ms_records": 0.0, "ms_total_device": 0.0}
-        frames = 0
-
-        def account():
-            st = ctx.stats_raw()
-            for k in tot:
-                tot[k] += getattr(st, k)
-
-        for i in range(count):
-            b = bufs[(first + i) % len(bufs)]
-            ctx.icao_flush()
-            if args.sync:
-                frames += ctx.demod_iq_device_raw(b.data_ptr(), n, out, cap)
-                account()
-            else:
-                ctx.submit_iq_device(b.data_ptr(), n)
-                if i >= args.depth - 1:
-                    frames += ctx.collect_raw(out, cap)
-                    account()
-        if not args.sync:
-            for _ in range(min(count, args.depth - 1)):
-                frames += ctx.collect_raw(out, cap)
-                account()
-        return frames, tot
-
-    run_steps(0, args.warmup, 1)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Timed region: K steps with HIP events around the scan kernel only (level 1), recorded
-    # by the library on the stream the kernels run on.
-    fence()
-    t0 = time.perf_counter()
-    frames, tot = run_steps(args.warmup, args.steps, args.timed_profiling)
-    fence()
-    elapsed = time.perf_counter() - t0
-    scan_ms = tot["ms_scan"]
-    stats = ctx.stats()
-
-    # untimed: the same steps once more with an event after every kernel, for the split
-    _, tot2 = run_steps(args.warmup, args.steps, 2)
-    if args.timed_profiling == 0:
-        scan_ms = tot2["ms_scan"]
-    match_ms, rec_ms, dev_ms = tot2["ms_match"], tot2["ms_records"], tot2["ms_total_device"]
-    ctx.set_profiling(1)
-
-    if dist is not None:
-        from dump1090_rs_amd import sharding
-        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device=dev if backend == "nccl" else "cpu")
-
-    total_samples = n * args.steps * world
-    msps = total_samples / elapsed / 1e6
-    scan_avg_s = scan_ms / args.steps / 1e3
-    achieved = BYTES_PER_SAMPLE * n / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-
-    result = {
-        "metric": "IQ Msamples/s demodulated",
-        "value": round(msps, 1),
-        "unit": "Msamples/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "i16 IQ -> f32 magnitude (exact) -> u16/i32 integer",
-        "data": "synthetic",
-        "frames_per_s": round(frames / elapsed, 1),
-        "frames_per_step": frames // max(1, args.steps * world),
-        "config": {
-            "workload": f"{args.chunks} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB synthetic 2.4 MSPS "
-                        f"i16 IQ resident in HBM, {n_bursts} injected Mode-S bursts ({args.workload}), "
-                        f"icao_flush + to_mag + demodulate2400 per buffer, {args.buffers} distinct buffers rotated",
-            "per_gpu_samples_per_step": n,
-            "sharding": "independent stream per GPU, no collectives",
-            "host_api": "blocking adsb_demod_iq_device per step" if args.sync else
-                        f"adsb_submit_iq_device / adsb_collect, {args.depth} passes in flight",
-            "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_match -> k_records -> host replay",
-            "library": "",
-        },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
-            "kernel": "k_scan_fast",
-            "kernel_avg_ms": round(scan_ms / args.steps, 4),
-            "kernel_exclusive_avg_ms": round(tot["ms_scan_exclusive"] / args.steps, 4),
-            "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
-            "other_kernels_avg_ms": {"k_match": round(match_ms / args.steps, 4),
-                                     "k_records": round(rec_ms / args.steps, 4)},
-            "device_chain_avg_ms": round(dev_ms / args.steps, 4),
-            # consecutive pipelined launches overlap by about one tile round (two scan streams):
-            # a launch's own duration then includes time it shared the GPU with its neighbour;
-            # the rate the GPU sustains over whole steps is bytes / ms_per_step
-            "launches_overlap": not args.sync,
-            "achieved_over_steps": round(BYTES_PER_SAMPLE * n * args.steps / elapsed / 1e9, 1),
-        },
-        "device_stats_last_step": {k: stats[k] for k in
-                                   ("n_candidates", "n_ap_entries", "n_records", "n_messages", "retries")},
-    }
-    from dump1090_rs_amd import _lib
-    result["config"]["library"] = _lib.lib().adsb_version().decode()
-    traffic_file = ROOT / "profiles" / "scan_hbm_traffic.json"
-    if traffic_file.exists():
-        try:
-            tf = json.loads(traffic_file.read_text())
-            if tf.get("library") == result["config"]["library"] and tf.get("chunks") == args.chunks:
-                result["roofline"]["traffic"] = tf.get("bytes_per_launch")
-                result["roofline"]["traffic_source"] = tf.get("source")
-        except Exception:
-            pass
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the C restatement of the reference (oracle/, "port"), one thread,
-        # on the host cores of this box, over buffer 0 of the same workload.  Also the
-        # parity gate of this run: the GPU output for that buffer must be identical.
-        from oracle import binding
-        host = bufs[0].cpu().numpy()
-        orc = binding.Oracle()
-        orc.icao_flush()
-        c0 = time.perf_counter()
-        want, _ = orc.demod_iq(host, cap=cap)
-        cpu_s = time.perf_counter() - c0
-        # the same buffer over all host cores (workers per buffer + ordered replay, SURVEY 8d-ii)
-        n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), args.chunks))
-        mt_s = None
-        if n_thr > 1:
-            orc_mt = binding.Oracle()
-            orc_mt.icao_flush()
-            orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
-            orc_mt.icao_flush()
-            c0 = time.perf_counter()
-            want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr)
-            mt_s = time.perf_counter() - c0
-            if want_mt != want:
-                raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
-        ctx.icao_flush()
-        got = ctx.demod_iq_device(bufs[0].data_ptr(), n, cap=cap)
-        same = [(m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level) for m in got] == \
-               [(w["chunk"], w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"]) for w in want]
-        result["cpu_baseline"] = {
-            "value": round(n / cpu_s / 1e6, 2),
-            "unit": "Msamples/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": f"buffer 0 of the workload, all {args.chunks} x 131072 samples once, {cpu_s:.2f} s; "
-                      "C restatement of dump1090_rs (oracle/), not the Rust binary",
-            "cpu": _cpu_model(),
-            "host_cores_available": os.cpu_count(),
-        }
-        if mt_s:
-            result["cpu_baseline"]["all_cores"] = {
-                "value": round(n / mt_s / 1e6, 2), "unit": "Msamples/s", "cores": n_thr,
-                "sample": f"the same buffer, {n_thr} threads over the 131072-sample buffers + ordered replay, {mt_s:.2f} s"}
-        result["parity_checked"] = bool(same)
-        result["parity_frames"] = len(want)
-        if not same:
-            result["parity_error"] = "GPU frame list differs from the CPU oracle"
-
-    ctx.close()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0 and result.get("parity_checked") is False:
-        sys.exit(3)
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run.
+    Nothing in THIS process has touched a GPU (torch is not even imported), it only waits for the
+    children and hands rank 0's JSON line on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    elif proc.stdout:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if proc.returncode else (0 if line is not None else 1)
 
 
-def stream_bench(args, torch, dist, rank, world, local_rank):
-    """BASELINE config 3: sustained rate with the IQ starting in host memory.  A step = one
-    ring slot of --chunks buffers (default here 64 = 32 MiB): adsb_ring_submit starts its
-    pinned H2D copy on the copy stream and the pass behind it; the other slot's pass runs
-    meanwhile.  No icao_flush between steps (the live loop of main.rs never flushes).  The
-    ring buffers are filled once, outside the timed region (an SDR driver would DMA into them)."""
-    from dump1090_rs_amd import Context, synth
-    from dump1090_rs_amd._lib import AdsbMsg
-
-    chunks = args.chunks if args.chunks != 512 else 64
-    n = chunks * CHUNK
-    ctx = Context(device=local_rank, max_chunks=chunks)
-    ctx.ring_create(n)
-    cap = 1 << 18
-    out = (AdsbMsg * cap)()
-    ctx.icao_flush()
-    for k in range(2):  # fill both pinned slots (and warm up)
-        buf = ctx.ring_acquire()
-        buf[:] = synth.make_iq(n, n_bursts=max(1, 64 * chunks // 512), seed=synth.SEED_DEFAULT + 7 * rank + k)
-        ctx.ring_submit(n)
-        ctx.collect_raw(out, cap)
-    for _ in range(args.warmup):
-        ctx.ring_acquire()
-        ctx.ring_submit(n)
-        ctx.collect_raw(out, cap)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    ctx.set_profiling(1)
-    frames, scan_ms = 0, 0.0
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ctx.ring_acquire()
-        ctx.ring_submit(n)
-        if i > 0:
-            frames += ctx.collect_raw(out, cap)
-            scan_ms += ctx.stats_raw().ms_scan
-    frames += ctx.collect_raw(out, cap)
-    scan_ms += ctx.stats_raw().ms_scan
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        from dump1090_rs_amd import sharding
-        gloo = os.environ.get("ADSB_BENCH_BACKEND", "nccl") != "nccl"
-        elapsed, frames = sharding.reduce_timing(dist, elapsed, frames, device="cpu" if gloo else torch.device("cuda", local_rank))
-    from dump1090_rs_amd import _lib
-    msps = n * args.steps * world / elapsed / 1e6
-    scan_avg_s = scan_ms / args.steps / 1e3
-    achieved = BYTES_PER_SAMPLE * n / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-    result = {
-        "metric": "IQ Msamples/s demodulated", "value": round(msps, 1), "unit": "Msamples/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i16 IQ -> f32 magnitude (exact) -> u16/i32 integer", "data": "synthetic",
-        "frames_per_s": round(frames / elapsed, 1),
-        "config": {"workload": f"streaming ring: {chunks} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB per slot, "
-                               "host-resident IQ, pinned double-buffered hipMemcpyAsync inside the timed region "
-                               "(BASELINE config 3)",
-                   "h2d_GBps": round(BYTES_PER_SAMPLE * n * args.steps / elapsed / 1e9, 2),
-                   "library": _lib.lib().adsb_version().decode()},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_scan_fast",
-                     "kernel_avg_ms": round(scan_ms / args.steps, 4),
-                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
-                     "note": "PCIe-fed: the scan kernel idles between transfers; value is the sustained end-to-end rate"},
-    }
-    ctx.close()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+def _median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
 
 
 def _cpu_model() -> str:
@@ -382,6 +109,562 @@ def _cpu_model() -> str:
     except OSError:
         pass
     return "unknown"
+
+
+def _same(got, want) -> bool:
+    return [(m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level) for m in got] == \
+           [(w["chunk"], w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"]) for w in want]
+
+
+class Env:
+    """Rank / device / process group of this process."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the demod_2400 path has no CPU fallback")
+        # (ADSB_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than
+        # ranks: ranks then share devices and the timing reduction goes over CPU tensors)
+        self.backend = os.environ.get("ADSB_BENCH_BACKEND", "nccl")
+        if self.backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend=self.backend)
+            self.dist = dist
+        self.reduce_device = self.dev if self.backend == "nccl" else "cpu"
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, elapsed, frames):
+        if self.dist is None:
+            return elapsed, frames
+        from dump1090_rs_amd import sharding
+        return sharding.reduce_timing(self.dist, elapsed, frames, device=self.reduce_device)
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2: bool = True):
+    """The device-resident pass loop (BASELINE configs 2 and 5).  Returns a dict of raw numbers and
+    keeps the context / buffers alive in it for the parity leg."""
+    torch = env.torch
+    from dump1090_rs_amd import Context, synth
+    from dump1090_rs_amd._lib import AdsbMsg
+
+    n = args.chunks * CHUNK
+    n_bursts = 64 if workload == "sparse" else 5000
+    n_bursts = max(1, n_bursts * args.chunks // 512)
+    # distinct data per rank and per buffer: the seed differs
+    bufs = [synth.make_iq_torch(n, n_bursts=n_bursts, seed=synth.SEED_DEFAULT + 1000 * env.rank + b, device=env.dev)
+            for b in range(args.buffers)]
+    torch.cuda.synchronize()
+    ctx = Context(device=env.local_rank, max_chunks=args.chunks)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cap = 1 << 20
+    out = (AdsbMsg * cap)()
+    depth = max(1, min(3, args.depth))
+
+    def run_steps(first: int, count: int, level: int):
+        """`count` steps starting at step index `first`.  A step is ONE icao_flush
+        (benches/demod_benchmark.rs:9 flushes per call) + the whole pass over one 256 MiB buffer.
+        Pipelined form: step i is submitted before step i - (depth-1) is collected, so the host part
+        of one step (wait, ordered replay) overlaps the device scans of the next; every step's full
+        work still happens inside the loop.  Returns frames, summed stats, collect timestamps."""
+        ctx.set_profiling(level)
+        tot = {"ms_scan": 0.0, "ms_scan_exclusive": 0.0, "ms_match": 0.0, "ms_records": 0.0, "ms_total_device": 0.0}
+        frames, stamps = 0, []
+
+        def account():
+            st = ctx.stats_raw()
+            for k in tot:
+                tot[k] += getattr(st, k)
+            stamps.append(time.perf_counter())
+
+        for i in range(count):
+            b = bufs[(first + i) % len(bufs)]
+            ctx.icao_flush()
+            if args.sync:
+                frames += ctx.demod_iq_device_raw(b.data_ptr(), n, out, cap)
+                account()
+            else:
+                ctx.submit_iq_device(b.data_ptr(), n)
+                if i >= depth - 1:
+                    frames += ctx.collect_raw(out, cap)
+                    account()
+        if not args.sync:
+            for _ in range(min(count, depth - 1)):
+                frames += ctx.collect_raw(out, cap)
+                account()
+        return frames, tot, stamps
+
+    run_steps(0, warmup, 1)
+    # Timed region: K steps with HIP events around the scan kernel only (level 1), stamped by the
+    # scan launch itself on the stream it runs on.
+    env.fence()
+    t0 = time.perf_counter()
+    frames, tot, stamps = run_steps(warmup, steps, args.timed_profiling)
+    env.fence()
+    elapsed = time.perf_counter() - t0
+    stats = ctx.stats()
+    tot2 = None
+    if level2:  # untimed: the same steps once more with an event after every kernel, for the split
+        _, tot2, _ = run_steps(warmup, steps, 2)
+        if args.timed_profiling == 0:
+            tot = tot2
+    ctx.set_profiling(1)
+    # step-to-step intervals between consecutive collects (steady state of the pipeline)
+    iv = [b - a for a, b in zip(stamps, stamps[1:])]
+    return {"ctx": ctx, "bufs": bufs, "n": n, "n_bursts": n_bursts, "cap": cap, "frames": frames, "elapsed": elapsed,
+            "tot": tot, "tot2": tot2, "stats": stats, "intervals": iv, "depth": depth}
+
+
+def parity_leg(r, chunks: int):
+    """CPU baseline on buffer 0 (the C restatement of the reference, 1 thread and all threads) and
+    the parity gate: the GPU frame list for that buffer must be identical."""
+    from oracle import binding
+    ctx, bufs, n, cap = r["ctx"], r["bufs"], r["n"], r["cap"]
+    host = bufs[0].cpu().numpy()
+    orc = binding.Oracle()
+    orc.icao_flush()
+    c0 = time.perf_counter()
+    want, _ = orc.demod_iq(host, cap=cap)
+    cpu_s = time.perf_counter() - c0
+    n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), chunks))
+    mt_s = None
+    if n_thr > 1:
+        orc_mt = binding.Oracle()
+        orc_mt.icao_flush()
+        orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
+        orc_mt.icao_flush()
+        c0 = time.perf_counter()
+        want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr)
+        mt_s = time.perf_counter() - c0
+        if want_mt != want:
+            raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
+    ctx.icao_flush()
+    got = ctx.demod_iq_device(bufs[0].data_ptr(), n, cap=cap)
+    base = {
+        "value": round(n / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "sample": f"buffer 0 of the workload, all {chunks} x 131072 samples once, {cpu_s:.2f} s; "
+                  "C restatement of dump1090_rs (oracle/), not the Rust binary",
+        "cpu": _cpu_model(), "host_cores_available": os.cpu_count(),
+    }
+    if mt_s:
+        base["all_cores"] = {"value": round(n / mt_s / 1e6, 2), "unit": "Msamples/s", "cores": n_thr,
+                             "sample": f"the same buffer, {n_thr} threads over the 131072-sample buffers + "
+                                       f"ordered replay, {mt_s:.2f} s"}
+    return base, _same(got, want), len(want)
+
+
+def resident_result(env: Env, args, r, workload: str):
+    from dump1090_rs_amd import _lib
+    n, steps = r["n"], args.steps
+    elapsed, frames = env.reduce(r["elapsed"], r["frames"])
+    tot, tot2 = r["tot"], r["tot2"] or r["tot"]
+    own_ms = tot["ms_scan"] / steps
+    # Consecutive pipelined scans overlap (the next one's workgroups fill the CUs as the previous grid
+    # drains, and with three passes in flight the next launch is dispatched while its predecessor still
+    # runs): a launch's own start-to-stop time then counts the shared stretch twice.  The device time
+    # per launch is the union of the launches' intervals / launches = ms_scan_exclusive.
+    excl_ms = tot["ms_scan_exclusive"] / steps
+    kernel_ms = own_ms if args.sync else excl_ms
+    achieved = BYTES_PER_SAMPLE * n / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else 0.0
+    iv = r["intervals"]
+    result = {
+        "metric": "IQ Msamples/s demodulated",
+        "value": round(n * steps * env.world / elapsed / 1e6, 1),
+        "unit": "Msamples/s",
+        "n_gpus": env.world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "ms_per_step_median": round(_median(iv) * 1e3, 4) if iv else None,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": DTYPE,
+        "data": "synthetic",
+        "frames_per_s": round(frames / elapsed, 1),
+        "frames_per_step": frames // max(1, steps * env.world),
+        "config": {
+            "workload": f"{args.chunks} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB synthetic 2.4 MSPS "
+                        f"i16 IQ resident in HBM, {r['n_bursts']} injected Mode-S bursts ({workload}); a step = one "
+                        f"icao_flush + (to_mag + demodulate2400 per buffer) over all {args.chunks} buffers, "
+                        f"{args.buffers} distinct 256 MiB buffers rotated",
+            "per_gpu_samples_per_step": n,
+            "sharding": "independent stream per GPU, no collectives",
+            "host_api": "blocking adsb_demod_iq_device per step" if args.sync else
+                        f"adsb_submit_iq_device / adsb_collect, {r['depth']} passes in flight",
+            "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_match -> "
+                       "k_order_* -> k_records -> host replay",
+            "library": _lib.lib().adsb_version().decode(),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "kernel": "k_scan_fast",
+            "kernel_avg_ms": round(kernel_ms, 4),
+            "kernel_avg_ms_is": "launch start -> stop (launches do not overlap)" if args.sync else
+                                "device time per launch: union of the overlapping launches' intervals / launches "
+                                "(HIP events stamped by the launches; adsb_stats.ms_scan_exclusive)",
+            "kernel_own_duration_avg_ms": round(own_ms, 4),
+            "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+            "other_kernels_avg_ms": {"k_match_and_order": round(tot2["ms_match"] / steps, 4),
+                                     "k_records": round(tot2["ms_records"] / steps, 4)},
+            "device_chain_avg_ms": round(tot2["ms_total_device"] / steps, 4),
+            "launches_overlap": not args.sync,
+            "achieved_over_steps": round(BYTES_PER_SAMPLE * n * steps / r["elapsed"] / 1e9, 1),
+        },
+        "device_stats_last_step": {k: r["stats"][k] for k in
+                                   ("n_candidates", "n_ap_entries", "n_records", "n_messages", "retries")},
+    }
+    traffic_file = ROOT / "profiles" / "scan_hbm_traffic.json"
+    if traffic_file.exists():
+        try:
+            tf = json.loads(traffic_file.read_text())
+            if tf.get("library") == result["config"]["library"] and tf.get("chunks") == args.chunks:
+                result["roofline"]["traffic"] = tf.get("bytes_per_launch")
+                result["roofline"]["traffic_source"] = tf.get("source")
+        except Exception:
+            pass
+    return result
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 3: streaming ring
+# ------------------------------------------------------------------------------------------------
+def run_stream(env: Env, chunks: int, steps: int, warmup: int, min_seconds: float = 0.0, check=False):
+    """Sustained rate with the IQ starting in pinned host memory.  A step = one ring slot of `chunks`
+    buffers: adsb_ring_submit starts its H2D copy on the copy stream and the pass behind it while the
+    other slots' passes run.  No icao_flush between steps (the live loop of main.rs never flushes).
+    The ring buffers are filled once, outside the timed region (an SDR driver would DMA into them)."""
+    from dump1090_rs_amd import Context, synth
+    from dump1090_rs_amd._lib import AdsbMsg
+
+    n = chunks * CHUNK
+    ctx = Context(device=env.local_rank, max_chunks=chunks)
+    ctx.ring_create(n)
+    cap = 1 << 18
+    out = (AdsbMsg * cap)()
+    ctx.icao_flush()
+    slots = 3
+    host_copies = []
+    for k in range(slots):  # fill every pinned slot (and warm up)
+        buf = ctx.ring_acquire()
+        buf[:] = synth.make_iq(n, n_bursts=max(1, 64 * chunks // 512), seed=synth.SEED_DEFAULT + 7 * env.rank + k)
+        if check:
+            host_copies.append(buf.copy())
+        ctx.ring_submit(n)
+        ctx.collect_raw(out, cap)
+    parity = None
+    if check:
+        # the same bytes through the CPU oracle as one stream: slot 0, 1, 2 and then slot 0 again
+        from oracle import binding
+        orc = binding.Oracle()
+        orc.icao_flush()
+        for hc in host_copies:
+            orc.demod_iq(hc, cap=cap)
+        want, _ = orc.demod_iq(host_copies[0], cap=cap)
+        ctx.ring_acquire()
+        ctx.ring_submit(n)
+        got = ctx.collect(cap=cap)
+        parity = _same(got, want)
+        for _ in range(slots - 1):  # back to slot 0 being next
+            ctx.ring_acquire()
+            ctx.ring_submit(n)
+            ctx.collect_raw(out, cap)
+    for _ in range(warmup):
+        ctx.ring_acquire()
+        ctx.ring_submit(n)
+        ctx.collect_raw(out, cap)
+    ctx.set_profiling(1)
+    frames, scan_ms, done = 0, 0.0, 0
+    env.fence()
+    t0 = time.perf_counter()
+    i = 0
+    while True:
+        ctx.ring_acquire()
+        ctx.ring_submit(n)
+        i += 1
+        if i >= 3:  # three passes in flight (ADSB_MAX_IN_FLIGHT): the ring has as many slots
+            frames += ctx.collect_raw(out, cap)
+            scan_ms += ctx.stats_raw().ms_scan
+            done += 1
+        if i >= steps and (time.perf_counter() - t0) >= min_seconds:
+            break
+    while done < i:
+        frames += ctx.collect_raw(out, cap)
+        scan_ms += ctx.stats_raw().ms_scan
+        done += 1
+    env.fence()
+    elapsed = time.perf_counter() - t0
+    ctx.close()
+    return {"n": n, "steps": i, "elapsed": elapsed, "frames": frames, "scan_ms": scan_ms, "parity": parity}
+
+
+def stream_result(env: Env, args, s):
+    from dump1090_rs_amd import _lib
+    elapsed, frames = env.reduce(s["elapsed"], s["frames"])
+    n, steps = s["n"], s["steps"]
+    scan_avg_s = s["scan_ms"] / steps / 1e3
+    achieved = BYTES_PER_SAMPLE * n / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+    return {
+        "metric": "IQ Msamples/s demodulated", "value": round(n * steps * env.world / elapsed / 1e6, 1),
+        "unit": "Msamples/s", "n_gpus": env.world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "frames_per_s": round(frames / elapsed, 1),
+        "config": {"workload": f"streaming ring: {n // CHUNK} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB per "
+                               "slot, host-resident IQ, pinned hipMemcpyAsync ring inside the timed region "
+                               "(BASELINE config 3)",
+                   "h2d_GBps": round(BYTES_PER_SAMPLE * n * steps / s["elapsed"] / 1e9, 2),
+                   "library": _lib.lib().adsb_version().decode()},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_scan_fast",
+                     "kernel_avg_ms": round(s["scan_ms"] / steps, 4),
+                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+                     "note": "PCIe-fed: the scan kernel idles between transfers; value is the sustained end-to-end rate"},
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 4: one capture cut into contiguous buffer ranges, one per GPU
+# ------------------------------------------------------------------------------------------------
+def run_shard(env: Env, args):
+    """ONE capture of world x --chunks buffers; rank r owns buffers [r*chunks, (r+1)*chunks).  A step =
+    icao_flush + adsb_shard_scan on every rank, a host-side exchange of the addresses the shards
+    learned (a few KB, object collective: not on the data path), adsb_shard_finish, the trial records
+    gathered on rank 0 and replayed once in global (buffer, j, try_phase) order: the reference's loop
+    dump1090_rs/src/main.rs:161-167 over the whole capture.  Checked: the merged frame list equals
+    the single-stream result of rank 0 demodulating the whole capture alone."""
+    torch = env.torch
+    from dump1090_rs_amd import Context, sharding, synth, _lib
+
+    n = args.chunks * CHUNK
+    n_bursts = max(1, 64 * args.chunks // 512)
+
+    def shard_iq(r, device):
+        return synth.make_iq_torch(n, n_bursts=n_bursts, seed=synth.SEED_DEFAULT + 31 * r, device=device)
+
+    mine = shard_iq(env.rank, env.dev)
+    torch.cuda.synchronize()
+    ctx = Context(device=env.local_rank, max_chunks=args.chunks)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        ctx.icao_flush()
+        return sharding.demod_sharded(ctx, mine.data_ptr(), n, env.rank * args.chunks, env.dist)
+
+    for _ in range(args.warmup):
+        step()
+    env.fence()
+    t0 = time.perf_counter()
+    frames = 0
+    stamps = []
+    for _ in range(args.steps):
+        msgs = step()
+        frames += len(msgs) if msgs is not None else 0
+        stamps.append(time.perf_counter())
+    env.fence()
+    elapsed = time.perf_counter() - t0
+    merged = step()
+    # the single-stream answer: rank 0 demodulates the whole capture alone (untimed)
+    same, n_frames = None, None
+    if env.rank == 0:
+        whole = torch.cat([mine] + [shard_iq(r, env.dev) for r in range(1, env.world)]) if env.world > 1 else mine
+        with Context(device=env.local_rank, max_chunks=args.chunks) as solo:
+            solo.icao_flush()
+            want = solo.demod_iq_device(whole.data_ptr(), n * env.world, cap=1 << 20)
+        key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
+        same = [key(m) for m in merged] == [key(m) for m in want]
+        n_frames = len(want)
+        del whole
+    elapsed, frames = env.reduce(elapsed, frames)
+    iv = [b - a for a, b in zip(stamps, stamps[1:])]
+    result = {
+        "metric": "IQ Msamples/s demodulated", "value": round(n * env.world * args.steps / elapsed / 1e6, 1),
+        "unit": "Msamples/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step_median": round(_median(iv) * 1e3, 4) if iv else None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "frames_per_s": round(frames / elapsed, 1),
+        "config": {"workload": f"one capture of {env.world} x {args.chunks} buffers = {env.world * n * 4 // (1 << 20)} MiB "
+                               f"cut into {env.world} contiguous ranges of {args.chunks} buffers, one per GPU, resident in "
+                               "HBM (BASELINE config 4); a step = icao_flush + shard scan on every rank + host-side "
+                               "exchange of learned addresses + match + records gathered and replayed once on rank 0",
+                   "per_gpu_samples_per_step": n,
+                   "sharding": "contiguous buffer ranges, no data-path collective; addresses / records exchanged "
+                               "through the host (torch.distributed object collectives)",
+                   "host_api": "adsb_shard_scan / adsb_shard_finish / adsb_replay_records (blocking, two phases)",
+                   "library": _lib.lib().adsb_version().decode()},
+        "shard_merge_equals_single_stream": same, "parity_frames": n_frames,
+    }
+    ctx.close()
+    return result
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 1: the reference's `cargo bench` case
+# ------------------------------------------------------------------------------------------------
+def run_config1(env: Env):
+    """icao_flush + to_mag + demodulate2400 on test_iq/test_1641427457780.iq (benches/demod_benchmark.rs:
+    7-12), through the reference's two-call API shape and fused, with the CPU oracle (1 thread) beside it."""
+    import numpy as np
+    torch = env.torch
+    from dump1090_rs_amd import Context
+    from oracle import binding
+
+    golden = json.loads((ROOT / "tests" / "golden" / "reference_frames.json").read_text())
+    fx = golden["fixtures"][0]
+    raw = np.fromfile(ROOT / "tests" / "golden" / fx["file"], dtype="<i2").reshape(-1, 2)
+    iq = np.ascontiguousarray(raw[:, ::-1])  # file order is [im][re] (src/utils.rs:29-31)
+    dev = torch.from_numpy(iq).to(env.dev)
+    ctx = Context(env.local_rank, 1)
+
+    def timeit(fn, reps=200):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    def ref_api():
+        ctx.icao_flush()
+        return ctx.demodulate2400(ctx.to_mag(iq))
+
+    def fused_host():
+        ctx.icao_flush()
+        return ctx.demod_iq(iq)
+
+    def fused_dev():
+        ctx.icao_flush()
+        return ctx.demod_iq_device(dev.data_ptr(), len(iq))
+
+    ok = all([m.buffer().hex() for m in f()] == fx["frames"] for f in (ref_api, fused_host, fused_dev))
+    out = {"workload": "icao_flush + to_mag + demodulate2400 on test_1641427457780.iq, 131072 samples "
+                       "(benches/demod_benchmark.rs:7-12; BASELINE config 1)",
+           "ms_to_mag_plus_demodulate2400": round(timeit(ref_api), 4),
+           "ms_fused_host_iq": round(timeit(fused_host), 4),
+           "ms_fused_resident_iq": round(timeit(fused_dev), 4),
+           "frames": len(fx["frames"]), "parity_checked": bool(ok),
+           "published_reference_ms": PUBLISHED_CONFIG1_MS,
+           "published_reference_note": "README.md:107, Intel i7-7700K, 1 thread, the Rust binary (other hardware)"}
+    orc = binding.Oracle()
+    reps, t = 30, time.perf_counter()
+    for _ in range(reps):
+        orc.icao_flush()
+        data, k = orc.to_mag(iq)
+        orc.demodulate2400(data, k)
+    out["cpu_port_1_thread_ms"] = round((time.perf_counter() - t) / reps * 1e3, 4)
+    out["note"] = "one buffer cannot fill the chip (17 tiles for 1024 workgroup slots): these are latencies"
+    ctx.close()
+    return out
+
+
+def dry_run(args) -> int:
+    """What the CPU tests run: the launch + rendezvous path of --gpus N with no device anywhere."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        import torch
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        total = 1
+    if rank == 0:
+        print(json.dumps({"metric": "IQ Msamples/s demodulated", "dry_run": True, "n_gpus": world,
+                          "rank_sum": total, "value": None}), flush=True)
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
+    env = Env(args)
+    args.gpus = env.world
+
+    if args.workload == "stream":
+        chunks = args.chunks if args.chunks != 512 else 64
+        result = stream_result(env, args, run_stream(env, chunks, args.steps, args.warmup))
+    elif args.workload == "shard":
+        result = run_shard(env, args)
+    else:
+        r = run_resident(env, args, args.workload, args.steps, args.warmup)
+        result = resident_result(env, args, r, args.workload)
+        if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"], same, n_frames = parity_leg(r, args.chunks)
+            result["parity_checked"] = bool(same)
+            result["parity_frames"] = n_frames
+            if not same:
+                result["parity_error"] = "GPU frame list differs from the CPU oracle"
+        r["ctx"].close()
+        del r
+        env.torch.cuda.empty_cache()
+        if env.rank == 0 and env.world == 1 and not args.no_also and not args.sync and args.workload == "sparse":
+            also = {}
+            also["config1_cargo_bench_case"] = run_config1(env)
+            s = run_stream(env, 64, 200, 3, min_seconds=2.0, check=True)
+            sr = stream_result(env, args, s)
+            also["config3_streaming_ring"] = {
+                "workload": sr["config"]["workload"], "value": sr["value"], "unit": "Msamples/s",
+                "seconds": round(s["elapsed"], 2), "steps": s["steps"], "ms_per_step": sr["ms_per_step"],
+                "h2d_GBps": sr["config"]["h2d_GBps"], "parity_checked": s["parity"],
+                "note": "PCIe-inclusive (host-resident IQ): never the headline value"}
+            d = run_resident(env, args, "dense", args.steps, args.warmup, level2=False)
+            dr = resident_result(env, args, d, "dense")
+            _, dsame, dframes = parity_leg(d, args.chunks) if not args.no_cpu_baseline else (None, None, None)
+            also["config5_dense"] = {
+                "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
+                "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
+                "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
+                "n_records_last_step": dr["device_stats_last_step"]["n_records"],
+                "parity_checked": dsame, "parity_frames": dframes}
+            d["ctx"].close()
+            result["also"] = also
+
+    if env.rank == 0:
+        print(json.dumps(result), flush=True)
+    env.finish()
+    if env.rank == 0:
+        bad = result.get("parity_checked") is False or result.get("shard_merge_equals_single_stream") is False
+        for leg in (result.get("also") or {}).values():
+            bad = bad or leg.get("parity_checked") is False
+        if bad:
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -170,3 +170,44 @@ def test_two_ranks_exact_merge_equals_single_stream(oracle_mod, hip_lib):
         a, b = sharding.sample_range(n, world, r)
         per_shard += oracle_mod.Oracle().demod_iq(iq[a:b])[0]
     assert len([m for m in per_shard if m["buffer"] == df4]) == 1
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_invocation():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks under
+    torch.distributed.run before touching any device, they rendezvous on 127.0.0.1, and rank 0's
+    single JSON line comes out of the parent (--dry-run: no GPU here, no measurement)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 3 and out["dry_run"] is True
+
+
+def test_bench_parent_process_never_imports_torch_before_launching():
+    """The launching parent must not initialise a GPU runtime (a process that has may not start
+    another program): it does not import torch at all."""
+    import subprocess
+    code = ("import sys, bench; sys.argv=['bench.py','--gpus','2','--dry-run'];\n"
+            "import subprocess as sp\n"
+            "real = sp.run\n"
+            "def fake(cmd, **kw):\n"
+            "    assert 'torch' not in sys.modules, 'torch imported before the ranks were started'\n"
+            "    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd\n"
+            "    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'\n"
+            "    class R: returncode = 0; stdout = '{\"metric\": \"x\"}\\n'\n"
+            "    return R()\n"
+            "sp.run = fake\n"
+            "try:\n"
+            "    bench.main()\n"
+            "except SystemExit as e:\n"
+            "    assert e.code == 0\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
