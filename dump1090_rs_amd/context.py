@@ -198,6 +198,21 @@ class Context:
     def collect(self, cap: int = 1 << 16) -> List[ModeSMessage]:
         return self._collect(lambda out, c, n: self._L.adsb_collect(self._h, out, c, n), "adsb_collect", cap)
 
+    def selftest_stage_lists(self, device_ptr: int, n_samples: int):
+        """adsb_selftest_stage_lists: (candidate positions as buffer << 32 | j, address/parity trials as
+        buffer << 45 | j << 28 | try_phase << 24 | residual), both ascending u64 arrays."""
+        cc, ac = max(4096, n_samples // 16), max(4096, n_samples // 8)
+        while True:
+            cand, ap = np.zeros(cc, dtype=np.uint64), np.zeros(ac, dtype=np.uint64)
+            nc, na = C.c_size_t(), C.c_size_t()
+            st = self._L.adsb_selftest_stage_lists(self._h, C.c_void_p(device_ptr), n_samples, cand.ctypes.data, cc,
+                                                   C.byref(nc), ap.ctypes.data, ac, C.byref(na))
+            if st == _lib.ADSB_ERR_CAPACITY:
+                cc, ac = max(cc, nc.value), max(ac, na.value)
+                continue
+            self._check(st, "adsb_selftest_stage_lists")
+            return cand[: nc.value].copy(), ap[: na.value].copy()
+
     # -- sharded capture: two phases around a host-side exchange of learned addresses
     def shard_scan(self, device_ptr: int, n_samples: int) -> np.ndarray:
         """Phase 1 on this shard: the addresses its clean DF11 / DF17 frames will add (sorted u32)."""

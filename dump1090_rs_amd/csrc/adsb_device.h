@@ -154,6 +154,11 @@ struct ScanParams {
     // (n_chunks + 1) and a second list of hits_cap entries
     uint32_t *order_cnt, *order_base;
     uint64_t *order_tmp;
+    // self-test only (adsb_selftest_stage_lists): every position that passes the gates is also
+    // appended here as chunk << 32 | j; null in every production pass
+    uint64_t *cand_out;
+    uint32_t *cand_count;
+    uint32_t cand_cap;
 };
 
 // The address bitmap: 2^24 bits, followed by a 4096-bit summary (bit a & 4095 is set when any

@@ -1079,6 +1079,99 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
     return ADSB_OK;
 }
 
+int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, uint64_t *cand, size_t cand_cap,
+                              size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap)
+{
+    if (!c || !d_iq || n_samples == 0 || (!cand && cand_cap) || (!ap && ap_cap)) return ADSB_ERR_INVALID;
+    if (c->submitted != c->collected || c->shard_active) return ADSB_ERR_BUSY;
+    if ((uintptr_t)d_iq % 16) return ADSB_ERR_INVALID;
+    const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
+    if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Slot &sl = c->slot[0];
+    const uint32_t dev_cap = (uint32_t)std::min<uint64_t>(n_samples, 1u << 26);  // a list entry per position at most
+    uint64_t *d_cand = nullptr;
+    uint32_t *d_count = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_cand, (size_t)dev_cap * sizeof(uint64_t)));
+    if (hipMalloc((void **)&d_count, sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(d_cand);
+        return ADSB_ERR_NOMEM;
+    }
+    std::vector<uint64_t> cands, aps;
+    int rc = ADSB_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+        ScanParams p{};
+        p.src = d_iq;
+        p.n_samples = n_samples;
+        p.n_chunks = (uint32_t)n_chunks;
+        p.bitmap = c->d_bitmap[c->cur_bitmap];  // learned addresses only widen the superset
+        p.hits = sl.d_hits;
+        p.hits_cap = sl.hits_cap;
+        p.ap = sl.d_ap;
+        p.ap_cap = c->ap_cap;
+        p.seg_cap = c->seg_cap;
+        p.tables = c->d_tables;
+        p.ctr = sl.d_ctr;
+        p.summary = sl.h_sum_dev;
+        p.cand_out = d_cand;
+        p.cand_count = d_count;
+        p.cand_cap = dev_cap;
+        if (int e = launch_scan(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
+        Counters ctr;
+        uint32_t count = 0;
+        HIP_TRY(c, hipMemcpyAsync(&ctr, sl.d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const bool overflow = ctr.overflow != 0 || count > dev_cap;
+        if (!overflow) {
+            cands.resize(count);
+            if (count) HIP_TRY(c, hipMemcpy(cands.data(), d_cand, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            std::sort(cands.begin(), cands.end());
+            const std::vector<uint32_t> tab = build_gf_tables();
+            const uint32_t *x56 = tab.data() + kTabX56 * 256;
+            std::vector<uint64_t> seg(c->seg_cap);
+            for (int g = 0; g < kApWaveSegs; g++) {
+                const uint32_t k = ctr.seg_ap[g];
+                if (!k) continue;
+                HIP_TRY(c, hipMemcpy(seg.data(), sl.d_ap + (size_t)g * c->seg_cap, (size_t)k * sizeof(uint64_t),
+                                     hipMemcpyDeviceToHost));
+                for (uint32_t i = 0; i < k; i++) {
+                    const uint64_t e = seg[i];
+                    const uint32_t code = entry_code(e);
+                    uint32_t v = entry_value(e);
+                    if (code >= 5 && code < 10) v = x56[v & 255u] ^ x56[256 + ((v >> 8) & 255u)] ^ x56[512 + (v >> 16)];
+                    aps.push_back(pack_entry(v, entry_tp(e), entry_j(e), entry_chunk(e)));
+                }
+            }
+            std::sort(aps.begin(), aps.end());
+        }
+        // put the slot back: the records kernel zeroes this pass's counters on its way out
+        p.cand_out = nullptr;
+        sl.seq = c->next_seq++;
+        if (c->next_seq == 0) c->next_seq = 1;
+        sl.h_sum->seq = 0;
+        p.seq = sl.seq;
+        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (overflow) {
+            c->last_error = "selftest: the pass overflowed the fast scan's lists";
+            return ADSB_ERR_HIP;
+        }
+        return ADSB_OK;
+    };
+    rc = body();
+    (void)hipFree(d_cand);
+    (void)hipFree(d_count);
+    if (rc) return rc;
+    if (n_cand) *n_cand = cands.size();
+    if (n_ap) *n_ap = aps.size();
+    if (cands.size() > cand_cap || aps.size() > ap_cap) return ADSB_ERR_CAPACITY;
+    if (!cands.empty()) std::memcpy(cand, cands.data(), cands.size() * sizeof(uint64_t));
+    if (!aps.empty()) std::memcpy(ap, aps.data(), aps.size() * sizeof(uint64_t));
+    return ADSB_OK;
+}
+
 static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors TrialRecord");
 
 // ---------------------------------------------------------------------------------

@@ -396,14 +396,18 @@ __device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint
 
 // One 64-lane pass of the gates: `ent` is this lane's pattern match (valid lanes only count),
 // passing positions are appended to the wave's candidate region.
-__device__ __forceinline__ void gate_pass(const FastLds &s, uint32_t ent, bool valid, uint16_t *wcand,
-                                          uint32_t &ncand_w)
+__device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s, uint32_t ent, bool valid,
+                                          uint16_t *wcand, uint32_t &ncand_w, int jbase, uint32_t chunk)
 {
     const bool pass = (gate_eval(s.mag, ent) & (uint32_t)valid) != 0;
     const unsigned long long mask = __ballot(pass);
     if (mask) {
         if (pass) wcand[mask_rank(mask, ncand_w)] = (uint16_t)(ent & 0x1FFFu);
         ncand_w += (uint32_t)__popcll(mask);
+        if (p.cand_out && pass) {  // self-test only: the candidate list itself (adsb_selftest_stage_lists)
+            const uint32_t at = atomicAdd(p.cand_count, 1u);
+            if (at < p.cand_cap) p.cand_out[at] = (uint64_t)chunk << 32 | (uint32_t)(jbase - kPad + (int)(ent & 0x1FFFu));
+        }
     }
 }
 
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
             // one lane per pattern match (gate_pass)
             {
                 const uint32_t idx = base + (uint32_t)lane;
-                gate_pass(s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, ncand_w);
+                gate_pass(p, s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, ncand_w, jbase, chunk);
             }
             base += 64;
             if (base >= npat_w) {

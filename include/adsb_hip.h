@@ -251,6 +251,18 @@ int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, a
 int adsb_selftest_mag_digest(adsb_ctx *ctx, uint32_t first_bits, uint32_t count,
                              uint64_t *sum_out, uint64_t *xor_out);
 
+/* Device self-test: the intermediate lists of one blocking pass over device-resident IQ, so that a
+ * test can compare stages, not only frames, with the CPU restatement of the reference:
+ *   cand[]  every position the gates let through (check_preamble + 3.5 dB + quiet samples,
+ *           src/demod_2400.rs:127-146), as buffer << 32 | j, ascending;
+ *   ap[]    every address/parity trial (DF 0,4,5,16,20,21,24-31, src/mode_s/mod.rs:56-72,110-135) with
+ *           its CRC residual (src/crc.rs:263-282), as buffer << 45 | j << 28 | try_phase << 24 | residual,
+ *           ascending.
+ * The context's filter is not touched.  ADSB_ERR_CAPACITY with the required counts when a list does
+ * not fit; ADSB_ERR_BUSY while passes are pending. */
+int adsb_selftest_stage_lists(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples, uint64_t *cand,
+                              size_t cand_cap, size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap);
+
 int adsb_get_stats(const adsb_ctx *ctx, adsb_stats *out);
 /* Diagnostic: how many collected passes handed the host their trial records out of
  * (buffer, j, try_phase) order, so that the host replay had to sort them first.  Passes of more

@@ -150,6 +150,65 @@ def demod_iq_carry(orc: "Oracle", iq, carry: np.ndarray, cap: Optional[int] = No
     return [unpack(m) for m in out[:n]], st
 
 
+TRIAL_DTYPE = np.dtype([("power", "<u8"), ("chunk", "<u4"), ("j_tp", "<u4"), ("msg", "u1", (14,)), ("pad", "<u2")])
+AP_DFS = frozenset([0, 4, 5, 16, 20, 21] + list(range(24, 32)))   # src/mode_s/mod.rs:56-72,110-135
+
+
+def all_trials(iq_chunk, chunk: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """(magnitudes, the 5 trial messages of every gate-passing j in (j, try_phase) order) of one buffer."""
+    L = lib()
+    a = as_iq(iq_chunk)
+    mb = OrcMagBuf()
+    if L.orc_to_mag(a.ctypes.data, a.shape[0], C.byref(mb)) != 0:
+        raise IndexError("more than 131072 samples")
+    cap = 5 * 131072
+    buf = np.zeros(cap, dtype=TRIAL_DTYPE)
+    k = L.orc_all_trials(C.byref(mb), chunk, buf.ctypes.data, cap)
+    return np.ctypeslib.as_array(mb.data).copy(), buf[:k].copy()
+
+
+def stage_lists(iq) -> dict:
+    """Stage-level values of the reference algorithm over an IQ stream, buffer by buffer -- what
+    tests/golden/stage_goldens.json freezes and adsb_selftest_stage_lists is compared with:
+      mags        list of u16 arrays (one per buffer)
+      preamble    positions where check_preamble returns Some      (buffer << 32 | j)
+      snr         ... that also pass the 3.5 dB gate (demod_2400.rs:129)
+      cand        ... and the quiet gate (:135-146): the positions that get sliced
+      trials      (buffer, j, try_phase, DF, residual over the message's own length) of all 5 trials of each
+      ap          the address/parity ones as buffer << 45 | j << 28 | try_phase << 24 | residual"""
+    L = lib()
+    a = as_iq(iq)
+    out = {"mags": [], "preamble": [], "snr": [], "cand": [], "trials": [], "ap": []}
+    hi, sig, noise = C.c_int32(), C.c_uint32(), C.c_uint32()
+    for chunk, off in enumerate(range(0, a.shape[0], 131072)):
+        part = np.ascontiguousarray(a[off:off + 131072])
+        data, tr = all_trials(part, chunk)
+        out["mags"].append(data)
+        d = np.ascontiguousarray(data, dtype=np.uint16)
+        base = d.ctypes.data
+        # the quick test of check_preamble (demod_2400.rs:221) first, vectorised: only those j can match
+        n = part.shape[0]
+        quick = np.nonzero((d[0:n] < d[1:n + 1]) & (d[12:n + 12] > d[13:n + 13]))[0]
+        for j in quick:
+            if L.orc_check_preamble(base + 2 * int(j), C.byref(hi), C.byref(sig), C.byref(noise)):
+                out["preamble"].append(chunk << 32 | int(j))
+                if 2 * sig.value >= 3 * noise.value:
+                    out["snr"].append(chunk << 32 | int(j))
+        js = tr["j_tp"] & 0xFFFFFF
+        out["cand"].extend((chunk << 32 | int(j)) for j in np.unique(js))
+        for r in tr:
+            msg = bytes(r["msg"])
+            df = msg[0] >> 3
+            bits = 112 if df & 0x10 else 56
+            res = L.orc_modes_checksum(msg, bits)
+            j, tp = int(r["j_tp"]) & 0xFFFFFF, int(r["j_tp"]) >> 24
+            out["trials"].append((chunk, j, tp, df, res))
+            if df in AP_DFS:
+                out["ap"].append(chunk << 45 | j << 28 | tp << 24 | res)
+    out["ap"].sort()
+    return out
+
+
 def unpack(m: OrcMsg) -> dict:
     return {"msg": bytes(m.msg), "len": int(m.len), "try_phase": int(m.try_phase), "score": int(m.score),
             "j": int(m.j), "chunk": int(m.chunk), "signal_level": float(m.signal_level),

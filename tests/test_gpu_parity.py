@@ -366,6 +366,41 @@ def test_output_array_too_small_loses_nothing_and_does_not_rerun_the_pass(hip_li
         assert_same(c.demod_iq(iq, cap=1), want2)
 
 
+# ----------------------------------------------------------------------------- stages
+def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod, golden, fixture_iq):
+    """Not only frames: the device's magnitudes, the list of positions its gates let through and its
+    address/parity trials (position, try_phase, CRC residual) against tests/golden/stage_goldens.json
+    on the reference captures, and list against list with the oracle on a synthetic stream whose
+    buffers are ragged and carry bursts."""
+    import hashlib
+    import json
+    import zlib
+    import torch
+    from dump1090_rs_amd import Context
+    from tests.conftest import GOLDEN
+    frozen = json.loads((GOLDEN / "stage_goldens.json").read_text())["fixtures"]
+    sha = lambda a: hashlib.sha256(np.asarray(a, dtype="<u8").tobytes()).hexdigest()
+    with Context(0, 8) as c:
+        for fx in golden["fixtures"]:
+            iq = fixture_iq[fx["file"]]
+            want = frozen[fx["file"]]
+            assert zlib.crc32(c.to_mag(iq).data.astype("<u2").tobytes()) == want["mag_crc32"][0]
+            dev = torch.from_numpy(iq).cuda()
+            cand, ap = c.selftest_stage_lists(dev.data_ptr(), len(iq))
+            assert (len(cand), sha(cand)) == (want["n_cand"], want["cand_sha256"])
+            assert (len(ap), sha(ap)) == (want["n_ap"], want["ap_sha256"])
+        n = 5 * 131072 + 7001
+        iq = synth.make_iq(n, n_bursts=60, seed=4242, n_icao=7, df11_every=5)
+        st = oracle_mod.stage_lists(iq)
+        dev = torch.from_numpy(iq).cuda()
+        cand, ap = c.selftest_stage_lists(dev.data_ptr(), n)
+        assert cand.tolist() == st["cand"]
+        assert ap.tolist() == st["ap"]
+        # the context is as it was: a normal call still gives the oracle's frames
+        c.icao_flush()
+        assert_same(c.demod_iq(iq), oracle_mod.Oracle().demod_iq(iq)[0])
+
+
 # ----------------------------------------------------------------------------- pipelined API
 def test_submit_collect_matches_blocking_calls_and_orders_flushes(ctx, oracle_mod):
     """adsb_submit_iq_device / adsb_collect: passes in flight, results in submission

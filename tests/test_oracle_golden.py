@@ -245,3 +245,25 @@ def test_threaded_oracle_matches_single_thread(oracle_mod, fixture_iq):
             assert got == want
             assert (stn.trials, stn.frames, stn.quiet_pass) == (st1.trials, st1.frames, st1.quiet_pass)
         assert len(want) > 0
+
+
+def test_stage_goldens_are_what_the_oracle_computes(golden, fixture_iq):
+    """tests/golden/stage_goldens.json (magnitude checksums, preamble / 3.5 dB / quiet-gate position
+    lists, per-trial CRC residuals, address/parity trials) is regenerated from the oracle and must not
+    have moved; the counts are also the ones SURVEY.md Appendix B derived independently from the
+    reference source before this oracle existed."""
+    import json
+    import importlib.util
+    from tests.conftest import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_stage_goldens", GOLDEN / "make_stage_goldens.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    frozen = json.loads((GOLDEN / "stage_goldens.json").read_text())["fixtures"]
+    survey_b = {"test_1641427457780.iq": (5872, 2769, 1449, 7245, 3152, 65535),
+                "test_1641428165033.iq": (5939, 2696, 1397, 6985, 2960, 43049),
+                "test_1641428106243.iq": (5896, 2701, 1342, 6710, 2943, 54533)}
+    for fx in golden["fixtures"]:
+        now = mod.stage_values(fixture_iq[fx["file"]])
+        assert now == frozen[fx["file"]], fx["file"]
+        assert (now["n_preamble"], now["n_snr"], now["n_cand"], now["n_trials"], now["n_ap"],
+                now["mag_max"][0]) == survey_b[fx["file"]]
