@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     __shared__ alignas(16) TrialRecord stage[kRecBatch];
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
+    unsigned long long my_sum = 0;  // of the u64 words this thread sent to the host
     for (uint32_t b0 = first; b0 < last; b0 += kRecBatch) {
         const uint32_t cnt = min((uint32_t)kRecBatch, last - b0);
         for (uint32_t q = wave; q < cnt; q += 4) {
@@ -337,11 +338,24 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next hit
         }
         __syncthreads();
-        if (threadIdx.x < 2 * cnt)
+        if (threadIdx.x < 2 * cnt) {
             host_store128((char *)(rec + b0) + 16 * threadIdx.x, ((const u32x4_t *)stage)[threadIdx.x]);
+            // (its own read of the two words: the 128-bit value above is only ever an asm operand)
+            const unsigned long long *sw = (const unsigned long long *)stage + 2 * threadIdx.x;
+            my_sum += sw[0] + sw[1];
+        }
         __syncthreads();  // stage is refilled by the next batch
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's records have left
+    // the pass's record checksum (the host recomputes it over what it finds in its memory)
+    if (first < last) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) my_sum += __shfl_down(my_sum, off);
+        if (lane == 0 && my_sum) atomicAdd((unsigned long long *)p.ctr->rec_sum, my_sum);
+        // performed (device scope) before this block reports itself done below; no cache flush: a
+        // __threadfence() here would write back the XCD's L2 under the running scan, once per block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     // The last block to finish totals the counters into the summary for the host -- like the
     // records it goes straight into mapped host memory with write-through stores, so the
@@ -363,15 +377,19 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         }
         if (lane == 0) {
             uint32_t *sm = (uint32_t *)p.summary;
-            const uint32_t vals[8] = {p.ctr->n_hits, p.ctr->overflow, 0u, p.ctr->n_dap,
-                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, 0u, p.seq};
+            const unsigned long long rs = atomicAdd((unsigned long long *)p.ctr->rec_sum, 0ull);
+            const uint32_t vals[8] = {p.ctr->n_hits, p.ctr->overflow, (uint32_t)rs, p.ctr->n_dap,
+                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq};
 #pragma unroll
             for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
         }
     }
     __syncthreads();
     if (p.keep_counters) {  // first phase of a shard: the match still has to see the lists
-        if (threadIdx.x == 0) p.ctr->blocks_done = 0;
+        if (threadIdx.x == 0) {
+            p.ctr->blocks_done = 0;
+            p.ctr->rec_sum[0] = p.ctr->rec_sum[1] = 0;  // the second phase's records kernel starts its own sum
+        }
         return;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) ((uint32_t *)p.ctr)[i] = 0;

@@ -100,7 +100,7 @@ struct Counters {
     uint32_t n_dap;        // entries in the dap list
     uint32_t n_cand_simple;  // candidates seen by the simple kernel (diagnostic)
     uint32_t blocks_done;    // records kernel: blocks that have finished (last one publishes)
-    uint32_t pad[2];
+    uint32_t rec_sum[2];     // records kernel: 64-bit sum of every u64 word of the records it wrote (8-byte aligned)
     uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
 };
@@ -108,10 +108,14 @@ struct Counters {
 // What the host needs after a pass, gathered by the records kernel (the last one to run)
 // so that one small copy brings it back.
 struct Summary {
-    uint32_t n_hits, overflow, reserved0, n_dap;
+    uint32_t n_hits, overflow;
+    uint32_t rec_sum_lo;    // 64-bit sum of every u64 word of the n_hits records (low half): the records and
+                            // this summary reach host memory as separate posted writes -- a record that has
+                            // not landed (or is torn) when the host reads it makes the sums disagree
+    uint32_t n_dap;
     uint32_t n_ap_total;    // all AP entries (fast segments + dap)
     uint32_t n_cand_total;  // all candidates
-    uint32_t pad;
+    uint32_t rec_sum_hi;
     uint32_t seq;           // the pass's sequence number (never 0): lets the host check it reads its own pass
 };
 

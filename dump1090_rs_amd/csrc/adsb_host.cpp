@@ -388,6 +388,25 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     return ADSB_OK;
 }
 
+// The records and the summary travel to host memory as separate posted writes; the summary's
+// sequence word says the pass is done, this says every one of its records has landed whole: the
+// 64-bit sum of all their u64 words, as the records kernel added them up.  (Records that are still
+// in flight when the completion event has fired would be a platform fault: give them a moment,
+// then fail loudly rather than replay something torn.)
+int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size_t n)
+{
+    const uint64_t want = (uint64_t)sum->rec_sum_hi << 32 | sum->rec_sum_lo;
+    for (int attempt = 0; attempt < 200; attempt++) {
+        uint64_t got = 0;
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(rec);
+        for (size_t i = 0; i < 4 * n; i++) got += __atomic_load_n(&w[i], __ATOMIC_RELAXED);
+        if (got == want) return ADSB_OK;
+        for (volatile int spin = 0; spin < 2000; spin++) {}
+    }
+    if (c) c->last_error = "trial records in host memory do not add up to the checksum of the pass that wrote them";
+    return ADSB_ERR_HIP;
+}
+
 // Wait for the pass in `sl` and replay it.  Returns 1 when a device list overflowed
 // (caller re-runs in smaller pieces), 0 on success, < 0 on error.
 int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out)
@@ -405,6 +424,7 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     }
     if (sl.h_sum->overflow) return 1;
     const size_t n = sl.h_sum->n_hits;
+    if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
     if (sl.profiled) {
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
@@ -1220,7 +1240,7 @@ int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, ui
         return ADSB_ERR_HIP;
     }
     *n_out = sl.h_sum->n_hits;
-    return ADSB_OK;
+    return verify_records(c, sl.h_sum, c->fb.h_rec, *n_out);
 }
 
 // mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17): the addresses the replay will add
@@ -1286,6 +1306,8 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
         }
         by_chunk = sl.h_sum->overflow != 0;
         n_hits = sl.h_sum->n_hits;
+        if (!by_chunk)
+            if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n_hits)) return rc;
     }
     std::vector<uint32_t> addrs;
     if (by_chunk) {
@@ -1362,6 +1384,8 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
             p.clean_bitmap = nullptr;
         }
         n = sl.h_sum->n_hits;
+        if (!by_chunk)
+            if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
     }
     if (by_chunk) {
         std::vector<TrialRecord> all;
