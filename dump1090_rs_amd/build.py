@@ -48,6 +48,8 @@ FEED_SRC = CSRC / "adsb_feed.cpp"
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and not stale() and FEED.exists() and FEED.stat().st_mtime >= FEED_SRC.stat().st_mtime:
+        if not ABI_HOST.exists() or ABI_HOST.stat().st_mtime < ABI_HOST_SRC.stat().st_mtime:
+            build_abi_host(verbose)
         return LIB
     # ADSB_HIPCC_FLAGS: extra flags, e.g. -DADSB_KERNEL_ACCT for the in-kernel phase accounting
     extra = os.environ.get("ADSB_HIPCC_FLAGS", "").split()
@@ -62,7 +64,23 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    build_abi_host(verbose)
     return LIB
+
+
+ABI_HOST_SRC = PKG.parent / "tests" / "abi_host.c"
+ABI_HOST = PKG.parent / "tests" / "abi_host"
+
+
+def build_abi_host(verbose: bool = False) -> Path:
+    """tests/abi_host.c: the reference's test routine from a plain-C host over include/adsb_hip.h
+    (gcc, no Python in between); the GPU tests run it against the golden frames."""
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", f"-I{PKG.parent / 'include'}", str(ABI_HOST_SRC),
+           "-o", str(ABI_HOST), f"-L{PKG}", "-ladsb_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../dump1090_rs_amd"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return ABI_HOST
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 //! `extern "C"` declarations for `include/adsb_hip.h` (libadsb_hip.so, gfx950).
-//! UNTESTED: written without a Rust toolchain; layouts follow the header field by field.
+//! NOT COMPILED in the build image (no Rust toolchain there); layouts follow the header field by
+//! field and are the ones tests/abi_host.c (plain C, same header) runs against on the GPU box.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -41,8 +42,9 @@ pub struct AdsbCtx {
     _private: [u8; 0],
 }
 
+// (edition 2024, Cargo.toml:7: extern blocks are `unsafe extern`)
 #[link(name = "adsb_hip")]
-extern "C" {
+unsafe extern "C" {
     pub fn adsb_create(out: *mut *mut AdsbCtx, device: c_int, max_chunks: usize) -> c_int;
     pub fn adsb_destroy(ctx: *mut AdsbCtx);
     pub fn adsb_set_stream(ctx: *mut AdsbCtx, hip_stream: *mut c_void) -> c_int;
@@ -56,6 +58,7 @@ extern "C" {
     pub fn adsb_submit_iq_device(ctx: *mut AdsbCtx, device_iq: *const c_void, n_samples: usize) -> c_int;
     pub fn adsb_collect(ctx: *mut AdsbCtx, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_pending(ctx: *const AdsbCtx) -> c_int;
+    pub fn adsb_fetch_messages(ctx: *mut AdsbCtx, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_ring_create(ctx: *mut AdsbCtx, samples_per_slot: usize) -> c_int;
     pub fn adsb_ring_acquire(ctx: *mut AdsbCtx, host_iq_re_im: *mut *mut i16, capacity_samples: *mut usize) -> c_int;
     pub fn adsb_ring_submit(ctx: *mut AdsbCtx, n_samples: usize) -> c_int;

@@ -1,0 +1,68 @@
+/* tests/abi_host.c -- the drop-in boundary from a COMPILED host, no Python and no ctypes in between.
+ *
+ * Plain C over include/adsb_hip.h, doing exactly what the reference's own test routine does
+ * (rsadsb/dump1090_rs tests/test.rs:7-17):
+ *
+ *     icao_filter::icao_flush();
+ *     let buf = utils::read_test_data(filename);
+ *     let outbuf = utils::to_mag(&buf);
+ *     let data = demod_2400::demodulate2400(&outbuf).unwrap();
+ *     for (a, b) in data.iter().zip(expected_data.iter()) { assert_eq_hex!(a.buffer(), b); }
+ *
+ * -- but exact in count and order (the reference's zip() only checks a prefix).
+ *
+ *     abi_host <capture.iq> <expected hex frame> ...
+ *
+ * Exit status 0: the frames are exactly the expected ones.  Built with gcc by __graft_entry__.build()
+ * and run by tests/test_gpu_parity.py on the GPU box with the frames of tests/golden/reference_frames.json
+ * (= tests/test.rs:22-28,35-40,49-56).  What a Rust host's `extern "C"` block binds is this same header.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "adsb_hip.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s <capture.iq> [expected hex frames...]\n", argv[0]);
+        return 2;
+    }
+    adsb_ctx *ctx = NULL;
+    int st = adsb_create(&ctx, 0, 1);
+    if (st != ADSB_OK) {
+        fprintf(stderr, "adsb_create: %s\n", adsb_strerror(st));
+        return 3;
+    }
+    int16_t *iq = malloc((size_t)ADSB_MODES_MAG_BUF_SAMPLES * 2 * sizeof(int16_t));
+    uint16_t *data = malloc((size_t)ADSB_MAG_DATA_LEN * sizeof(uint16_t));
+    adsb_msg msgs[256];
+    size_t n_iq = 0, length = 0, n = 0;
+    int rc = 1;
+    if (!iq || !data) goto out;
+
+    st = adsb_icao_flush(ctx);                                                       /* test.rs:9  */
+    if (st == ADSB_OK) st = adsb_read_test_data(argv[1], iq, ADSB_MODES_MAG_BUF_SAMPLES, &n_iq); /* :10 */
+    if (st == ADSB_OK) st = adsb_to_mag(ctx, iq, n_iq, data, &length);               /* test.rs:11 */
+    if (st == ADSB_OK) st = adsb_demodulate2400(ctx, data, length, msgs, 256, &n);   /* test.rs:12 */
+    if (st != ADSB_OK) {
+        fprintf(stderr, "%s (%s)\n", adsb_strerror(st), adsb_last_error(ctx));
+        goto out;
+    }
+    rc = (n == (size_t)(argc - 2)) ? 0 : 1;
+    for (size_t i = 0; i < n; i++) {
+        char hex[2 * ADSB_MODES_LONG_MSG_BYTES + 1];
+        for (unsigned k = 0; k < msgs[i].len; k++) sprintf(hex + 2 * k, "%02x", msgs[i].msg[k]);  /* buffer() */
+        const char *want = i + 2 < (size_t)argc ? argv[i + 2] : "(none)";
+        const int same = strcmp(hex, want) == 0;
+        printf("%s %s\n", hex, same ? "ok" : want);
+        if (!same) rc = 1;
+    }
+    if (n != (size_t)(argc - 2)) fprintf(stderr, "%zu frames, %d expected\n", n, argc - 2);
+out:
+    free(iq);
+    free(data);
+    adsb_destroy(ctx);
+    return rc;
+}

@@ -366,6 +366,22 @@ def test_output_array_too_small_loses_nothing_and_does_not_rerun_the_pass(hip_li
         assert_same(c.demod_iq(iq, cap=1), want2)
 
 
+def test_compiled_c_host_runs_the_reference_test_routine(hip_lib, golden):
+    """tests/abi_host.c: plain C over include/adsb_hip.h (gcc, no ctypes) doing reference tests/test.rs:7-17
+    on the three captures; exit status 0 = exactly the frames upstream asserts, in order."""
+    import subprocess
+    from tests.conftest import GOLDEN, ROOT
+    exe = ROOT / "tests" / "abi_host"
+    assert exe.exists(), "tests/abi_host was not built (dump1090_rs_amd.build.build_abi_host)"
+    for fx in golden["fixtures"]:
+        r = subprocess.run([str(exe), str(GOLDEN / fx["file"]), *fx["frames"]], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert [ln.split()[0] for ln in r.stdout.splitlines()] == fx["frames"]
+    # one frame too few / a wrong frame is a failure, not a prefix match
+    fx = golden["fixtures"][0]
+    assert subprocess.run([str(exe), str(GOLDEN / fx["file"]), *fx["frames"][:-1]], capture_output=True).returncode == 1
+
+
 # ----------------------------------------------------------------------------- stages
 def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod, golden, fixture_iq):
     """Not only frames: the device's magnitudes, the list of positions its gates let through and its
