@@ -1,5 +1,6 @@
 // adsb_aux.hip -- the small kernels around the scan: to_mag alone, the address/parity
 // match, the record builder and the magnitude self-test digest.
+#include "../../include/adsb_hip.h"
 #include "adsb_dev_common.h"
 
 namespace adsb {
@@ -223,6 +224,225 @@ __device__ __forceinline__ uint32_t icao_hash_dev(uint32_t a)
 #ifndef ADSB_REC_BLOCKS_PER_CHUNK
 #define ADSB_REC_BLOCKS_PER_CHUNK 1
 #endif
+// ---------------------------------------------------------------------------
+// device-side scoring (adsb_device.h: ScoreDev).  first index at which an address is added: an
+// open-addressing table of (value << 32 | index), atomic-min per key.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t score_hash_slot(uint32_t v) { return (v * 2654435761u) >> 8; }
+
+__device__ __forceinline__ uint32_t score_hash_insert(const ScoreDev &sd, uint32_t v, uint32_t idx)
+{
+    const unsigned long long mine = (unsigned long long)v << 32 | idx;
+    uint32_t h = score_hash_slot(v) & sd.hash_mask;
+    for (;;) {
+        unsigned long long cur = atomicCAS(&sd.hash[h], ~0ull, mine);
+        if (cur == ~0ull) return h;                    // claimed an empty slot
+        if ((uint32_t)(cur >> 32) == v) {              // the key's slot: keep the smallest index
+            atomicMin(&sd.hash[h], mine);
+            return h;
+        }
+        h = (h + 1u) & sd.hash_mask;
+    }
+}
+
+// index of the first adder of v in this pass, or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t score_hash_first(const ScoreDev &sd, uint32_t v)
+{
+    uint32_t h = score_hash_slot(v) & sd.hash_mask;
+    for (;;) {
+        const unsigned long long cur = __hip_atomic_load(&sd.hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == ~0ull) return 0xFFFFFFFFu;
+        if ((uint32_t)(cur >> 32) == v) return (uint32_t)cur;
+        h = (h + 1u) & sd.hash_mask;
+    }
+}
+
+// "v is in the filter when trial i is scored" (src/icao_filter.rs:65-97; address 0 always is)
+__device__ __forceinline__ bool score_in_filter(const ScoreDev &sd, uint32_t v, uint32_t i)
+{
+    if (v == 0) return true;
+    if ((sd.exact[v >> 5] >> (v & 31)) & 1u) return true;
+    return score_hash_first(sd, v) < i;
+}
+
+// src/mode_s/mod.rs:56-135 for trial i; *adds: the value this trial hands to icao_filter_add (or 0)
+__device__ __forceinline__ int score_trial(const ScoreDev &sd, uint32_t i, uint32_t *adds)
+{
+    const uint32_t w = sd.si[i], v = w & 0xFFFFFFu, kind = w >> 24;
+    *adds = 0;
+    switch (kind) {
+    case kSkApShort: return score_in_filter(sd, v, i) ? 1000 : -1;
+    case kSkApLong: return score_in_filter(sd, v, i) ? 1000 : -2;
+    case kSkDf11: return score_in_filter(sd, v, i) ? 1000 : -1;
+    case kSkDf11Iid0:
+        if (score_in_filter(sd, v, i)) return 1600;
+        *adds = v;
+        return 750;
+    case kSkDf17:
+        if (score_in_filter(sd, v, i)) return 1800;
+        *adds = v;
+        return 1400;
+    case kSkDf18:
+        if (score_in_filter(sd, v, i)) return 1800;
+        *adds = v | (1u << 25);                       // ICAO_FILTER_ADSB_NT, src/icao_filter.rs:6
+        return 1400;
+    case kSkNone: return -3;                          // the reference's None: never taken
+    default: return -2;
+    }
+}
+
+__device__ __forceinline__ uint64_t score_pos(const TrialRecord &r) { return (uint64_t)r.chunk << 24 | (r.j_tp & 0xFFFFFFu); }
+
+// k_score: one thread per hit.  Its own score, whether it is the one its (buffer, j) emits
+// (src/demod_2400.rs:149-207: strictly greater wins, from -2; emitted when >= 0) and what it adds.
+__global__ __launch_bounds__(256) void k_score(ScanParams p)
+{
+    const ScoreDev &sd = p.score;
+    const uint32_t n = sd.state->n;
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t first = blockIdx.x * per, last = min(n, first + per);
+    uint32_t emits = 0, addc = 0;
+    for (uint32_t i = first + threadIdx.x; i < last; i += blockDim.x) {
+        const uint64_t pos = score_pos(sd.rec[i]);
+        uint32_t g0 = i;
+        while (g0 > 0 && i - g0 < 8 && score_pos(sd.rec[g0 - 1]) == pos) g0--;
+        int best = -2, mine = -2;
+        uint32_t win = 0xFFFFFFFFu, my_add = 0;
+        for (uint32_t k = g0; k < n && k < g0 + 16 && score_pos(sd.rec[k]) == pos; k++) {
+            uint32_t a;
+            const int s = score_trial(sd, k, &a);
+            if (k == i) {
+                mine = s;
+                my_add = a;
+            }
+            if (s > best) {
+                best = s;
+                win = k;
+            }
+        }
+        const bool emit = win == i && best >= 0;
+        sd.flag[i] = (emit ? 1u : 0u) | (my_add ? 2u : 0u) | ((uint32_t)(mine + 3) << 8);
+        emits += emit;
+        addc += my_add != 0;
+    }
+    __shared__ uint32_t tot[2];
+    if (threadIdx.x < 2) tot[threadIdx.x] = 0;
+    __syncthreads();
+    if (emits) atomicAdd(&tot[0], emits);
+    if (addc) atomicAdd(&tot[1], addc);
+    __syncthreads();
+    if (threadIdx.x < 2) sd.blk[2 * blockIdx.x + threadIdx.x] = tot[threadIdx.x];
+}
+
+// k_emit: the messages and the additions in order (block b writes behind what blocks < b write),
+// the additions committed to the exact bitmap, the hash table left empty, the summary last.
+__global__ __launch_bounds__(256) void k_emit(ScanParams p)
+{
+    const ScoreDev &sd = p.score;
+    const uint32_t n = sd.state->n;
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t first = blockIdx.x * per, last = min(n, first + per);
+    __shared__ uint32_t base[2], scan[2][256];
+    __shared__ unsigned long long stage[5 * 256];  // this round's messages, 40 bytes each
+    if (threadIdx.x < 2) {
+        uint32_t b = 0;
+        for (uint32_t k = 0; k < blockIdx.x; k++) b += sd.blk[2 * k + threadIdx.x];
+        base[threadIdx.x] = b;
+    }
+    __syncthreads();
+    adsb_msg *out = (adsb_msg *)sd.out_msgs;
+    unsigned long long my_sum = 0;
+    for (uint32_t i0 = first; i0 < last; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t f = i < last ? sd.flag[i] : 0u;
+        scan[0][threadIdx.x] = f & 1u;
+        scan[1][threadIdx.x] = (f >> 1) & 1u;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            const uint32_t a0 = threadIdx.x >= off ? scan[0][threadIdx.x - off] : 0u;
+            const uint32_t a1 = threadIdx.x >= off ? scan[1][threadIdx.x - off] : 0u;
+            __syncthreads();
+            scan[0][threadIdx.x] += a0;
+            scan[1][threadIdx.x] += a1;
+            __syncthreads();
+        }
+        if (i < last) {
+            const TrialRecord r = sd.rec[i];
+            const uint32_t w = sd.si[i], v = w & 0xFFFFFFu, kind = w >> 24;
+            if (f & 1u) {
+                adsb_msg m;
+                for (int k = 0; k < 14; k++) m.msg[k] = r.msg[k];
+                m.len = (r.msg[0] & 0x80) ? ADSB_MODES_LONG_MSG_BYTES : ADSB_MODES_SHORT_MSG_BYTES;
+                m.try_phase = (uint8_t)(r.j_tp >> 24);
+                m.score = (int32_t)(f >> 8) - 3;
+                m.j = r.j_tp & 0xFFFFFFu;
+                m.chunk = r.chunk;
+                // demod_2400.rs:191-198: the same three divisions, in this order
+                const double signal_power = (double)(r.power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
+                m.signal_level = signal_power / 33.0;
+                // staged: the block's messages of this round are contiguous in the output, so they
+                // leave as consecutive 8-byte words from consecutive lanes (separate 8-byte writes
+                // to host memory from one lane each cost ~30 ns apiece)
+                const unsigned long long *mw = (const unsigned long long *)&m;
+                unsigned long long *sw = stage + 5u * (scan[0][threadIdx.x] - 1u);
+#pragma unroll
+                for (int k = 0; k < 5; k++) sw[k] = mw[k];
+            }
+            if (f & 2u) {
+                const uint32_t val = kind == kSkDf18 ? (v | (1u << 25)) : v;
+                host_store32(sd.out_adds + base[1] + scan[1][threadIdx.x] - 1u, val);
+                if (kind != kSkDf18) atomicOr(&sd.exact[v >> 5], 1u << (v & 31));  // visible to later passes only
+            }
+            // leave the hash table empty for the next pass: every adder resets the slot its key sits in
+            // (remembered at insertion; probes only happen in k_score, which has finished)
+            const uint32_t hs = sd.slot[i];
+            if (hs != 0xFFFFFFFFu) sd.hash[hs] = ~0ull;
+        }
+        __syncthreads();
+        {
+            const uint32_t words = 5u * scan[0][255];
+            unsigned long long *ow = (unsigned long long *)(out + base[0]);
+            for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) {
+                const unsigned long long v = stage[w];
+                __hip_atomic_store(ow + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                my_sum += v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            base[0] += scan[0][255];
+            base[1] += scan[1][255];
+        }
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_sum += __shfl_down(my_sum, off);
+    if ((threadIdx.x & 63) == 0 && my_sum) atomicAdd(&sd.state->msg_sum, my_sum);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&sd.state->blocks_done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    // the last block: totals and summary, then the state and the hash table back to empty
+    if (threadIdx.x == 0) {
+        uint32_t nm = 0, na = 0;
+        for (uint32_t k = 0; k < gridDim.x; k++) {
+            nm += sd.blk[2 * k];
+            na += sd.blk[2 * k + 1];
+        }
+        const unsigned long long ms = atomicAdd(&sd.state->msg_sum, 0ull);
+        uint32_t *sm = (uint32_t *)sd.summary;
+        const uint32_t vals[8] = {nm, na, (uint32_t)ms, (uint32_t)(ms >> 32), n ? 1u : 0u, 0u, 0u, sd.seq};
+#pragma unroll
+        for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
+        sd.state->n = 0;
+        sd.state->blocks_done = 0;
+        sd.state->msg_sum = 0;
+    }
+}
+
 constexpr int kRecWindow = 296;   // magnitudes a trial can touch: data[j+19 .. j+290], rounded up
 constexpr int kRecBatch = 64;     // records a block stages before writing them out together
 
@@ -247,6 +467,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
     unsigned long long my_sum = 0;  // of the u64 words this thread sent to the host
+    const bool do_score = p.score.si && n <= p.score.cap && !p.ctr->overflow;  // (uniform) k_score follows
     for (uint32_t b0 = first; b0 < last; b0 += kRecBatch) {
         const uint32_t cnt = min((uint32_t)kRecBatch, last - b0);
         for (uint32_t q = wave; q < cnt; q += 4) {
@@ -333,6 +554,24 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
                 const bool ap = ((0xFF310031u >> df) & 1u) != 0;
                 const uint32_t addr = (uint32_t)(half[0] >> 32) & 0xFFFFFFu;
                 r.pad = (uint16_t)(3u | (icao_hash_dev(ap ? crc : addr) << 4));
+                if (do_score) {
+                    // for k_score: what this trial asks the filter about, and what it may add
+                    // (src/mode_s/mod.rs:56-135); clean DF11 (IID 0) / DF17 register as adders
+                    const bool zero = (half[0] | half[1]) == 0;
+                    const bool d11 = df == 11u, d17 = df == 17u, d18 = df == 18u;
+                    const bool clean11 = d11 && (crc & 0xFFFF80u) == 0, iid0 = (crc & 0x7Fu) == 0;
+                    const bool clean17 = (d17 || d18) && crc == 0;
+                    uint32_t kind = kSkOther;
+                    if (zero) kind = kSkNone;
+                    else if (ap) kind = lng ? kSkApLong : kSkApShort;
+                    else if (clean11) kind = iid0 ? kSkDf11Iid0 : kSkDf11;
+                    else if (clean17) kind = d17 ? kSkDf17 : kSkDf18;
+                    const uint32_t v = ap ? crc : addr;
+                    p.score.si[b0 + q] = v | (kind << 24);
+                    p.score.rec[b0 + q] = r;
+                    p.score.slot[b0 + q] = (kind == kSkDf11Iid0 || kind == kSkDf17) ? score_hash_insert(p.score, v, b0 + q)
+                                                                                   : 0xFFFFFFFFu;
+                }
                 stage[q] = r;
             }
             __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next hit
@@ -377,6 +616,10 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         }
         if (lane == 0) {
             uint32_t *sm = (uint32_t *)p.summary;
+            if (p.score.si) {
+                const uint32_t nh = p.ctr->n_hits;
+                p.score.state->n = (p.ctr->overflow || nh > p.score.cap) ? 0u : nh;
+            }
             const unsigned long long rs = atomicAdd((unsigned long long *)p.ctr->rec_sum, 0ull);
             const uint32_t vals[8] = {p.ctr->n_hits, p.ctr->overflow, (uint32_t)rs, p.ctr->n_dap,
                                       ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq};
@@ -499,6 +742,15 @@ int launch_order_hits(const ScanParams &p, void *stream)
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(k_order_rank, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_score(const ScanParams &p, void *stream)
+{
+    hip_clear();
+    if (!p.score.si) return 0;
+    hipLaunchKernelGGL(k_score, dim3(kScoreBlocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_emit, dim3(kScoreBlocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

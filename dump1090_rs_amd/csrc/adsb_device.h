@@ -125,6 +125,48 @@ constexpr int kTabF = 0, kTabX56 = 3, kTabCount = 6;
 constexpr int kTabR16Off = kTabCount * 256, kTabFieldOff = kTabR16Off + 16, kTabBitsOff = kTabFieldOff + 300,
               kTabWords = kTabBitsOff + 168;  // + per-bit residual constants (build_bit_residuals)
 
+// Device-side scoring of a pass whose hits are in (buffer, j, try_phase) order: the sequential part
+// of demodulate2400 (src/mode_s/mod.rs:34-139 scores read AND write the ICAO filter,
+// src/demod_2400.rs:184-207 keeps the best of the five phases) done in parallel.  What makes that
+// possible: a trial's score depends on the filter only through "is value v in the filter when this
+// trial is scored", and v is in it then iff it was in it when the pass began (the exact bitmap) or an
+// EARLIER trial of the pass added it -- the first index at which a clean DF11 (IID 0) / DF17 with
+// address v occurs, found with one atomic-min hash table over the adders.  (DF18 adds addr | 1 << 25,
+// which no 24-bit test value equals.)  The only thing this cannot reproduce is the reference's
+// behaviour once the 4096-slot table fills up; the host checks the count and replays such a pass
+// itself from the records, which are always there.
+struct ScoreState {
+    uint32_t n;            // hits of this pass (0 when it is not to be scored: overflow, too many)
+    uint32_t blocks_done;  // k_emit
+    uint32_t n_msgs, n_adds;
+    unsigned long long msg_sum;  // 64-bit sum of every u64 word of the messages written
+};
+struct ScoreSummary {      // in mapped host memory
+    uint32_t n_msgs, n_adds;
+    uint32_t msg_sum_lo, msg_sum_hi;
+    uint32_t scored;       // 1: messages / adds are the pass's result; 0: the host replays the records
+    uint32_t pad[2];
+    uint32_t seq;
+};
+struct ScoreDev {
+    uint32_t cap;                  // hits a pass may have to be scored here
+    uint32_t *si;                  // per hit: value24 | kind << 24
+    TrialRecord *rec;              // per hit: the record (device copy)
+    uint32_t *flag;                // per hit: bit 0 emit, bit 1 add; bits 8.. : score + 2
+    unsigned long long *hash;      // adders: (value << 32 | first index), ~0 = empty
+    uint32_t hash_mask;
+    uint32_t *slot;                // per hit: the hash slot its key sits in (adders), else 0xFFFFFFFF
+    uint32_t *blk;                 // per k_score block: emits, adds
+    uint32_t *exact;               // 2^24 bits: the filter as it stands before this pass
+    ScoreState *state;
+    void *out_msgs;                // adsb_msg[cap], mapped host memory
+    uint32_t *out_adds;            // mapped host memory: values handed to icao_filter_add, in order
+    ScoreSummary *summary;         // mapped host memory
+    uint32_t seq;
+};
+constexpr int kScoreBlocks = 256;  // k_score / k_emit grid: block b owns a contiguous run of hits
+enum ScoreKind : uint32_t { kSkOther = 0, kSkApShort, kSkApLong, kSkDf11Iid0, kSkDf11, kSkDf17, kSkDf18, kSkNone };
+
 struct ScanParams {
     const void *src;        // IQ as {re,im} int16 pairs, or u16 magnitudes (from_mag)
     uint64_t n_samples;     // IQ: total samples in the call.  from_mag: `length` of the buffer
@@ -163,7 +205,11 @@ struct ScanParams {
     uint64_t *cand_out;
     uint32_t *cand_count;
     uint32_t cand_cap;
+    // device-side scoring (k_score / k_emit; score.si null: the host replays the records)
+    ScoreDev score;
 };
+
+
 
 // The address bitmap: 2^24 bits, followed by a 4096-bit summary (bit a & 4095 is set when any
 // address a is): the match kernel tests the summary from LDS and goes to the big bitmap only
@@ -186,6 +232,9 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
 // sort the hit list by (buffer, j, try_phase) on the device, so that the records come out in the
 // order the host replays them in (src/demod_2400.rs:121,158: ascending j, then try_phase)
 int launch_order_hits(const ScanParams &p, void *stream);
+// score the (ordered) hits of the pass on the device: messages, filter additions and a summary
+// into mapped host memory (p.score)
+int launch_score(const ScanParams &p, void *stream);
 // OR a list of 24-bit addresses into a bitmap (addresses learned by other shards)
 int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream);
 // next[i] = sample (n - kCarrySamples + i) of the stream: from d_src, or from `prev` where the

@@ -44,6 +44,17 @@ struct Slot {
     // each), and the second list the counting sort scatters into
     uint32_t *d_order_cnt = nullptr, *d_order_base = nullptr;
     uint64_t *d_order_tmp = nullptr;
+    // device-side scoring: the messages, the filter additions and their summary, in mapped host memory
+    adsb_msg *h_msgs = nullptr, *h_msgs_dev = nullptr;
+    uint32_t *h_adds = nullptr, *h_adds_dev = nullptr;
+    ScoreSummary *h_ssum = nullptr, *h_ssum_dev = nullptr;
+    // a pass the library finished ahead of the caller's adsb_collect (park_pending): its result waits here
+    bool parked = false;
+    int park_rc = 0;
+    std::vector<adsb_msg> parked_msgs;
+    adsb_stats parked_stats{};
+    bool device_scored = false;   // this pass went through k_score / k_emit
+    uint64_t score_epoch = 0;     // ... against the filter history of this epoch
     uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
                                    // (kept until the slot is reused: the overflow fallback re-reads it)
     hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
@@ -107,7 +118,12 @@ struct adsb_ctx {
     hipEvent_t last_stop = nullptr;  // stop event of the pass collected last, and its number
     uint64_t last_scan_seq = 0;
     uint64_t scan_counter = 0;
-    uint64_t submitted = 0, collected = 0;
+    uint64_t submitted = 0, collected = 0;  // passes enqueued / finished (replayed) by the library
+    uint64_t delivered = 0;                 // passes handed to the caller (<= collected: park_pending)
+    // Dense input (thousands of trial records per pass) is ordered and scored on the device; sparse
+    // input is not worth the extra launches on the tail stream, the host does it in microseconds.
+    // Decided from the last pass finished (a stream's density changes slowly).
+    bool dense_mode = false;
     uint32_t next_seq = 1;
 
     // streaming ring (adsb_ring_*): per slot a pinned host buffer the caller fills and a
@@ -138,6 +154,15 @@ struct adsb_ctx {
     // the messages of a call whose `out` was too small (ADSB_ERR_CAPACITY): the pass is consumed
     // and the filter has moved on, so they are kept for adsb_fetch_messages
     uint64_t host_sorts = 0;  // passes whose records the host had to put in order itself
+    uint64_t host_replays = 0;  // passes the host scored itself (small passes, fallbacks, full filter ...)
+    // Device-side scoring (adsb_device.h: ScoreDev).  The exact bitmap follows the filter pass by pass
+    // on the tail stream; the host's own filter follows at collect time from the additions each pass
+    // reports.  Whenever the host scores a pass itself the two part ways: `score_epoch` moves on, which
+    // disowns the device results of passes already in flight, and device scoring resumes once the
+    // context is idle and the bitmap has been rebuilt from the host's table.
+    ScoreDev score{};
+    bool exact_valid = false;
+    uint64_t score_epoch = 0;
 #ifdef ADSB_TUNING
     double t_wait = 0, t_replay = 0, t_enqueue = 0;  // host seconds (ADSB_HOST_TIMES prints them at destroy)
 #endif
@@ -270,12 +295,25 @@ int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp)
     return ADSB_OK;
 }
 
+int resync_exact(adsb_ctx *c);
+int park_pending(adsb_ctx *c);
+
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
                  uint32_t n_chunks, bool inline_tail = false, bool lead_from_src = false,
                  bool advance_carry = true, bool force_simple = false, hipEvent_t input_done = nullptr)
 {
+    // Passes of many buffers of a dense stream hand their hits over in (buffer, j, try_phase) order and
+    // scored; a small pass is all launch overhead and a sparse one leaves a few hundred records that
+    // the host sorts and scores in no time; the worst-case lists of the fallback are the host's too.
+    const bool order_on_device = !force_simple && n_chunks > kInlineTailChunks && sl.hits_cap == c->hits_cap && c->dense_mode;
+    if (order_on_device && c->score.si && !c->exact_valid) {
+        // the device's copy of the filter can only be rebuilt from the host's once every pass in
+        // flight has been replayed: finish them now (their results wait for adsb_collect)
+        if (int rc = park_pending(c)) return rc;
+        if (int rc = resync_exact(c)) return rc;
+    }
     ScanParams p{};
     p.src = d_src;
     p.n_samples = n_samples;
@@ -301,13 +339,20 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.timeline = c->d_timeline;
     p.carry = c->carry_over && !from_mag ? sl.d_carry : nullptr;
     p.lead_from_src = lead_from_src ? 1u : 0u;
-    // Passes of many buffers hand their hits over in (buffer, j, try_phase) order, so that the host
-    // only scores; a small pass is all launch overhead and its few records sort in no time on the
-    // host, and the worst-case lists of the fallback are the host's business too.
-    const bool order_on_device = !force_simple && n_chunks > kInlineTailChunks && sl.hits_cap == c->hits_cap;
     p.order_cnt = order_on_device ? sl.d_order_cnt : nullptr;
     p.order_base = order_on_device ? sl.d_order_base : nullptr;
     p.order_tmp = order_on_device ? sl.d_order_tmp : nullptr;
+    sl.device_scored = false;
+    if (order_on_device && c->score.si) {
+        if (c->exact_valid) {
+            p.score = c->score;
+            p.score.out_msgs = sl.h_msgs_dev;
+            p.score.out_adds = sl.h_adds_dev;
+            p.score.summary = sl.h_ssum_dev;
+            sl.device_scored = true;
+            sl.score_epoch = c->score_epoch;
+        }
+    }
 
     sl.src = d_src;
     sl.from_mag = from_mag;
@@ -323,6 +368,10 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.ev[1] = c->scan_ev[sl.scan_seq % (kSlots + 1)][1];
     sl.h_sum->seq = 0;  // the records kernel overwrites it, last, with sl.seq
     p.seq = sl.seq;
+    if (sl.device_scored) {
+        p.score.seq = sl.seq;
+        sl.h_ssum->seq = 0;
+    }
     // level 1: the scan launch stamps its own begin/end (no extra packets on the stream);
     // level 2: classic event records between all kernels
     static const bool ext_events = !tuning_env("ADSB_NO_EXT_EVENTS");
@@ -381,8 +430,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
     // the records kernel writes the records and the summary into the slot's mapped host
     // memory with write-through stores; `done` only has to say the kernel has drained
+    if (sl.device_scored && sl.flush_before)  // icao_flush: the filter this pass starts from is empty
+        HIP_TRY(c, hipMemsetAsync(c->score.exact, 0, kBitmapAllocWords * sizeof(uint32_t), ts));
     if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
         return fail(c, (hipError_t)e, "launch_records");
+    if (sl.device_scored)
+        if (int e = launch_score(p, ts)) return fail(c, (hipError_t)e, "launch_score");
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
     HIP_TRY(c, hipEventRecord(sl.done, ts));
     return ADSB_OK;
@@ -405,6 +458,62 @@ int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size
     }
     if (c) c->last_error = "trial records in host memory do not add up to the checksum of the pass that wrote them";
     return ADSB_ERR_HIP;
+}
+
+// The exact bitmap rebuilt from the host's filter table (only while nothing is in flight).
+int resync_exact(adsb_ctx *c)
+{
+    std::vector<uint32_t> addrs;
+    for (uint32_t a : c->filter.table())
+        if (a != 0 && a <= 0xFFFFFFu) addrs.push_back(a);
+    hipStream_t ts = c->tail_stream;
+    HIP_TRY(c, hipMemsetAsync(c->score.exact, 0, kBitmapAllocWords * sizeof(uint32_t), ts));
+    if (!addrs.empty()) {
+        if (addrs.size() > c->addrs_cap) {
+            if (c->d_addrs) (void)hipFree(c->d_addrs);
+            c->d_addrs = nullptr;
+            c->addrs_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_addrs, IcaoFilter::kSize * sizeof(uint32_t)));
+            c->addrs_cap = IcaoFilter::kSize;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ts));
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->score.exact, ts))
+            return fail(c, (hipError_t)e, "launch_set_addresses");
+    }
+    HIP_TRY(c, hipStreamSynchronize(ts));  // (rare: only after the host scored a pass itself)
+    c->exact_valid = true;
+    return ADSB_OK;
+}
+
+// The pass's messages as the device scored them, when they can be taken as they are: scored in the
+// current epoch, whole (checksum), and with the filter nowhere near full -- the one situation whose
+// reference behaviour (icao_filter_add gives up on a full table, src/icao_filter.rs:46-62) the parallel
+// formulation does not reproduce.  Applies the pass's additions to the host's filter, in order.
+bool take_device_result(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, std::vector<adsb_msg> &out)
+{
+    if (!sl.device_scored || sl.score_epoch != c->score_epoch) return false;
+    const ScoreSummary *ss = sl.h_ssum;
+    if (__atomic_load_n(&ss->seq, __ATOMIC_ACQUIRE) != sl.seq || !ss->scored) return false;
+    const size_t nm = ss->n_msgs, na = ss->n_adds;
+    if (nm > c->score.cap || na > c->score.cap) return false;
+    size_t held = 0;
+    for (uint32_t a : c->filter.table()) held += a != 0;
+    if (held + na + 64 >= IcaoFilter::kSize) return false;
+    const uint64_t want = (uint64_t)ss->msg_sum_hi << 32 | ss->msg_sum_lo;
+    bool whole = false;
+    for (int attempt = 0; attempt < 200 && !whole; attempt++) {
+        uint64_t got = 0;
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(sl.h_msgs);
+        for (size_t i = 0; i < 5 * nm; i++) got += __atomic_load_n(&w[i], __ATOMIC_RELAXED);
+        whole = got == want;
+    }
+    if (!whole) return false;
+    const size_t at = out.size();
+    out.insert(out.end(), sl.h_msgs, sl.h_msgs + nm);
+    if (chunk_offset)
+        for (size_t i = at; i < out.size(); i++) out[i].chunk += chunk_offset;
+    for (size_t i = 0; i < na; i++) c->filter.add(sl.h_adds[i]);
+    return true;
 }
 
 // Wait for the pass in `sl` and replay it.  Returns 1 when a device list overflowed
@@ -452,6 +561,14 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     st.n_candidates += sl.h_sum->n_cand_total;
     st.n_ap_entries += sl.h_sum->n_ap_total;
     st.n_records += n;
+    if (sl.hits_cap == c->hits_cap) {  // (not the fallback's one-buffer passes)
+        if (n >= 4096) c->dense_mode = true;
+        else if (n < 1024) c->dense_mode = false;
+    }
+    if (take_device_result(c, sl, chunk_offset, out)) return 0;
+    c->host_replays++;
+    c->score_epoch++;        // passes in flight were scored on the device without what this replay adds
+    c->exact_valid = false;
     static const bool skip_replay = tuning_env("ADSB_SKIP_REPLAY") != nullptr;  // measurement aid (tuning build only)
 #ifdef ADSB_TUNING
     const auto tr0 = std::chrono::steady_clock::now();
@@ -542,13 +659,43 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     return ADSB_OK;
 }
 
+// Finish every pass in flight now; the caller still gets them from adsb_collect, in order.
+int park_pending(adsb_ctx *c)
+{
+    while (c->collected < c->submitted) {
+        Slot &sl = c->slot[c->collected % kSlots];
+        sl.parked_msgs.clear();
+        sl.park_rc = collect_oldest(c, sl.parked_msgs);
+        sl.parked_stats = c->stats;
+        sl.parked = true;
+    }
+    return ADSB_OK;
+}
+
+// adsb_collect: the oldest pass the caller has not had yet
+int collect_next(adsb_ctx *c, std::vector<adsb_msg> &out)
+{
+    if (c->delivered < c->collected) {
+        Slot &sl = c->slot[c->delivered % kSlots];
+        out.swap(sl.parked_msgs);
+        sl.parked_msgs.clear();
+        c->stats = sl.parked_stats;
+        sl.parked = false;
+        c->delivered++;
+        return sl.park_rc;
+    }
+    const int rc = collect_oldest(c, out);
+    c->delivered++;
+    return rc;
+}
+
 int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false,
            hipEvent_t input_done = nullptr)
 {
     const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks == 0 || n_chunks > kMaxChunks || n_chunks > c->max_chunks) return ADSB_ERR_INVALID;
     Slot &sl = c->slot[c->submitted % kSlots];
-    if (sl.busy || c->shard_active) return ADSB_ERR_BUSY;
+    if (sl.busy || sl.parked || c->shard_active) return ADSB_ERR_BUSY;
 #ifdef ADSB_TUNING
     const auto te0 = std::chrono::steady_clock::now();
 #endif
@@ -566,10 +713,10 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bo
 // synchronous pass: everything pending is finished first, in order
 int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out)
 {
-    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     int rc = submit(c, d_src, from_mag, n_samples, true);
     if (rc) return rc;
-    return collect_oldest(c, out);
+    return collect_next(c, out);
 }
 
 // IQ stream of any length resident on the device.
@@ -716,6 +863,35 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         HIP_TRY(c, hipMalloc((void **)&c->d_carry_next, kCarrySamples * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t)));
+        {
+            // device-side scoring state (shared by the passes: they go through it one after the other
+            // on the tail stream); passes of more hits than `cap` are scored on the host
+            ScoreDev &sd = c->score;
+            sd.cap = std::min<uint32_t>(c->hits_cap, 131072u);
+            uint32_t hsize = 1;
+            while (hsize < 2 * sd.cap) hsize <<= 1;
+            sd.hash_mask = hsize - 1;
+            HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sd.rec, (size_t)sd.cap * sizeof(TrialRecord)));
+            HIP_TRY(c, hipMalloc((void **)&sd.flag, (size_t)sd.cap * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sd.slot, (size_t)sd.cap * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sd.hash, (size_t)hsize * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemset(sd.hash, 0xFF, (size_t)hsize * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMalloc((void **)&sd.blk, 2 * kScoreBlocks * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sd.exact, kBitmapAllocWords * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(sd.exact, 0, kBitmapAllocWords * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sd.state, sizeof(ScoreState)));
+            HIP_TRY(c, hipMemset(sd.state, 0, sizeof(ScoreState)));
+            for (Slot &sl : c->slot) {
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_msgs, (size_t)sd.cap * sizeof(adsb_msg), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_adds, (size_t)sd.cap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_ssum, sizeof(ScoreSummary), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_msgs_dev, sl.h_msgs, 0));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_adds_dev, sl.h_adds, 0));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_ssum_dev, sl.h_ssum, 0));
+                std::memset(sl.h_ssum, 0, sizeof(ScoreSummary));
+            }
+        }
         HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
         {
             std::vector<uint32_t> tab = build_gf_tables();
@@ -791,6 +967,9 @@ void adsb_destroy(adsb_ctx *c)
         if (sl.d_order_cnt) (void)hipFree(sl.d_order_cnt);
         if (sl.d_order_base) (void)hipFree(sl.d_order_base);
         if (sl.d_order_tmp) (void)hipFree(sl.d_order_tmp);
+        if (sl.h_msgs) (void)hipHostFree(sl.h_msgs);
+        if (sl.h_adds) (void)hipHostFree(sl.h_adds);
+        if (sl.h_ssum) (void)hipHostFree(sl.h_ssum);
         if (sl.d_carry) (void)hipFree(sl.d_carry);
         if (sl.h_sum) (void)hipHostFree(sl.h_sum);
         if (sl.h_rec) (void)hipHostFree(sl.h_rec);
@@ -810,6 +989,9 @@ void adsb_destroy(adsb_ctx *c)
         (void)hipStreamSynchronize(c->tail_stream);
         (void)hipStreamDestroy(c->tail_stream);
     }
+    for (void *q : {(void *)c->score.si, (void *)c->score.rec, (void *)c->score.flag, (void *)c->score.slot,
+                    (void *)c->score.hash, (void *)c->score.blk, (void *)c->score.exact, (void *)c->score.state})
+        if (q) (void)hipFree(q);
     if (c->fb.d_hits) (void)hipFree(c->fb.d_hits);
     if (c->fb.d_dap) (void)hipFree(c->fb.d_dap);
     if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
@@ -865,7 +1047,7 @@ void adsb_destroy(adsb_ctx *c)
 int adsb_set_stream(adsb_ctx *c, void *hip_stream)
 {
     if (!c) return ADSB_ERR_INVALID;
-    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return ADSB_OK;
@@ -881,7 +1063,7 @@ int adsb_set_profiling(adsb_ctx *c, int enabled)
 int adsb_set_carry_over(adsb_ctx *c, int enabled)
 {
     if (!c) return ADSB_ERR_INVALID;
-    if (c->submitted != c->collected || c->shard_active) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipSetDevice(c->device));
     c->carry_over = enabled != 0;
     // the stream starts here: nothing precedes the next call
@@ -925,7 +1107,7 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
     if (!c || !data || (!out && cap)) return ADSB_ERR_INVALID;
     if (length > kChunkSamples) return ADSB_ERR_TOO_LONG;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     c->stats = adsb_stats{};
     c->stats.n_samples = length;
     c->stats.n_chunks = 1;
@@ -964,15 +1146,15 @@ int adsb_submit_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples)
 int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
 {
     if (!c || (!out && cap)) return ADSB_ERR_INVALID;
-    if (c->submitted == c->collected) return ADSB_ERR_INVALID;
+    if (c->submitted == c->delivered) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<adsb_msg> msgs;
-    int rc = collect_oldest(c, msgs);
+    int rc = collect_next(c, msgs);
     if (rc) return rc;
     return deliver(c, msgs, out, cap, n_out);
 }
 
-int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->collected) : 0; }
+int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->delivered) : 0; }
 
 int adsb_fetch_messages(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
 {
@@ -1001,7 +1183,7 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
 int adsb_ring_acquire(adsb_ctx *c, int16_t **host_iq, size_t *capacity_samples)
 {
     if (!c || !host_iq || !c->ring_samples) return ADSB_ERR_INVALID;
-    if (c->slot[c->submitted % kSlots].busy) return ADSB_ERR_BUSY;  // collect the oldest pass first
+    if (c->slot[c->submitted % kSlots].busy || c->slot[c->submitted % kSlots].parked) return ADSB_ERR_BUSY;  // collect the oldest pass first
     *host_iq = c->ring[c->submitted % kSlots].h_iq;
     if (capacity_samples) *capacity_samples = c->ring_samples;
     return ADSB_OK;
@@ -1010,7 +1192,7 @@ int adsb_ring_acquire(adsb_ctx *c, int16_t **host_iq, size_t *capacity_samples)
 int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
 {
     if (!c || !c->ring_samples || n_samples == 0 || n_samples > c->ring_samples) return ADSB_ERR_INVALID;
-    if (c->slot[c->submitted % kSlots].busy) return ADSB_ERR_BUSY;
+    if (c->slot[c->submitted % kSlots].busy || c->slot[c->submitted % kSlots].parked) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipSetDevice(c->device));
     auto &r = c->ring[c->submitted % kSlots];
     // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's
@@ -1080,7 +1262,7 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
                              uint64_t *xor_out)
 {
     if (!c || !sum_out || !xor_out) return ADSB_ERR_INVALID;
-    if (c->submitted != c->collected) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipSetDevice(c->device));
     // the counters block doubles as the 16-byte result area
     static_assert(sizeof(Counters) >= 16, "digest result fits the counters block");
@@ -1103,7 +1285,7 @@ int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, u
                               size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap)
 {
     if (!c || !d_iq || n_samples == 0 || (!cand && cand_cap) || (!ap && ap_cap)) return ADSB_ERR_INVALID;
-    if (c->submitted != c->collected || c->shard_active) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     if ((uintptr_t)d_iq % 16) return ADSB_ERR_INVALID;
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
@@ -1260,7 +1442,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
                     size_t *n_addrs)
 {
     if (!c || (!device_iq && n_samples) || (!addrs_out && cap)) return ADSB_ERR_INVALID;
-    if (c->submitted != c->collected || c->shard_active) return ADSB_ERR_BUSY;
+    if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     if (n_addrs) *n_addrs = 0;
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
@@ -1465,6 +1647,7 @@ int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
 }
 
 uint64_t adsb_host_sorts(const adsb_ctx *c) { return c ? c->host_sorts : 0; }
+uint64_t adsb_host_replays(const adsb_ctx *c) { return c ? c->host_replays : 0; }
 
 int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 {

@@ -268,6 +268,12 @@ int adsb_get_stats(const adsb_ctx *ctx, adsb_stats *out);
  * (buffer, j, try_phase) order, so that the host replay had to sort them first.  Passes of more
  * than 16 buffers are put in order on the device; small passes and the overflow fallback are not. */
 uint64_t adsb_host_sorts(const adsb_ctx *ctx);
+/* Diagnostic: how many collected passes the host scored itself (the ordered replay of
+ * score_modes_message / best-of-5, src/mode_s/mod.rs:34-139, src/demod_2400.rs:184-207) instead of
+ * taking the messages the device scored.  Passes of more than 16 buffers in a steady pipeline are
+ * scored on the device against a device-resident copy of the ICAO filter; small passes, fallbacks,
+ * a filter close to its 4096 entries and the passes in flight behind any of those are not. */
+uint64_t adsb_host_replays(const adsb_ctx *ctx);
 const char *adsb_strerror(int status);
 /* Text of the last HIP failure on this context ("" if none). */
 const char *adsb_last_error(const adsb_ctx *ctx);

@@ -271,12 +271,19 @@ def test_full_256mib_buffer_bit_exact(hip_lib, oracle_mod, n_bursts):
     want, st = oracle_mod.Oracle().demod_iq(host, cap=1 << 20)
     with Context(0, 512) as c:
         c.icao_flush()
+        c.demod_iq_device(t.data_ptr(), n, cap=1 << 20)   # (tells the context how dense this stream is)
+        c.icao_flush()
         got = c.demod_iq_device(t.data_ptr(), n, cap=1 << 20)
         s = c.stats()
-        host_sorts = c._L.adsb_host_sorts(c._h)
+        host_sorts, host_replays = c._L.adsb_host_sorts(c._h), c._L.adsb_host_replays(c._h)
     assert_same(got, want)
     assert s["n_candidates"] == st.quiet_pass and s["retries"] == 0
-    assert host_sorts == 0     # the device handed the records over in replay order
+    if n_bursts >= 5000:
+        # dense: the device handed the second pass over in replay order and scored it itself (mode_s
+        # scoring + best-of-5 against its copy of the filter); the host did neither
+        assert (host_sorts, host_replays) == (1, 1)
+    else:
+        assert (host_sorts, host_replays) == (2, 2)   # sparse: a few hundred records, the host's business
     injected = {b.frame for b in synth.plan_bursts(n, n_bursts)}
     assert len(injected & {w["buffer"] for w in want}) >= 0.95 * len(injected)
 
@@ -381,6 +388,72 @@ def test_compiled_c_host_runs_the_reference_test_routine(hip_lib, golden):
     fx = golden["fixtures"][0]
     assert subprocess.run([str(exe), str(GOLDEN / fx["file"]), *fx["frames"][:-1]], capture_output=True).returncode == 1
 
+
+def test_device_side_scoring_follows_the_filter_across_pipelined_passes(hip_lib, oracle_mod):
+    """Passes of more than 16 buffers are scored on the device against its own copy of the ICAO
+    filter: 750 -> 1600, 1400 -> 1800 and address/parity frames that depend on addresses learned earlier
+    in the same pass, in earlier passes in flight, and not after an icao_flush -- against the oracle,
+    with the host never scoring (adsb_host_replays) until a small pass forces it to, after which the
+    device copy is rebuilt and takes over again."""
+    import torch
+    from dump1090_rs_amd import Context
+    n = 20 * 131072
+    icaos = [0x4840D6, 0x3C6589, 0xA1B2C3]
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = lambda icao: body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    host = [synth.make_iq(n, n_bursts=1600, seed=700 + k, n_icao=5, df11_every=3) for k in range(4)]
+    # address/parity frames whose address is learned late in buffer 0 of pass 0, and only there
+    synth.add_bursts(host[0], [synth.Burst(5 * (131072 * 3 + 5000) + 2, 21000, 2, synth.df17_frame(icaos[0], 7))])
+    for k in (1, 2, 3):
+        synth.add_bursts(host[k], [synth.Burst(5 * (131072 * (2 + q) + 900 * q + 333) + q, 21000, q, df4(icaos[0]))
+                                   for q in range(1, 6)])
+    bufs = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    orc = oracle_mod.Oracle()
+    want = []
+    for k, flush in ((0, True), (1, False), (2, False), (3, True), (1, False), (0, False)):
+        if flush:
+            orc.icao_flush()
+        want.append(orc.demod_iq(host[k])[0])
+    assert sum(w["buffer"] == df4(icaos[0]) for w in want[1]) >= 3 and not any(w["buffer"] == df4(icaos[0]) for w in want[3])
+    assert {1000, 1400, 1600, 1800} <= {w["score"] for ws in want for w in ws}
+    with Context(0, 32) as c:
+        c.icao_flush()
+        c.demod_iq_device(bufs[2].data_ptr(), n)             # (tells the context how dense this stream is)
+        assert c._L.adsb_host_replays(c._h) == 1
+        got = []
+        c.icao_flush()
+        c.submit_iq_device(bufs[0].data_ptr(), n)
+        c.submit_iq_device(bufs[1].data_ptr(), n)
+        c.submit_iq_device(bufs[2].data_ptr(), n)
+        got.append(c.collect())
+        c.icao_flush()
+        c.submit_iq_device(bufs[3].data_ptr(), n)
+        got.append(c.collect())
+        c.submit_iq_device(bufs[1].data_ptr(), n)
+        got.append(c.collect())
+        c.submit_iq_device(bufs[0].data_ptr(), n)
+        got += [c.collect(), c.collect(), c.collect()]
+        for g, w in zip(got, want):
+            assert_same(g, w)
+        assert c.stats()["n_records"] >= 4096
+        assert c._L.adsb_host_replays(c._h) == 1 and c._L.adsb_host_sorts(c._h) == 1
+        # a small pass is the host's; once the stream is dense again the passes in flight are finished
+        # early, the device's copy of the filter is rebuilt from the host's, and it takes over again
+        small = host[2][: 3 * 131072]
+        assert_same(c.demod_iq(small), orc.demod_iq(small)[0])
+        assert c._L.adsb_host_replays(c._h) == 2
+        seq = [3, 2, 1, 0, 3]
+        for k in seq[:3]:
+            c.submit_iq_device(bufs[k].data_ptr(), n)
+        outs = [c.collect()]
+        for k in seq[3:]:
+            c.submit_iq_device(bufs[k].data_ptr(), n)
+            outs.append(c.collect())
+        outs += [c.collect(), c.collect()]
+        for k, g in zip(seq, outs):
+            assert_same(g, orc.demod_iq(host[k])[0])
+        assert 3 <= c._L.adsb_host_replays(c._h) <= 5         # the first one to three of these five, not all
 
 # ----------------------------------------------------------------------------- stages
 def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod, golden, fixture_iq):

@@ -6,10 +6,10 @@ rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$T -o g -- pyth
 python3 - <<PY
 import csv, glob
 f=glob.glob('$R/gpurun_out/tl_$T/**/g_kernel_trace.csv', recursive=True)[0]
-rows=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name']) for r in csv.DictReader(open(f)) if 'adsb::' in r['Kernel_Name']]
+rows=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name']) for r in csv.DictReader(open(f)) if 'adsb::' in r['Kernel_Name'] or 'fillBuffer' in r['Kernel_Name']]
 rows.sort()
 def short(n):
-    for k in ('k_scan_fast','k_match','k_records','k_sort','k_score'):
+    for k in ('k_scan_fast','k_match','k_records','k_order_prefix','k_order_scatter','k_order_rank','k_score','k_emit','fillBuffer'):
         if k in n: return k
     return n[:20]
 scans=[r for r in rows if 'k_scan_fast' in r[2]]
