@@ -344,12 +344,29 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
     __shared__ uint32_t base[2], scan[2][256];
     __shared__ unsigned long long stage[5 * 256];  // this round's messages, 40 bytes each
-    if (threadIdx.x < 2) {
-        uint32_t b = 0;
-        for (uint32_t k = 0; k < blockIdx.x; k++) b += sd.blk[2 * k + threadIdx.x];
-        base[threadIdx.x] = b;
+    {
+        // what the blocks before this one write: all threads fetch, one reduction (kScoreBlocks == blockDim)
+        const uint32_t k = threadIdx.x;
+        scan[0][k] = k < blockIdx.x ? sd.blk[2 * k] : 0u;
+        scan[1][k] = k < blockIdx.x ? sd.blk[2 * k + 1] : 0u;
+        __syncthreads();
+        for (uint32_t off = 128; off > 0; off >>= 1) {
+            if (k < off) {
+                scan[0][k] += scan[0][k + off];
+                scan[1][k] += scan[1][k + off];
+            }
+            __syncthreads();
+        }
+        if (k < 2) base[k] = scan[k][0];
+        __syncthreads();
     }
-    __syncthreads();
+    // an icao_flush preceded this pass: it scores against the other (clean) bitmap; the one the passes
+    // before it used is cleared here, for the flush after this one
+    if (sd.exact_retired) {
+        uint4 *w = (uint4 *)sd.exact_retired;
+        for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < kBitmapAllocWords / 4; k += gridDim.x * blockDim.x)
+            w[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     adsb_msg *out = (adsb_msg *)sd.out_msgs;
     unsigned long long my_sum = 0;
     for (uint32_t i0 = first; i0 < last; i0 += blockDim.x) {
@@ -723,7 +740,9 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
     // dense pass (tens of hits per chunk) still has only a few hits per wave
     // (the count lives on the device: sized for a dense pass -- ~35 hits per buffer -- to leave a wave
     // one or two hits; on sparse input most blocks find nothing and leave at once)
-    uint32_t blocks = ADSB_REC_BLOCKS_PER_CHUNK * p.n_chunks + 8;
+    // (more, smaller blocks were measured on dense input -- 17 000 hits -- and are slower: 104 us
+    // against 55: shorter bursts of host stores)
+    uint32_t blocks = (uint32_t)ADSB_REC_BLOCKS_PER_CHUNK * p.n_chunks + 8;
     if (blocks > 4096) blocks = 4096;
     if (from_mag)
         hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);

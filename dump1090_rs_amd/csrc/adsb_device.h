@@ -158,6 +158,8 @@ struct ScoreDev {
     uint32_t *slot;                // per hit: the hash slot its key sits in (adders), else 0xFFFFFFFF
     uint32_t *blk;                 // per k_score block: emits, adds
     uint32_t *exact;               // 2^24 bits: the filter as it stands before this pass
+    uint32_t *exact_retired;       // after an icao_flush: the bitmap the passes before it used, for k_emit to
+                                   // clear (the next flush switches back to it), else null
     ScoreState *state;
     void *out_msgs;                // adsb_msg[cap], mapped host memory
     uint32_t *out_adds;            // mapped host memory: values handed to icao_filter_add, in order

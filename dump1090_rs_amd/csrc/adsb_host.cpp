@@ -53,6 +53,10 @@ struct Slot {
     int park_rc = 0;
     std::vector<adsb_msg> parked_msgs;
     adsb_stats parked_stats{};
+    ScoreDev score{};             // this slot's scoring buffers (the exact bitmap in it is the context's)
+    hipEvent_t recorded = nullptr;  // this pass's records kernel has finished (k_score may start; the superset
+                                    // bitmap it matched against may be cleared)
+    hipStream_t tail_q = nullptr;   // the stream its match / order / records ran on
     bool device_scored = false;   // this pass went through k_score / k_emit
     uint64_t score_epoch = 0;     // ... against the filter history of this epoch
     uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
@@ -91,6 +95,7 @@ struct adsb_ctx {
     // is ever needed.
     uint32_t *d_bitmap[kBitmaps] = {};
     int cur_bitmap = 0;
+    hipStream_t score_stream = nullptr;  // k_score / k_emit of the device-scored passes, in pass order
     hipStream_t tail_stream = nullptr;  // match + records of pass i run here, beside scan i+1
     // The scans run on two internal streams, alternating between consecutive pipelined passes:
     // those do not depend on each other (own lists and counters per slot; bits another scan
@@ -161,6 +166,8 @@ struct adsb_ctx {
     // disowns the device results of passes already in flight, and device scoring resumes once the
     // context is idle and the bitmap has been rebuilt from the host's table.
     ScoreDev score{};
+    uint32_t *exact_bm[2] = {nullptr, nullptr};  // the exact bitmap in use and the clean one an icao_flush switches to
+    int cur_exact = 0;
     bool exact_valid = false;
     uint64_t score_epoch = 0;
 #ifdef ADSB_TUNING
@@ -345,7 +352,13 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.device_scored = false;
     if (order_on_device && c->score.si) {
         if (c->exact_valid) {
-            p.score = c->score;
+            p.score = sl.score;
+            p.score.exact_retired = nullptr;
+            if (c->flush_pending) {  // icao_flush: this pass starts from the clean bitmap
+                p.score.exact_retired = c->exact_bm[c->cur_exact];
+                c->cur_exact ^= 1;
+            }
+            p.score.exact = c->exact_bm[c->cur_exact];
             p.score.out_msgs = sl.h_msgs_dev;
             p.score.out_adds = sl.h_adds_dev;
             p.score.summary = sl.h_ssum_dev;
@@ -417,8 +430,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (p.clean_bitmap && fast) {
         // this pass's records kernel clears the bitmap the previous passes matched against: not
         // before the pass still in flight (whichever stream its tail is on) is through with it
+        // (a pass whose tail ran on this same in-order stream is already behind us: only tails that
+        // ran elsewhere -- small passes keep theirs on their scan stream -- need the event; it is the
+        // one behind their records kernel, not `done`, which device-scored passes record later, on
+        // the score stream)
         for (Slot &other : c->slot)
-            if (&other != &sl && other.busy) HIP_TRY(c, hipStreamWaitEvent(ts, other.done, 0));
+            if (&other != &sl && other.busy && other.tail_q != ts) HIP_TRY(c, hipStreamWaitEvent(ts, other.recorded, 0));
     }
     if (!inline_tail) {
         HIP_TRY(c, hipEventRecord(sl.scanned, ss));
@@ -430,12 +447,21 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
     // the records kernel writes the records and the summary into the slot's mapped host
     // memory with write-through stores; `done` only has to say the kernel has drained
-    if (sl.device_scored && sl.flush_before)  // icao_flush: the filter this pass starts from is empty
-        HIP_TRY(c, hipMemsetAsync(c->score.exact, 0, kBitmapAllocWords * sizeof(uint32_t), ts));
     if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
         return fail(c, (hipError_t)e, "launch_records");
-    if (sl.device_scored)
-        if (int e = launch_score(p, ts)) return fail(c, (hipError_t)e, "launch_score");
+    sl.tail_q = ts;
+    if (sl.device_scored || ts != c->tail_stream) HIP_TRY(c, hipEventRecord(sl.recorded, ts));
+    if (sl.device_scored) {
+        // Scoring runs on its own in-order stream behind this pass's records kernel, so that the next
+        // pass's match / order / records (tail stream) overlap it: every kernel beside the persistent
+        // scan is latency, and one chain of eight would be longer than the scan it hides behind.
+        // The score stream's order is the filter's order: k_score(i+1) reads the exact bitmap after
+        // k_emit(i) has committed pass i's additions to it.
+        hipStream_t qs = c->score_stream;
+        HIP_TRY(c, hipStreamWaitEvent(qs, sl.recorded, 0));
+        if (int e = launch_score(p, qs)) return fail(c, (hipError_t)e, "launch_score");
+        ts = qs;
+    }
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
     HIP_TRY(c, hipEventRecord(sl.done, ts));
     return ADSB_OK;
@@ -466,8 +492,8 @@ int resync_exact(adsb_ctx *c)
     std::vector<uint32_t> addrs;
     for (uint32_t a : c->filter.table())
         if (a != 0 && a <= 0xFFFFFFu) addrs.push_back(a);
-    hipStream_t ts = c->tail_stream;
-    HIP_TRY(c, hipMemsetAsync(c->score.exact, 0, kBitmapAllocWords * sizeof(uint32_t), ts));
+    hipStream_t ts = c->score_stream;
+    for (uint32_t *bm : c->exact_bm) HIP_TRY(c, hipMemsetAsync(bm, 0, kBitmapAllocWords * sizeof(uint32_t), ts));
     if (!addrs.empty()) {
         if (addrs.size() > c->addrs_cap) {
             if (c->d_addrs) (void)hipFree(c->d_addrs);
@@ -477,7 +503,7 @@ int resync_exact(adsb_ctx *c)
             c->addrs_cap = IcaoFilter::kSize;
         }
         HIP_TRY(c, hipMemcpyAsync(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ts));
-        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->score.exact, ts))
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->exact_bm[c->cur_exact], ts))
             return fail(c, (hipError_t)e, "launch_set_addresses");
     }
     HIP_TRY(c, hipStreamSynchronize(ts));  // (rare: only after the host scored a pass itself)
@@ -620,6 +646,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         st.retries++;
         for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->score_stream));
         const bool keep_flush = c->flush_pending;
         c->flush_pending = false;
         Slot tmp;
@@ -632,6 +659,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         st.retries++;
         for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->score_stream));
         const bool keep_flush = c->flush_pending;
         c->flush_pending = false;
         Slot tmp;  // same counters, summary and events; one chunk at a time into the worst-case lists
@@ -866,22 +894,39 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         {
             // device-side scoring state (shared by the passes: they go through it one after the other
             // on the tail stream); passes of more hits than `cap` are scored on the host
-            ScoreDev &sd = c->score;
-            sd.cap = std::min<uint32_t>(c->hits_cap, 131072u);
+            ScoreDev &cd = c->score;   // cap / hash_mask / exact: the context's; the rest per slot
+            cd.cap = std::min<uint32_t>(c->hits_cap, 131072u);
             uint32_t hsize = 1;
-            while (hsize < 2 * sd.cap) hsize <<= 1;
-            sd.hash_mask = hsize - 1;
-            HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&sd.rec, (size_t)sd.cap * sizeof(TrialRecord)));
-            HIP_TRY(c, hipMalloc((void **)&sd.flag, (size_t)sd.cap * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&sd.slot, (size_t)sd.cap * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&sd.hash, (size_t)hsize * sizeof(unsigned long long)));
-            HIP_TRY(c, hipMemset(sd.hash, 0xFF, (size_t)hsize * sizeof(unsigned long long)));
-            HIP_TRY(c, hipMalloc((void **)&sd.blk, 2 * kScoreBlocks * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&sd.exact, kBitmapAllocWords * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemset(sd.exact, 0, kBitmapAllocWords * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&sd.state, sizeof(ScoreState)));
-            HIP_TRY(c, hipMemset(sd.state, 0, sizeof(ScoreState)));
+            while (hsize < 2 * cd.cap) hsize <<= 1;
+            cd.hash_mask = hsize - 1;
+            for (auto &bm : c->exact_bm) {
+                HIP_TRY(c, hipMalloc((void **)&bm, kBitmapAllocWords * sizeof(uint32_t)));
+                HIP_TRY(c, hipMemset(bm, 0, kBitmapAllocWords * sizeof(uint32_t)));
+            }
+            cd.exact = c->exact_bm[0];
+            cd.si = reinterpret_cast<uint32_t *>(cd.exact);  // (non-null: "scoring is available")
+            {
+                int least = 0, greatest = 0;
+                HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                int ps = least;  // with the tail stream's priority: its own hardware queue in that pool
+                if (const char *e = tuning_env("ADSB_SCORE_PRIO")) ps = std::atoi(e) == 2 ? greatest : (std::atoi(e) == 1 ? (least + greatest) / 2 : least);
+                HIP_TRY(c, hipStreamCreateWithPriority(&c->score_stream, hipStreamNonBlocking, ps));
+            }
+            for (Slot &sl : c->slot) {
+                ScoreDev &sd = sl.score;
+                sd = cd;
+                HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.rec, (size_t)sd.cap * sizeof(TrialRecord)));
+                HIP_TRY(c, hipMalloc((void **)&sd.flag, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.slot, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.hash, (size_t)hsize * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMemset(sd.hash, 0xFF, (size_t)hsize * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMalloc((void **)&sd.blk, 2 * kScoreBlocks * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.state, sizeof(ScoreState)));
+                HIP_TRY(c, hipMemset(sd.state, 0, sizeof(ScoreState)));
+                HIP_TRY(c, hipEventCreateWithFlags(&sl.recorded, hipEventDisableTiming | hipEventDisableSystemFence));
+            }
+            const ScoreDev &sd = cd;
             for (Slot &sl : c->slot) {
                 HIP_TRY(c, hipHostMalloc((void **)&sl.h_msgs, (size_t)sd.cap * sizeof(adsb_msg), hipHostMallocMapped | hipHostMallocCoherent));
                 HIP_TRY(c, hipHostMalloc((void **)&sl.h_adds, (size_t)sd.cap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -989,9 +1034,18 @@ void adsb_destroy(adsb_ctx *c)
         (void)hipStreamSynchronize(c->tail_stream);
         (void)hipStreamDestroy(c->tail_stream);
     }
-    for (void *q : {(void *)c->score.si, (void *)c->score.rec, (void *)c->score.flag, (void *)c->score.slot,
-                    (void *)c->score.hash, (void *)c->score.blk, (void *)c->score.exact, (void *)c->score.state})
-        if (q) (void)hipFree(q);
+    for (Slot &sl : c->slot) {
+        for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot,
+                        (void *)sl.score.hash, (void *)sl.score.blk, (void *)sl.score.state})
+            if (q && q != (void *)c->score.exact) (void)hipFree(q);
+        if (sl.recorded) (void)hipEventDestroy(sl.recorded);
+    }
+    for (uint32_t *bm : c->exact_bm)
+        if (bm) (void)hipFree(bm);
+    if (c->score_stream) {
+        (void)hipStreamSynchronize(c->score_stream);
+        (void)hipStreamDestroy(c->score_stream);
+    }
     if (c->fb.d_hits) (void)hipFree(c->fb.d_hits);
     if (c->fb.d_dap) (void)hipFree(c->fb.d_dap);
     if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
@@ -1673,6 +1727,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.7 gfx950 scan=v5-le-planes-xcd"; }
+const char *adsb_version(void) { return "adsb_hip 0.9 gfx950 scan=v6-markstein"; }
 
 }  // extern "C"
