@@ -2,7 +2,7 @@
 # gaps between consecutive k_scan_fast launches (end -> next start) from a rocprofv3 kernel trace
 # usage: tools/gaps.sh <tag> [bench args...]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }; T=$1; shift; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps_$T -o g -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/gaps_$T.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps_$T -o g -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also "$@" > $R/gpurun_out/gaps_$T.log 2>&1
 python3 - <<PY
 import csv, glob
 f=glob.glob('$R/gpurun_out/gaps_$T/**/g_kernel_trace.csv', recursive=True)[0]

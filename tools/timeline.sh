@@ -2,7 +2,7 @@
 # Timeline of the pipelined bench from a rocprofv3 kernel trace: per step the start / end of
 # scan, match and records relative to the previous scan's start.  usage: tools/timeline.sh <tag> [bench args]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }; T=$1; shift; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$T -o g -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/tl_$T.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$T -o g -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-also "$@" > $R/gpurun_out/tl_$T.log 2>&1
 python3 - <<PY
 import csv, glob
 f=glob.glob('$R/gpurun_out/tl_$T/**/g_kernel_trace.csv', recursive=True)[0]

@@ -2,7 +2,7 @@
 # HBM traffic of k_scan_fast from PMC counters (separate passes), per launch.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }; N=$1; cd /tmp; export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/$N/$ctr -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/$N/$ctr -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-also > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, collections, json
