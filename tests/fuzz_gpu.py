@@ -77,6 +77,56 @@ def okey(w):
     return (w["chunk"], w["j"], w["try_phase"], w["score"], w["len"], w["msg"], w["signal_level"])
 
 
+def dense_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
+    """A stream of passes that switches between the host's and the device's ordering / scoring:
+    dense passes of 17-30 buffers (thousands of records), the odd sparse or small one, random
+    icao_flush, up to three in flight -- every pass against the oracle fed the same sequence."""
+    chunks = int(rng.integers(17, 31))
+    n = chunks * CHUNK
+    n_icao = int(rng.integers(3, 40))
+    bufs, host = [], []
+    for k in range(3):
+        dense = rng.random() < 0.8
+        h = synth.make_iq(n, n_bursts=int(chunks * (rng.integers(70, 110) if dense else rng.integers(0, 6))),
+                          seed=int(rng.integers(1, 1 << 30)), n_icao=n_icao, df11_every=int(rng.integers(0, 5)))
+        host.append(h)
+        bufs.append(torch.from_numpy(h).cuda())
+    torch.cuda.synchronize()
+
+    def check(got, want, what):
+        if [key(m) for m in got] != [okey(w) for w in want]:
+            print(f"MISMATCH dense pipeline {case} (fuzz seed {seed}) at {what}: {len(got)} frames, {len(want)} expected")
+            sys.exit(1)
+
+    orc = Oracle()
+    ctx = Context(0, 32)
+    orc.icao_flush()
+    ctx.icao_flush()
+    pending = []   # expected outputs of the passes in flight
+    for step in range(int(rng.integers(6, 14))):
+        if rng.random() < 0.15 and not pending:     # a small blocking call in between (host-scored)
+            k = int(rng.integers(0, 3))
+            m = int(rng.integers(1, 4)) * CHUNK
+            check(ctx.demod_iq(host[k][:m]), orc.demod_iq(host[k][:m])[0], f"step {step} (small)")
+            continue
+        if rng.random() < 0.3:
+            orc.icao_flush()
+            ctx.icao_flush()
+        k = int(rng.integers(0, 3))
+        if len(pending) == 3:
+            check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
+        ctx.submit_iq_device(bufs[k].data_ptr(), n)
+        pending.append(orc.demod_iq(host[k], cap=1 << 18)[0])
+        if rng.random() < 0.4:
+            check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
+    while pending:
+        check(ctx.collect(cap=1 << 18), pending.pop(0), "drain")
+    modes[("dense_pipeline", False)] = modes.get(("dense_pipeline", False), 0) + 1
+    modes[("dense_pipeline:host_replays", False)] = modes.get(("dense_pipeline:host_replays", False), 0) + int(ctx._L.adsb_host_replays(ctx._h))
+    modes[("dense_pipeline:passes", False)] = modes.get(("dense_pipeline:passes", False), 0) + int(step)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -85,6 +135,9 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="replay just this case of the seed")
     ap.add_argument("--api", default="", help="with --only: force this entry point")
     ap.add_argument("--ringcuts", action="store_true", help="with --only: cut every 2 buffers, as the ring does")
+    ap.add_argument("--dense", type=int, default=8,
+                    help="also run this many dense pipelines: passes of 17-30 buffers with thousands of trial records "
+                         "each (ordered and scored on the device), random flushes, small and sparse passes between")
     args = ap.parse_args()
     import torch
     from dump1090_rs_amd import Context, sharding, synth
@@ -197,6 +250,9 @@ def main():
                         print(" first difference:", x, y)
                         break
             sys.exit(1)
+    if args.only < 0:
+        for k in range(args.dense):
+            dense_pipeline_case(np.random.default_rng([args.seed, k]), synth, Context, binding.Oracle, torch, modes, k, args.seed)
     print(f"{args.cases} cases identical in {time.time() - t0:.1f} s; modes: "
           + ", ".join(f"{k[0]}{'+carry' if k[1] else ''}={v}" for k, v in sorted(modes.items())))
 

@@ -822,10 +822,10 @@ def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
     import subprocess
     import sys
     from tests.conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "80", "--seed", "7"],
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "80", "--seed", "7", "--dense", "5"],
                        capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "80 cases identical" in r.stdout
+    assert "80 cases identical" in r.stdout and "dense_pipeline=5" in r.stdout   # (+ 5 dense pipelines: device-side order / score)
 
 
 def test_inputs_longer_than_the_context_was_sized_for(hip_lib, oracle_mod):
