@@ -459,7 +459,7 @@ def stream_result(env: Env, args, s):
 def run_shard(env: Env, args):
     """ONE capture of world x --chunks buffers; rank r owns buffers [r*chunks, (r+1)*chunks).  A step =
     icao_flush + adsb_shard_scan on every rank, a host-side exchange of the addresses the shards
-    learned (a few KB, object collective: not on the data path), adsb_shard_finish, the trial records
+    learned (a few KB, two tensor all-gathers: the one real exchange step), adsb_shard_finish, the trial records
     gathered on rank 0 and replayed once in global (buffer, j, try_phase) order: the reference's loop
     dump1090_rs/src/main.rs:161-167 over the whole capture.  Checked: the merged frame list equals
     the single-stream result of rank 0 demodulating the whole capture alone."""
@@ -519,8 +519,8 @@ def run_shard(env: Env, args):
                                "HBM (BASELINE config 4); a step = icao_flush + shard scan on every rank + host-side "
                                "exchange of learned addresses + match + records gathered and replayed once on rank 0",
                    "per_gpu_samples_per_step": n,
-                   "sharding": "contiguous buffer ranges, no data-path collective; addresses / records exchanged "
-                               "through the host (torch.distributed object collectives)",
+                   "sharding": "contiguous buffer ranges, the IQ never moves; learned addresses and trial records "
+                               "exchanged with fixed-size tensor all-gathers (RCCL, or gloo)",
                    "host_api": "adsb_shard_scan / adsb_shard_finish / adsb_replay_records (blocking, two phases)",
                    "library": _lib.lib().adsb_version().decode()},
         "shard_merge_equals_single_stream": same, "parity_frames": n_frames,

@@ -9,9 +9,9 @@ call).  Two ways to use N GPUs:
   running one dump1090_rs per SDR.  torch.distributed is used for the barrier and for
   reducing the timing, nothing else.
 * one capture, exact (`demod_sharded`): the ranks' results are merged into what a single
-  stream would have produced.  The filter is the only coupling, so the exchange is host-side
-  and tiny: the addresses each shard learned (all_gather of a few u32) and the raw trial
-  records (gather to rank 0, a few per buffer), then one ordered replay on rank 0.
+  stream would have produced.  The filter is the only coupling, so the exchange is tiny: the
+  addresses each shard learned and the raw trial records (a few per buffer), each as two
+  fixed-size tensor all-gathers (RCCL over xGMI, or gloo), then one ordered replay on rank 0.
 """
 from __future__ import annotations
 
@@ -59,30 +59,61 @@ def merge_records(shard_records, chunk_bases):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=shard_records[0].dtype)
 
 
+def _coll_device(dist):
+    """Where collective tensors live: the GPU for RCCL ("nccl"), the host for gloo."""
+    import torch
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _all_gather_ragged(dist, mine_u8):
+    """All ranks' byte strings (numpy uint8), gathered with two fixed-size tensor collectives: the
+    lengths, then the payloads padded to the longest.  No pickling: this is the exchange step of the
+    sharded form, and over RCCL it is one small all-gather over xGMI."""
+    import numpy as np
+    import torch
+
+    dev = _coll_device(dist)
+    world = dist.get_world_size()
+    n = torch.tensor([mine_u8.size], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n)
+    counts = counts.cpu().numpy()
+    width = max(int(counts.max()), 1)
+    pad = np.zeros(width, dtype=np.uint8)
+    pad[: mine_u8.size] = mine_u8
+    out = torch.zeros(world * width, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, torch.from_numpy(pad).to(dev))
+    out = out.cpu().numpy().reshape(world, width)
+    return [out[r, : int(counts[r])] for r in range(world)]
+
+
 def exchange_addresses(dist, mine):
-    """Union of every rank's learned addresses (sorted u32).  Object collectives: a few KB."""
+    """Union of every rank's learned addresses (sorted u32): a few KB per rank."""
     import numpy as np
 
+    mine = np.ascontiguousarray(np.asarray(mine, dtype=np.uint32))
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.asarray(mine, dtype=np.uint32)
-    lists = [None] * dist.get_world_size()
-    dist.all_gather_object(lists, np.asarray(mine, dtype=np.uint32).tobytes())
-    allv = np.concatenate([np.frombuffer(b, dtype=np.uint32) for b in lists]) if lists else np.zeros(0, np.uint32)
+        return mine
+    parts = _all_gather_ragged(dist, mine.view(np.uint8))
+    allv = np.concatenate([np.frombuffer(p.tobytes(), dtype=np.uint32) for p in parts]) if parts else np.zeros(0, np.uint32)
     return np.unique(allv)
 
 
 def gather_records(dist, mine, chunk_base: int):
-    """All shards' records on rank 0, `chunk` global (None on the other ranks)."""
+    """All shards' records on rank 0, `chunk` made global (None on the other ranks)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return merge_records([mine], [chunk_base])
     import numpy as np
 
-    world, rank = dist.get_world_size(), dist.get_rank()
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object((mine.tobytes(), int(chunk_base)), parts, dst=0)
-    if rank != 0:
+    head = np.array([chunk_base], dtype=np.int64).view(np.uint8)
+    body = np.ascontiguousarray(mine).view(np.uint8).reshape(-1)
+    parts = _all_gather_ragged(dist, np.concatenate([head, body]))
+    if dist.get_rank() != 0:
         return None
-    return merge_records([np.frombuffer(b, dtype=mine.dtype) for b, _ in parts], [base for _, base in parts])
+    recs = [np.frombuffer(p[8:].tobytes(), dtype=mine.dtype) for p in parts]
+    bases = [int(np.frombuffer(p[:8].tobytes(), dtype=np.int64)[0]) for p in parts]
+    return merge_records(recs, bases)
 
 
 def demod_sharded(ctx, device_ptr: int, n_samples: int, chunk_base: int, dist=None, filter_table=None):
