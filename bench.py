@@ -60,9 +60,10 @@ def parse(argv=None):
     ap.add_argument("--timed-profiling", type=int, default=1,
                     help="HIP-event level inside the timed region (1 = scan kernel stamped by its "
                          "own launch; 0 = none, then roofline numbers come from the untimed repeat)")
-    ap.add_argument("--depth", type=int, default=3,
-                    help="passes in flight in the pipelined form (<= ADSB_MAX_IN_FLIGHT = 3): with 3 the "
-                         "next scan is always queued on the device while the host collects")
+    ap.add_argument("--depth", type=int, default=4,
+                    help="passes in flight in the pipelined form (<= ADSB_MAX_IN_FLIGHT = 4): from 3 on the next "
+                         "scan is always queued on the device while the host collects; a dense stream, whose "
+                         "passes are ordered and scored by six more small kernels, needs the fourth")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test (no GPU, no measurement): the ranks rendezvous over gloo, "
                          "barrier, and rank 0 prints a line that says so")
@@ -182,7 +183,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = 1 << 20
     out = (AdsbMsg * cap)()
-    depth = max(1, min(3, args.depth))
+    depth = max(1, min(4, args.depth))
 
     def run_steps(first: int, count: int, level: int):
         """`count` steps starting at step index `first`.  A step is ONE icao_flush
@@ -374,7 +375,7 @@ def run_stream(env: Env, chunks: int, steps: int, warmup: int, min_seconds: floa
     cap = 1 << 18
     out = (AdsbMsg * cap)()
     ctx.icao_flush()
-    slots = 3
+    slots = 4
     host_copies = []
     for k in range(slots):  # fill every pinned slot (and warm up)
         buf = ctx.ring_acquire()
@@ -385,7 +386,7 @@ def run_stream(env: Env, chunks: int, steps: int, warmup: int, min_seconds: floa
         ctx.collect_raw(out, cap)
     parity = None
     if check:
-        # the same bytes through the CPU oracle as one stream: slot 0, 1, 2 and then slot 0 again
+        # the same bytes through the CPU oracle as one stream: every slot in turn, then slot 0 again
         from oracle import binding
         orc = binding.Oracle()
         orc.icao_flush()
@@ -413,7 +414,7 @@ def run_stream(env: Env, chunks: int, steps: int, warmup: int, min_seconds: floa
         ctx.ring_acquire()
         ctx.ring_submit(n)
         i += 1
-        if i >= 3:  # three passes in flight (ADSB_MAX_IN_FLIGHT): the ring has as many slots
+        if i >= 3:  # three passes in flight (the ring has ADSB_MAX_IN_FLIGHT = 4 slots)
             frames += ctx.collect_raw(out, cap)
             scan_ms += ctx.stats_raw().ms_scan
             done += 1

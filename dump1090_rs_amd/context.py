@@ -185,7 +185,7 @@ class Context:
         self._check(st, "adsb_demod_iq_device")
         return n.value
 
-    # -- pipelined form: keep up to three passes in flight (ADSB_MAX_IN_FLIGHT), results in submission order
+    # -- pipelined form: keep up to four passes in flight (ADSB_MAX_IN_FLIGHT), results in submission order
     def submit_iq_device(self, device_ptr: int, n_samples: int) -> None:
         self._check(self._L.adsb_submit_iq_device(self._h, C.c_void_p(device_ptr), n_samples),
                     "adsb_submit_iq_device")

@@ -69,7 +69,7 @@ struct Slot {
     int profiled = 0;  // profiling level the pass was enqueued with
 };
 
-constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 3: the device never waits for the host between passes
+constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 4: the device never waits for the host between passes (3 do for sparse streams; a dense one has a longer tail)
 constexpr int kBitmaps = kSlots + 1;
 
 constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup

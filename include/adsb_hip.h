@@ -60,7 +60,7 @@ typedef enum {
     ADSB_ERR_BUSY = -7       /* submissions pending where none are allowed, or too many in flight */
 } adsb_status;
 
-#define ADSB_MAX_IN_FLIGHT 3
+#define ADSB_MAX_IN_FLIGHT 4
 
 typedef struct adsb_ctx adsb_ctx;
 
@@ -99,7 +99,7 @@ typedef struct {
  * `max_chunks` 131072-sample buffers per call (host-pointer calls stage through
  * a device buffer of that size; device-pointer calls only size the lists).
  * Device memory: ~7.5 MB for max_chunks = 1 (three 2 MiB address bitmaps and the
- * lists of three passes in flight), ~220 MB for 512; input denser than the lists are
+ * lists of four passes in flight), ~300 MB for 512; input denser than the lists are
  * sized for (several times a busy airspace) is still demodulated exactly, buffer
  * by buffer through worst-case lists allocated on first use (stats.retries). */
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks);

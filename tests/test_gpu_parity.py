@@ -522,16 +522,17 @@ def test_submit_collect_matches_blocking_calls_and_orders_flushes(ctx, oracle_mo
     ctx.submit_iq_device(bufs[0].data_ptr(), n)
     ctx.submit_iq_device(bufs[1].data_ptr(), n)
     assert ctx.pending() == 2
-    spare = torch.zeros(4 * 131072, dtype=torch.int32, device="cuda")   # ADSB_MAX_IN_FLIGHT = 3
+    spare = torch.zeros(4 * 131072, dtype=torch.int32, device="cuda")   # ADSB_MAX_IN_FLIGHT = 4
     ctx.submit_iq_device(spare.data_ptr(), 131072)
-    with pytest.raises(AdsbError) as ei:                      # a fourth one does not fit
+    ctx.submit_iq_device(spare.data_ptr(), 131072)
+    with pytest.raises(AdsbError) as ei:                      # a fifth one does not fit
         ctx.submit_iq_device(bufs[2].data_ptr(), n)
     assert ei.value.status == ADSB_ERR_BUSY
     with pytest.raises(AdsbError):                            # blocking calls refuse while pending
         ctx.demod_iq_device(bufs[2].data_ptr(), n)
     got.append(ctx.collect())
     got.append(ctx.collect())
-    assert ctx.collect() == []                                # the all-zero buffer
+    assert ctx.collect() == [] and ctx.collect() == []        # the all-zero buffers
     ctx.icao_flush()
     ctx.submit_iq_device(bufs[2].data_ptr(), n)
     ctx.submit_iq_device(bufs[0].data_ptr(), n)
@@ -875,15 +876,17 @@ def test_abi_misuse_is_refused_not_crashed(hip_lib):
     assert L.adsb_ring_create(h, 131072) == 0
     assert L.adsb_ring_create(h, 131072) == INVALID                                                   # once only
     assert L.adsb_ring_submit(h, 131073) == INVALID
-    # three in flight (ADSB_MAX_IN_FLIGHT), the fourth is refused; blocking calls are refused while passes are pending
+    # four in flight (ADSB_MAX_IN_FLIGHT), the fifth is refused; blocking calls are refused while passes are pending
+    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
     assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
     assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
     assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
     assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == BUSY
     assert L.adsb_demod_iq_device(h, C.c_void_p(ptr), 1000, out, 16, C.byref(n)) == BUSY
     assert L.adsb_set_carry_over(h, 1) == BUSY
-    assert L.adsb_pending(h) == 3
+    assert L.adsb_pending(h) == 4
     assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and n.value == 0
+    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 2
     assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 1
     assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 0
     # too small an output array: the count comes back, the first `cap` entries are written
