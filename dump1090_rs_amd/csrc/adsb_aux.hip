@@ -303,12 +303,12 @@ __global__ __launch_bounds__(256) void k_score(ScanParams p)
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
     uint32_t emits = 0, addc = 0;
     for (uint32_t i = first + threadIdx.x; i < last; i += blockDim.x) {
-        const uint64_t pos = score_pos(sd.rec[i]);
+        const uint64_t pos = sd.pos[i];
         uint32_t g0 = i;
-        while (g0 > 0 && i - g0 < 8 && score_pos(sd.rec[g0 - 1]) == pos) g0--;
+        while (g0 > 0 && i - g0 < 8 && sd.pos[g0 - 1] == pos) g0--;
         int best = -2, mine = -2;
         uint32_t win = 0xFFFFFFFFu, my_add = 0;
-        for (uint32_t k = g0; k < n && k < g0 + 16 && score_pos(sd.rec[k]) == pos; k++) {
+        for (uint32_t k = g0; k < n && k < g0 + 16 && sd.pos[k] == pos; k++) {
             uint32_t a;
             const int s = score_trial(sd, k, &a);
             if (k == i) {
@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
     __shared__ uint32_t base[2], scan[2][256];
     __shared__ unsigned long long stage[5 * 256];  // this round's messages, 40 bytes each
+    __shared__ uint32_t wtot[2][4];
     {
         // what the blocks before this one write: all threads fetch, one reduction (kScoreBlocks == blockDim)
         const uint32_t k = threadIdx.x;
@@ -372,15 +373,24 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
     for (uint32_t i0 = first; i0 < last; i0 += blockDim.x) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t f = i < last ? sd.flag[i] : 0u;
-        scan[0][threadIdx.x] = f & 1u;
-        scan[1][threadIdx.x] = (f >> 1) & 1u;
-        __syncthreads();
-        for (uint32_t off = 1; off < 256; off <<= 1) {
-            const uint32_t a0 = threadIdx.x >= off ? scan[0][threadIdx.x - off] : 0u;
-            const uint32_t a1 = threadIdx.x >= off ? scan[1][threadIdx.x - off] : 0u;
+        {
+            // inclusive scan of the two flags over the block: ballots inside a wave, four wave totals
+            const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+            const unsigned long long m0 = __ballot(f & 1u), m1 = __ballot((f >> 1) & 1u);
+            const unsigned long long below = ln == 63u ? ~0ull : ((1ull << (ln + 1u)) - 1ull);
+            const uint32_t i0 = (uint32_t)__popcll(m0 & below), i1 = (uint32_t)__popcll(m1 & below);
+            if (ln == 0) {
+                wtot[0][wv] = (uint32_t)__popcll(m0);
+                wtot[1][wv] = (uint32_t)__popcll(m1);
+            }
             __syncthreads();
-            scan[0][threadIdx.x] += a0;
-            scan[1][threadIdx.x] += a1;
+            uint32_t b0w = 0, b1w = 0;
+            for (uint32_t k = 0; k < wv; k++) {
+                b0w += wtot[0][k];
+                b1w += wtot[1][k];
+            }
+            scan[0][threadIdx.x] = b0w + i0;
+            scan[1][threadIdx.x] = b1w + i1;
             __syncthreads();
         }
         if (i < last) {
@@ -586,6 +596,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
                     const uint32_t v = ap ? crc : addr;
                     p.score.si[b0 + q] = v | (kind << 24);
                     p.score.rec[b0 + q] = r;
+                    p.score.pos[b0 + q] = score_pos(r);
                     p.score.slot[b0 + q] = (kind == kSkDf11Iid0 || kind == kSkDf17) ? score_hash_insert(p.score, v, b0 + q)
                                                                                    : 0xFFFFFFFFu;
                 }

@@ -152,7 +152,8 @@ struct ScoreDev {
     uint32_t cap;                  // hits a pass may have to be scored here
     uint32_t *si;                  // per hit: value24 | kind << 24
     TrialRecord *rec;              // per hit: the record (device copy)
-    uint32_t *flag;                // per hit: bit 0 emit, bit 1 add; bits 8.. : score + 2
+    unsigned long long *pos;       // per hit: buffer << 24 | j (what groups the five trial phases of a position)
+    uint32_t *flag;                // per hit: bit 0 emit, bit 1 add; bits 8.. : score + 3
     unsigned long long *hash;      // adders: (value << 32 | first index), ~0 = empty
     uint32_t hash_mask;
     uint32_t *slot;                // per hit: the hash slot its key sits in (adders), else 0xFFFFFFFF

@@ -918,6 +918,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                 HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
                 HIP_TRY(c, hipMalloc((void **)&sd.rec, (size_t)sd.cap * sizeof(TrialRecord)));
                 HIP_TRY(c, hipMalloc((void **)&sd.flag, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.pos, (size_t)sd.cap * sizeof(unsigned long long)));
                 HIP_TRY(c, hipMalloc((void **)&sd.slot, (size_t)sd.cap * sizeof(uint32_t)));
                 HIP_TRY(c, hipMalloc((void **)&sd.hash, (size_t)hsize * sizeof(unsigned long long)));
                 HIP_TRY(c, hipMemset(sd.hash, 0xFF, (size_t)hsize * sizeof(unsigned long long)));
@@ -1035,7 +1036,7 @@ void adsb_destroy(adsb_ctx *c)
         (void)hipStreamDestroy(c->tail_stream);
     }
     for (Slot &sl : c->slot) {
-        for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot,
+        for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot, (void *)sl.score.pos,
                         (void *)sl.score.hash, (void *)sl.score.blk, (void *)sl.score.state})
             if (q && q != (void *)c->score.exact) (void)hipFree(q);
         if (sl.recorded) (void)hipEventDestroy(sl.recorded);
