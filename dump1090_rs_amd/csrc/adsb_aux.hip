@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
     const uint32_t n = sd.state->n;
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
+    static_assert(kScoreBlocks == 256, "the block-offset reduction below takes one earlier block per thread");
     __shared__ uint32_t base[2], scan[2][256];
     __shared__ unsigned long long stage[5 * 256];  // this round's messages, 40 bytes each
     __shared__ uint32_t wtot[2][4];
@@ -461,10 +462,11 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
         }
         const unsigned long long ms = atomicAdd(&sd.state->msg_sum, 0ull);
         uint32_t *sm = (uint32_t *)sd.summary;
-        const uint32_t vals[8] = {nm, na, (uint32_t)ms, (uint32_t)(ms >> 32), n ? 1u : 0u, 0u, 0u, sd.seq};
+        const uint32_t vals[8] = {nm, na, (uint32_t)ms, (uint32_t)(ms >> 32), sd.state->scored, 0u, 0u, sd.seq};
 #pragma unroll
         for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
         sd.state->n = 0;
+        sd.state->scored = 0;
         sd.state->blocks_done = 0;
         sd.state->msg_sum = 0;
     }
@@ -646,7 +648,9 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
             uint32_t *sm = (uint32_t *)p.summary;
             if (p.score.si) {
                 const uint32_t nh = p.ctr->n_hits;
-                p.score.state->n = (p.ctr->overflow || nh > p.score.cap) ? 0u : nh;
+                const bool ok = !p.ctr->overflow && nh <= p.score.cap;
+                p.score.state->n = ok ? nh : 0u;
+                p.score.state->scored = ok ? 1u : 0u;
             }
             const unsigned long long rs = atomicAdd((unsigned long long *)p.ctr->rec_sum, 0ull);
             const uint32_t vals[8] = {p.ctr->n_hits, p.ctr->overflow, (uint32_t)rs, p.ctr->n_dap,

@@ -138,7 +138,8 @@ constexpr int kTabR16Off = kTabCount * 256, kTabFieldOff = kTabR16Off + 16, kTab
 struct ScoreState {
     uint32_t n;            // hits of this pass (0 when it is not to be scored: overflow, too many)
     uint32_t blocks_done;  // k_emit
-    uint32_t n_msgs, n_adds;
+    uint32_t scored;       // 1: k_score / k_emit handle this pass (a pass without a single hit included)
+    uint32_t reserved;
     unsigned long long msg_sum;  // 64-bit sum of every u64 word of the messages written
 };
 struct ScoreSummary {      // in mapped host memory
