@@ -11,6 +11,14 @@ namespace {
 // to_mag alone (adsb_to_mag).  data[0..326) = 0, data[326+k] = mag(iq[k]), rest 0
 // (src/lib.rs:36-50, src/utils.rs:43-58).
 // ---------------------------------------------------------------------------
+// The tail kernels are a dependent chain of small launches that run beside a scan which keeps every
+// SIMD's vector pipe busy: their waves ask for issue priority, so the chain costs the scan the cycles
+// it needs instead of waiting for the cycles the scan leaves (-DADSB_TAIL_PRIO=0: measurement).
+#ifndef ADSB_TAIL_PRIO
+#define ADSB_TAIL_PRIO 3
+#endif
+#define TAIL_PRIO() __builtin_amdgcn_s_setprio(ADSB_TAIL_PRIO)
+
 __global__ __launch_bounds__(256) void k_to_mag(const uint32_t *__restrict__ iq, uint32_t n,
                                                 uint16_t *__restrict__ data)
 {
@@ -49,6 +57,7 @@ __device__ __forceinline__ uint32_t gf_apply(const uint32_t *tab3, uint32_t h)
 
 __global__ __launch_bounds__(256) void k_match(ScanParams p)
 {
+    if (p.order_cnt) TAIL_PRIO();  // dense streams only: elsewhere the scan is what bounds the step
     // the x^56 multiplier table (3 KB) and the bitmap's 4096-bit summary in LDS: an entry costs
     // one coalesced 8-byte load and LDS lookups; only the few per cent of residuals whose low 12
     // bits are taken by some address go on to the 2 MiB bitmap
@@ -132,6 +141,7 @@ __device__ __forceinline__ uint64_t order_key(uint64_t e)
 
 __global__ __launch_bounds__(1024) void k_order_prefix(ScanParams p)
 {
+    TAIL_PRIO();
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
     const uint32_t tid = threadIdx.x;
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(1024) void k_order_prefix(ScanParams p)
 
 __global__ __launch_bounds__(256) void k_order_scatter(ScanParams p)
 {
+    TAIL_PRIO();
     if (p.ctr->overflow) return;
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -172,6 +183,7 @@ __global__ __launch_bounds__(256) void k_order_scatter(ScanParams p)
 
 __global__ __launch_bounds__(256) void k_order_rank(ScanParams p)
 {
+    TAIL_PRIO();
     if (p.ctr->overflow) return;
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -221,9 +233,6 @@ __device__ __forceinline__ uint32_t icao_hash_dev(uint32_t a)
     return (uint32_t)h & 4095u;
 }
 
-#ifndef ADSB_REC_BLOCKS_PER_CHUNK
-#define ADSB_REC_BLOCKS_PER_CHUNK 1
-#endif
 // ---------------------------------------------------------------------------
 // device-side scoring (adsb_device.h: ScoreDev).  first index at which an address is added: an
 // open-addressing table of (value << 32 | index), atomic-min per key.
@@ -297,6 +306,7 @@ __device__ __forceinline__ uint64_t score_pos(const TrialRecord &r) { return (ui
 // (src/demod_2400.rs:149-207: strictly greater wins, from -2; emitted when >= 0) and what it adds.
 __global__ __launch_bounds__(256) void k_score(ScanParams p)
 {
+    TAIL_PRIO();
     const ScoreDev &sd = p.score;
     const uint32_t n = sd.state->n;
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(256) void k_score(ScanParams p)
 // the additions committed to the exact bitmap, the hash table left empty, the summary last.
 __global__ __launch_bounds__(256) void k_emit(ScanParams p)
 {
+    TAIL_PRIO();
     const ScoreDev &sd = p.score;
     const uint32_t n = sd.state->n;
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -454,12 +465,24 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
     __syncthreads();
     if (!is_last) return;
     // the last block: totals and summary, then the state and the hash table back to empty
-    if (threadIdx.x == 0) {
-        uint32_t nm = 0, na = 0;
-        for (uint32_t k = 0; k < gridDim.x; k++) {
-            nm += sd.blk[2 * k];
-            na += sd.blk[2 * k + 1];
+    __shared__ uint32_t tot[2][4];
+    {
+        uint32_t nm = threadIdx.x < gridDim.x ? sd.blk[2 * threadIdx.x] : 0u;   // kScoreBlocks == blockDim.x
+        uint32_t na = threadIdx.x < gridDim.x ? sd.blk[2 * threadIdx.x + 1] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nm += __shfl_down(nm, off);
+            na += __shfl_down(na, off);
         }
+        if ((threadIdx.x & 63) == 0) {
+            tot[0][threadIdx.x >> 6] = nm;
+            tot[1][threadIdx.x >> 6] = na;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nm = tot[0][0] + tot[0][1] + tot[0][2] + tot[0][3];
+        const uint32_t na = tot[1][0] + tot[1][1] + tot[1][2] + tot[1][3];
         const unsigned long long ms = atomicAdd(&sd.state->msg_sum, 0ull);
         uint32_t *sm = (uint32_t *)sd.summary;
         const uint32_t vals[8] = {nm, na, (uint32_t)ms, (uint32_t)(ms >> 32), sd.state->scored, 0u, 0u, sd.seq};
@@ -473,11 +496,17 @@ __global__ __launch_bounds__(256) void k_emit(ScanParams p)
 }
 
 constexpr int kRecWindow = 296;   // magnitudes a trial can touch: data[j+19 .. j+290], rounded up
+constexpr int kRecRow = 320;      // a window's row in LDS: five magnitudes per lane, stored unguarded
 constexpr int kRecBatch = 64;     // records a block stages before writing them out together
+#ifndef ADSB_REC_GROUP
+#define ADSB_REC_GROUP 4
+#endif
+constexpr int kRecGroup = ADSB_REC_GROUP;  // hits a wave works on at once
 
 template <bool FROM_MAG>
 __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 {
+    if (p.order_cnt) TAIL_PRIO();  // dense streams only: elsewhere the scan is what bounds the step
     const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Housekeeping so that no pass needs a reset launch: after an icao_flush retired a
@@ -487,11 +516,11 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     if (p.clean_bitmap) bitmap_clear(p.clean_bitmap, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     // A block owns a contiguous run of hits, so its records leave as one contiguous burst of
     // 16-byte stores (mapped host memory sits behind PCIe: thousands of separate 8-byte writes
-    // cost ~6 ns each, wide neighbouring ones combine).  One wave per hit: the window of
+    // cost ~6 ns each, wide neighbouring ones combine).  Per hit, a wave: the window of
     // magnitudes behind j is rebuilt from IQ into LDS with coalesced loads (rare path: a handful
     // of hits per chunk, so magnitudes are never kept in HBM), lanes are message bits
     // (demod_2400.rs:158-182), the 33-sample power is summed (:191-196).
-    __shared__ uint16_t win[4][kRecWindow];
+    __shared__ uint16_t win[4][kRecGroup][kRecRow];
     __shared__ alignas(16) TrialRecord stage[kRecBatch];
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
@@ -499,116 +528,188 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     const bool do_score = p.score.si && n <= p.score.cap && !p.ctr->overflow;  // (uniform) k_score follows
     for (uint32_t b0 = first; b0 < last; b0 += kRecBatch) {
         const uint32_t cnt = min((uint32_t)kRecBatch, last - b0);
-        for (uint32_t q = wave; q < cnt; q += 4) {
-            const uint64_t e = p.hits[b0 + q];
-            const uint64_t chunk = entry_chunk(e);
-            const uint32_t j = entry_j(e), tp = entry_tp(e);
-            // win[k] = data[j + 19 + k]
+        // A wave takes kRecGroup hits at a time and lane h writes the record of the group's hit h.
+        // Beside a scan only one wave of this kernel fits a SIMD (the scan leaves 96 registers), so the
+        // group is the wave's only source of independent work: its hits' memory latencies (entry, IQ
+        // window, residual constants, hash insertion) and LDS round trips overlap.  On its own that
+        // changed nothing measurable; what did (dense stream: step -7 %) is the instruction count per
+        // hit -- range-checked buffer loads instead of four compares and branches per IQ word, two
+        // magnitudes per pass of the packed arithmetic, a slicer without the five-way branch on the
+        // phase: 1375 -> 906 vector and 274 -> 82 branch instructions per group of four.
+        for (uint32_t g0 = wave * kRecGroup; g0 < cnt; g0 += 4 * kRecGroup) {
+            const uint32_t ng = min((uint32_t)kRecGroup, cnt - g0);
+            uint64_t e[kRecGroup];
+#pragma unroll
+            for (int h = 0; h < kRecGroup; h++) {
+                // (every lane reads the same entry; made wave-uniform for the buffer resource below)
+                const uint64_t v = p.hits[b0 + g0 + min((uint32_t)h, ng - 1u)];  // (past ng: a repeat, unused)
+                e[h] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            }
+            // win[h][k] = data[j_h + 19 + k]
             if (FROM_MAG) {
-                for (int k = lane; k < kRecWindow; k += 64) {
-                    const int d = (int)j + 19 + k;
-                    win[wave][k] = d < kMagDataLen ? ((const uint16_t *)p.src)[d] : (uint16_t)0;
-                }
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h++)
+                    for (int k = lane; k < kRecWindow; k += 64) {
+                        const int d = (int)entry_j(e[h]) + 19 + k;
+                        win[wave][h][k] = d < kMagDataLen ? ((const uint16_t *)p.src)[d] : (uint16_t)0;
+                    }
             } else {
-                const int len = chunk_len(p.n_samples, chunk);
-                const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
-                const bool lead = p.carry != nullptr && (chunk > 0 || p.lead_from_src);
-                // (all five loads of a lane are issued before the first magnitude: one latency, not five)
-                uint32_t w[(kRecWindow + 63) / 64];
+                // The IQ behind the window through a buffer resource that spans exactly the samples this
+                // buffer may see (as the scan's tile loads, adsb_scan_fast.hip: load_tile_iq): the range
+                // check returns zero before the start, past the ragged end of a short last buffer, and
+                // -- carry-over mode -- the resource starts kCarrySamples early when those samples are
+                // in src.  No branch per load, and all loads of the group are in flight together.
+                constexpr int kQ = kRecRow / 64;  // 5 per lane (the row is a little longer than the window)
+                static_assert(kRecRow % 64 == 0 && kRecRow >= kRecWindow, "whole lanes");
+                uint32_t w[kRecGroup][kQ + 1];
 #pragma unroll
-                for (int q5 = 0; q5 < (kRecWindow + 63) / 64; q5++) {
-                    const int k = lane + 64 * q5;
-                    const int s = (int)j + 19 + k - kLead;  // IQ sample behind data[j+19+k]
-                    w[q5] = 0;
-                    if (k >= kRecWindow) continue;
-                    if (s >= 0 && s < len)
-                        w[q5] = iq[s];
-                    else if (s < 0 && lead)                 // carry-over mode: the samples before
-                        w[q5] = *(iq + s);
-                    else if (s < 0 && p.carry != nullptr)
-                        w[q5] = p.carry[s + kCarrySamples];
+                for (int h = 0; h < kRecGroup; h++) {
+                    const uint64_t chunk = entry_chunk(e[h]);
+                    const int len = chunk_len(p.n_samples, chunk);
+                    const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
+                    const bool lead = p.carry != nullptr && (chunk > 0 || p.lead_from_src);
+                    const int shift = lead ? kCarrySamples : 0;
+                    const __amdgpu_buffer_rsrc_t rsrc =
+                        __builtin_amdgcn_make_buffer_rsrc((void *)(iq - shift), 0, (len + shift) * 4, 0x00020000);
+                    const int s0 = (int)entry_j(e[h]) + 19 - kLead + shift + lane;  // IQ sample behind data[j+19+lane]
+                    // (each offset is made opaque: left to itself the compiler folds the "+ 256 q5" into the
+                    // instruction's immediate offset, and the hardware adds that to the register offset
+                    // without wrapping at 32 bits -- a negative register offset plus a positive immediate
+                    // is then out of range although their sum is not.  Seen: zeros for samples 0 and 1.)
+                    int off[kQ];
+#pragma unroll
+                    for (int q5 = 0; q5 < kQ; q5++) {
+                        off[q5] = (s0 + 64 * q5) * 4;
+                        asm volatile("" : "+v"(off[q5]));
+                        w[h][q5] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[q5], 0, 0);
+                    }
+                    w[h][kQ] = 0;
+                    if (p.carry != nullptr && !lead) {
+                        // first buffer of a call: the samples before it are the end of the previous call
+                        // (one resource's zero is the other's sample: the two loads OR together)
+                        const __amdgpu_buffer_rsrc_t crsrc =
+                            __builtin_amdgcn_make_buffer_rsrc((void *)p.carry, 0, kCarrySamples * 4, 0x00020000);
+#pragma unroll
+                        for (int q5 = 0; q5 < kQ; q5++) {
+                            int coff = off[q5] + kCarrySamples * 4;
+                            asm volatile("" : "+v"(coff));
+                            w[h][q5] |= __builtin_amdgcn_raw_buffer_load_b32(crsrc, coff, 0, 0);
+                        }
+                    }
                 }
 #pragma unroll
-                for (int q5 = 0; q5 < (kRecWindow + 63) / 64; q5++) {
-                    const int k = lane + 64 * q5;
-                    if (k < kRecWindow) win[wave][k] = (uint16_t)mag_of_dword(w[q5]);
-                }
+                for (int h = 0; h < kRecGroup; h++)
+#pragma unroll
+                    for (int q5 = 0; q5 < kQ; q5 += 2) {  // two magnitudes per pass of the packed arithmetic
+                        const uint32_t m = mag2(w[h][q5], w[h][q5 + 1]);
+                        win[wave][h][lane + 64 * q5] = (uint16_t)m;
+                        if (q5 + 1 < kQ) win[wave][h][lane + 64 * (q5 + 1)] = (uint16_t)(m >> 16);
+                    }
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            unsigned long long half[2];
-            bool mybit[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int nbit = lane + 64 * h;
-                bool bit = false;
-                if (nbit < 112) {
-                    const int pos = (int)tp + 12 * nbit;  // relative to 5 * (j + 19)
-                    const int sidx = pos / 5;
-                    bit = slice_value(&win[wave][sidx], pos - 5 * sidx) > 0;
-                }
-                mybit[h] = bit;
-                // lane n holds message bit n; the message is MSB-first
-                half[h] = __brevll(__ballot(bit));
-            }
-            // the CRC residual, so that the host replay does not have to walk the bytes: XOR over
-            // the set bits n of x^(bits-1-n) mod g (adsb_tables.h: build_bit_residuals), bits =
-            // 112 when DF >= 16 (message bit 0 set), else 56
-            const bool lng = (half[0] >> 63) != 0;
+            unsigned long long half[kRecGroup][2];
+            uint32_t crc[kRecGroup];
+            unsigned long long pw[kRecGroup];
             const uint32_t *tb = p.tables + kTabBitsOff;
-            uint32_t crc = 0;
-            if (mybit[0] && (lng || lane < 56)) crc = tb[(lng ? 0 : 112) + lane];
-            if (mybit[1] && lng) crc ^= tb[64 + lane];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) crc ^= __shfl_xor(crc, off);
-            unsigned long long pw = 0;
-            if (lane < 33) {
-                const unsigned long long m = win[wave][lane];
-                pw = m * m;
+            for (int h = 0; h < kRecGroup; h++) {
+                const uint32_t tp = entry_tp(e[h]);
+                bool mybit[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) {
+                    const int nbit = lane + 64 * hh;
+                    bool bit = false;
+                    if (nbit < 112) {
+                        const uint32_t pos = tp + 12u * (uint32_t)nbit;  // relative to 5 * (j + 19); < 1341
+                        const uint32_t sidx = __umul24(pos, 13108u) >> 16;  // pos / 5
+                        bit = slice_value_any(&win[wave][h][sidx], (int)(pos - 5u * sidx)) > 0;
+                    }
+                    mybit[hh] = bit;
+                    // lane n holds message bit n; the message is MSB-first
+                    half[h][hh] = __brevll(__ballot(bit));
+                }
+                // the CRC residual, so that the host replay does not have to walk the bytes: XOR over
+                // the set bits n of x^(bits-1-n) mod g (adsb_tables.h: build_bit_residuals), bits =
+                // 112 when DF >= 16 (message bit 0 set), else 56
+                const bool lng = (half[h][0] >> 63) != 0;
+                uint32_t c = 0;
+                if (mybit[0] && (lng || lane < 56)) c = tb[(lng ? 0 : 112) + lane];
+                if (mybit[1] && lng) c ^= tb[64 + lane];
+                crc[h] = c;
+                unsigned long long m = 0;
+                if (lane < 33) m = win[wave][h][lane];
+                pw[h] = m * m;
             }
+            // (butterflies: every lane ends up with every hit's totals, lane h keeps those of hit h)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) pw += __shfl_down(pw, off);
-            if (lane == 0) {
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h++) {
+                    crc[h] ^= __shfl_xor(crc[h], off);
+                    pw[h] += __shfl_xor(pw[h], off);
+                }
+            if ((uint32_t)lane < ng) {
+                uint64_t me = e[0];
+                unsigned long long h0 = half[0][0], h1 = half[0][1], mpw = pw[0];
+                uint32_t mcrc = crc[0];
+#pragma unroll
+                for (int h = 1; h < kRecGroup; h++)
+                    if (lane == h) {
+                        me = e[h];
+                        h0 = half[h][0];
+                        h1 = half[h][1];
+                        mpw = pw[h];
+                        mcrc = crc[h];
+                    }
+                const uint32_t q = g0 + (uint32_t)lane;
+                const uint32_t j = entry_j(me), tp = entry_tp(me);
+                const bool lng = (h0 >> 63) != 0;
                 TrialRecord r;
-                r.power = pw | ((unsigned long long)crc << 40);  // pw < 2^38
-                r.chunk = (uint32_t)chunk;
+                r.power = mpw | ((unsigned long long)mcrc << 40);  // pw < 2^38
+                r.chunk = (uint32_t)entry_chunk(me);
                 r.j_tp = j | (tp << 24);
 #pragma unroll
-                for (int k = 0; k < 8; k++) r.msg[k] = (uint8_t)(half[0] >> (56 - 8 * k));
+                for (int k = 0; k < 8; k++) r.msg[k] = (uint8_t)(h0 >> (56 - 8 * k));
 #pragma unroll
-                for (int k = 0; k < 6; k++) r.msg[8 + k] = (uint8_t)(half[1] >> (56 - 8 * k));
+                for (int k = 0; k < 6; k++) r.msg[8 + k] = (uint8_t)(h1 >> (56 - 8 * k));
                 // `power` carries the residual (bit 0); bits 4..15: icao_hash of what this DF will ask
                 // the filter about (bit 1) -- the residual for the address/parity DFs, else the address
-                const uint32_t df = (uint32_t)(half[0] >> 59);
+                const uint32_t df = (uint32_t)(h0 >> 59);
                 const bool ap = ((0xFF310031u >> df) & 1u) != 0;
-                const uint32_t addr = (uint32_t)(half[0] >> 32) & 0xFFFFFFu;
-                r.pad = (uint16_t)(3u | (icao_hash_dev(ap ? crc : addr) << 4));
+                const uint32_t addr = (uint32_t)(h0 >> 32) & 0xFFFFFFu;
+                r.pad = (uint16_t)(3u | (icao_hash_dev(ap ? mcrc : addr) << 4));
                 if (do_score) {
                     // for k_score: what this trial asks the filter about, and what it may add
                     // (src/mode_s/mod.rs:56-135); clean DF11 (IID 0) / DF17 register as adders
-                    const bool zero = (half[0] | half[1]) == 0;
+                    const bool zero = (h0 | h1) == 0;
                     const bool d11 = df == 11u, d17 = df == 17u, d18 = df == 18u;
-                    const bool clean11 = d11 && (crc & 0xFFFF80u) == 0, iid0 = (crc & 0x7Fu) == 0;
-                    const bool clean17 = (d17 || d18) && crc == 0;
+                    const bool clean11 = d11 && (mcrc & 0xFFFF80u) == 0, iid0 = (mcrc & 0x7Fu) == 0;
+                    const bool clean17 = (d17 || d18) && mcrc == 0;
                     uint32_t kind = kSkOther;
                     if (zero) kind = kSkNone;
                     else if (ap) kind = lng ? kSkApLong : kSkApShort;
                     else if (clean11) kind = iid0 ? kSkDf11Iid0 : kSkDf11;
                     else if (clean17) kind = d17 ? kSkDf17 : kSkDf18;
-                    const uint32_t v = ap ? crc : addr;
+                    const uint32_t v = ap ? mcrc : addr;
                     p.score.si[b0 + q] = v | (kind << 24);
-                    p.score.rec[b0 + q] = r;
                     p.score.pos[b0 + q] = score_pos(r);
                     p.score.slot[b0 + q] = (kind == kSkDf11Iid0 || kind == kSkDf17) ? score_hash_insert(p.score, v, b0 + q)
                                                                                    : 0xFFFFFFFFu;
                 }
                 stage[q] = r;
             }
-            __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next hit
+            __builtin_amdgcn_wave_barrier();  // win is rewritten for the wave's next group
         }
         __syncthreads();
         if (threadIdx.x < 2 * cnt) {
-            host_store128((char *)(rec + b0) + 16 * threadIdx.x, ((const u32x4_t *)stage)[threadIdx.x]);
+            // a pass that k_score takes over keeps its records in HBM: the host only wants them when
+            // it cannot use the device's result, and fetches them then (adsb_host.cpp: finish_pass)
+            if (do_score)
+                ((u32x4_t *)(p.score.rec + b0))[threadIdx.x] = ((const u32x4_t *)stage)[threadIdx.x];
+            else
+                host_store128((char *)(rec + b0) + 16 * threadIdx.x, ((const u32x4_t *)stage)[threadIdx.x]);
             // (its own read of the two words: the 128-bit value above is only ever an asm operand)
             const unsigned long long *sw = (const unsigned long long *)stage + 2 * threadIdx.x;
             my_sum += sw[0] + sw[1];
@@ -635,16 +736,29 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     if (threadIdx.x == 0) is_last = atomicAdd(&p.ctr->blocks_done, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
-    if (threadIdx.x < 64) {
+    {
+        // (every thread's loads are issued together: as a loop of one wave this total was most of the
+        // kernel's duration beside a scan -- a hundred dependent round trips to a contended L2)
+        static_assert(kApWaveSegs % 256 == 0 && kApSegments % 256 == 0, "unrolled below");
         uint32_t ap = 0, cand = 0;
-        for (int i = lane; i < kApWaveSegs; i += 64) ap += p.ctr->seg_ap[i];
-        for (int i = lane; i < kApSegments; i += 64) cand += p.ctr->seg_cand[i];
+#pragma unroll
+        for (int i = 0; i < kApWaveSegs / 256; i++) ap += p.ctr->seg_ap[i * 256 + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < kApSegments / 256; i++) cand += p.ctr->seg_cand[i * 256 + threadIdx.x];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             ap += __shfl_down(ap, off);
             cand += __shfl_down(cand, off);
         }
+        __shared__ uint32_t tot[2][4];
         if (lane == 0) {
+            tot[0][wave] = ap;
+            tot[1][wave] = cand;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ap = tot[0][0] + tot[0][1] + tot[0][2] + tot[0][3];
+            cand = tot[1][0] + tot[1][1] + tot[1][2] + tot[1][3];
             uint32_t *sm = (uint32_t *)p.summary;
             if (p.score.si) {
                 const uint32_t nh = p.ctr->n_hits;
@@ -751,13 +865,14 @@ int launch_match(const ScanParams &p, void *stream)
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream)
 {
     hip_clear();
-    // contiguous runs of hits per block (the count lives on the device): enough blocks that a
-    // dense pass (tens of hits per chunk) still has only a few hits per wave
-    // (the count lives on the device: sized for a dense pass -- ~35 hits per buffer -- to leave a wave
-    // one or two hits; on sparse input most blocks find nothing and leave at once)
-    // (more, smaller blocks were measured on dense input -- 17 000 hits -- and are slower: 104 us
-    // against 55: shorter bursts of host stores)
-    uint32_t blocks = (uint32_t)ADSB_REC_BLOCKS_PER_CHUNK * p.n_chunks + 8;
+    // Contiguous runs of hits per block (the count lives on the device); on sparse input most
+    // blocks find nothing and leave at once.  Measured on dense input (17 000 hits per pass, beside
+    // a scan): the kernel's duration does not depend on the block count between one per CU and
+    // one per buffer (the scan's four workgroups leave a SIMD 96 registers per lane, one wave of
+    // this kernel, whatever the grid), and four or eight blocks per buffer are two and four
+    // times slower (more rounds of the fixed per-block latencies).  What it does depend on is the
+    // instruction count per hit: see the hit loop.
+    uint32_t blocks = p.n_chunks + 8u;
     if (blocks > 4096) blocks = 4096;
     if (from_mag)
         hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);

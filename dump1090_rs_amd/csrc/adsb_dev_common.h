@@ -206,6 +206,17 @@ __device__ __forceinline__ int slice_value(Ptr m, int phase)
     }
 }
 
+// The same for a phase that differs from lane to lane, without the five-way branch: the
+// coefficients of phases 0..3 are linear in the phase, (5 - ph, 2 ph - 3, -(2 + ph)), and
+// phase 4 is that line's (1, 5, -6) plus (0, 0, 1, -1).  Reads m[3] whatever the phase.
+template <typename Ptr>
+__device__ __forceinline__ int slice_value_any(Ptr m, int phase)
+{
+    const int m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+    const int v = (5 - phase) * m0 + (2 * phase - 3) * m1 - (2 + phase) * m2;
+    return phase == 4 ? v + m2 - m3 : v;
+}
+
 template <typename Ptr>
 __device__ __forceinline__ void slice_message(Ptr at_j, int tp, uint32_t w[4])
 {

@@ -559,7 +559,10 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     }
     if (sl.h_sum->overflow) return 1;
     const size_t n = sl.h_sum->n_hits;
-    if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    // (k_records' own test: a pass that k_score took over has left its records in device memory)
+    const bool rec_on_device = sl.device_scored && n <= c->score.cap;
+    if (!rec_on_device)
+        if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
     if (sl.profiled) {
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
@@ -592,6 +595,10 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         else if (n < 1024) c->dense_mode = false;
     }
     if (take_device_result(c, sl, chunk_offset, out)) return 0;
+    if (rec_on_device && n) {
+        HIP_TRY(c, hipMemcpy(sl.h_rec, sl.score.rec, n * sizeof(TrialRecord), hipMemcpyDeviceToHost));
+        if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    }
     c->host_replays++;
     c->score_epoch++;        // passes in flight were scored on the device without what this replay adds
     c->exact_valid = false;

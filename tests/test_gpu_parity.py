@@ -161,6 +161,30 @@ def test_demodulate2400_honours_caller_magnitudes(ctx, oracle_mod, fixture_iq, g
         assert_same(got, want)
 
 
+def test_demodulate2400_frames_over_the_tile_load_seams(ctx, oracle_mod):
+    """Caller-supplied magnitudes are loaded four u16 per lane and 1024 per pass of a workgroup; the
+    first lane's first load of a buffer starts two entries before data[0] (out of range, zero).  A
+    compiler that folds the "+ 2048 bytes" of the next pass into the instruction's immediate offset
+    makes that load out of range too (the hardware adds register and immediate offsets without
+    wrapping), which would zero data[1022..1025]: frames laid over every such seam must decode."""
+    from dump1090_rs_amd import MagnitudeBuffer
+    orc = oracle_mod.Oracle()
+    for seam in (1022, 2046, 3070, 7710, 7712 + 1022):
+        for back in (40, 120, 200, 260):
+            start = seam - 326 - back          # sample at which the preamble starts: the frame spans the seam
+            iq = synth.noise_numpy(131072, seed=seam * 7 + back)
+            synth.add_bursts(iq, [synth.Burst(5 * start + back % 5, 9000 + 50 * back, back % 16,
+                                               synth.df17_frame(0xABC000 + back, 0x1234567890ABC + seam))])
+            data, n = orc.to_mag(iq)
+            orc.icao_flush()
+            want, st = orc.demodulate2400(data, n)
+            assert any(abs(w["j"] - (start + 326)) <= 2 for w in want), (seam, back)   # the frame is there
+            ctx.icao_flush()
+            got = ctx.demodulate2400(MagnitudeBuffer(data.copy(), n))
+            assert_same(got, want)
+            assert ctx.stats()["n_candidates"] == st.quiet_pass
+
+
 def test_saturated_and_constant_inputs(ctx, oracle_mod):
     for val in (0, 1, -32768, 32767):
         iq = np.full((131072, 2), val, dtype=np.int16)
