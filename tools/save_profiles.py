@@ -22,6 +22,13 @@ stats(R / f'gpurun_out/psync_{tag}/bench_kernel_stats.csv', R / f'profiles/{name
 for src, dst in ((f'gpurun_out/bench_{tag}.json', f'profiles/{name}_bench.json'), (f'gpurun_out/bench_sync_{tag}.json', f'profiles/{name}_sync_bench.json')):
     line = [l for l in open(R / src).read().splitlines() if l.startswith('{')][-1]
     (R / dst).write_text(line + '\n')
+for w in ('dense', 'stream', 'shard', 'gloo2', 'gloo2_shard'):  # tools/profile_all.sh
+    src = R / f'gpurun_out/bench_{w}_{tag}.json'
+    if src.exists():
+        line = [l for l in src.read_text().splitlines() if l.startswith('{')][-1]
+        (R / f'profiles/{name}_{w}_bench.json').write_text(line + '\n')
+if (R / f'gpurun_out/pdense_{tag}/bench_kernel_stats.csv').exists():
+    stats(R / f'gpurun_out/pdense_{tag}/bench_kernel_stats.csv', R / f'profiles/{name}_dense_sync_kernel_stats.csv')
 tr = json.loads([l for l in open(R / f'gpurun_out/traffic_{tag}.json').read().splitlines() if l.startswith('{')][-1])
 lib = json.loads((R / f'profiles/{name}_bench.json').read_text())['config']['library']
 fetch, write = tr['scan_FETCH_SIZE_avg'] * 1024 * 2, tr['scan_WRITE_SIZE_avg'] * 1024
