@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -141,6 +142,7 @@ struct adsb_ctx {
     } ring[kSlots];
     size_t ring_samples = 0;
     hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream_spare = nullptr;  // a pooled copy stream this context has not needed (yet)
 
     bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
     uint32_t *d_carry_next = nullptr;  // the end of the latest submission's input: the next one's lead-in
@@ -823,6 +825,31 @@ int ensure_stage(adsb_ctx *c, size_t bytes)
 
 extern "C" {
 
+// The internal streams of destroyed contexts, kept for the next context on the same device.  The
+// runtime gives every new stream of a priority a new hardware queue until it has four of that priority
+// and never gives one back, so a process that creates, destroys and re-creates contexts ends up with its
+// streams spread over a different set of queues each time -- measured: a dense stream in the second
+// context alternates 88 / 270 us per pass (0.175 ms mean) where the first one holds 0.13.  Re-using the
+// same streams keeps every context of a process on the queues the first one got.
+struct StreamSet {
+    int device = -1;
+    hipStream_t own = nullptr, scan[2] = {nullptr, nullptr}, tail = nullptr, score = nullptr, copy = nullptr;
+};
+std::mutex g_stream_pool_mu;
+std::vector<StreamSet> g_stream_pool;
+
+bool take_stream_set(int device, StreamSet &out)
+{
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+        if (g_stream_pool[i].device == device) {
+            out = g_stream_pool[i];
+            g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
 {
     if (!out) return ADSB_ERR_INVALID;
@@ -856,10 +883,21 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     int rc = ADSB_OK;
     auto body = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        StreamSet pooled;
+        const bool reuse = !tuning_env("ADSB_STREAM_PRIO") && !tuning_env("ADSB_SCORE_PRIO") && take_stream_set(device, pooled);
+        if (reuse) {
+            c->own_stream = pooled.own;
+            c->scan_stream[0] = pooled.scan[0];
+            c->scan_stream[1] = pooled.scan[1];
+            c->tail_stream = pooled.tail;
+            c->score_stream = pooled.score;
+            c->copy_stream_spare = pooled.copy;
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        }
         c->stream = c->own_stream;
         HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
-        {
+        if (!reuse) {
             // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
             // default) and two streams on one queue run strictly one after the other; queues
             // are pooled per priority, so giving the two scan streams different priorities
@@ -912,7 +950,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             }
             cd.exact = c->exact_bm[0];
             cd.si = reinterpret_cast<uint32_t *>(cd.exact);  // (non-null: "scoring is available")
-            {
+            if (!c->score_stream) {
                 int least = 0, greatest = 0;
                 HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
                 int ps = least;  // with the tail stream's priority: its own hardware queue in that pool
@@ -1032,16 +1070,10 @@ void adsb_destroy(adsb_ctx *c)
     for (auto &b : c->d_bitmap)
         if (b) (void)hipFree(b);
     for (hipStream_t q : c->scan_stream)
-        if (q) {
-            (void)hipStreamSynchronize(q);
-            (void)hipStreamDestroy(q);
-        }
+        if (q) (void)hipStreamSynchronize(q);
     for (hipEvent_t e : c->input_ready)
         if (e) (void)hipEventDestroy(e);
-    if (c->tail_stream) {
-        (void)hipStreamSynchronize(c->tail_stream);
-        (void)hipStreamDestroy(c->tail_stream);
-    }
+    if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
     for (Slot &sl : c->slot) {
         for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot, (void *)sl.score.pos,
                         (void *)sl.score.hash, (void *)sl.score.blk, (void *)sl.score.state})
@@ -1050,10 +1082,7 @@ void adsb_destroy(adsb_ctx *c)
     }
     for (uint32_t *bm : c->exact_bm)
         if (bm) (void)hipFree(bm);
-    if (c->score_stream) {
-        (void)hipStreamSynchronize(c->score_stream);
-        (void)hipStreamDestroy(c->score_stream);
-    }
+    if (c->score_stream) (void)hipStreamSynchronize(c->score_stream);
     if (c->fb.d_hits) (void)hipFree(c->fb.d_hits);
     if (c->fb.d_dap) (void)hipFree(c->fb.d_dap);
     if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
@@ -1065,7 +1094,7 @@ void adsb_destroy(adsb_ctx *c)
     }
     if (c->d_addrs) (void)hipFree(c->d_addrs);
     if (c->d_carry_next) (void)hipFree(c->d_carry_next);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->d_timeline && c->debug_stop == 100) {
         // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves
         std::vector<unsigned long long> tl(kTimelineWords);
@@ -1102,7 +1131,25 @@ void adsb_destroy(adsb_ctx *c)
                 }
         (void)hipFree(c->d_timeline);
     }
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    {
+        // the streams go back to the pool (a context whose creation failed half-way has no full set:
+        // its streams are simply destroyed)
+        StreamSet set;
+        set.device = c->device;
+        set.own = c->own_stream;
+        set.scan[0] = c->scan_stream[0];
+        set.scan[1] = c->scan_stream[1];
+        set.tail = c->tail_stream;
+        set.score = c->score_stream;
+        set.copy = c->copy_stream ? c->copy_stream : c->copy_stream_spare;
+        if (set.own && set.scan[0] && set.scan[1] && set.tail && set.score) {
+            std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+            g_stream_pool.push_back(set);
+        } else {
+            for (hipStream_t q : {set.own, set.scan[0], set.scan[1], set.tail, set.score, set.copy})
+                if (q) (void)hipStreamDestroy(q);
+        }
+    }
     delete c;
 }
 
@@ -1232,7 +1279,12 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
     if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
     if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (c->copy_stream_spare) {
+        c->copy_stream = c->copy_stream_spare;
+        c->copy_stream_spare = nullptr;
+    } else {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    }
     for (auto &r : c->ring) {
         HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocDefault));
         HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
