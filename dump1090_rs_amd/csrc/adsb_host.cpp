@@ -72,6 +72,7 @@ struct Slot {
 
 constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 4: the device never waits for the host between passes (3 do for sparse streams; a dense one has a longer tail)
 constexpr int kBitmaps = kSlots + 1;
+constexpr int kScanEvRing = kSlots + 3;  // scan start / stop event pairs in rotation (finish_pass: ms_scan_exclusive)
 
 constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup
 
@@ -120,7 +121,7 @@ struct adsb_ctx {
     Slot slot[kSlots];
     // start / stop events of the scans, in a ring one longer than the passes in flight: when pass N
     // is collected the stop event of pass N-1 is still its own (ms_scan_exclusive)
-    hipEvent_t scan_ev[kSlots + 1][2] = {};
+    hipEvent_t scan_ev[kScanEvRing][2] = {};
     hipEvent_t last_stop = nullptr;  // stop event of the pass collected last, and its number
     uint64_t last_scan_seq = 0;
     uint64_t scan_counter = 0;
@@ -379,8 +380,8 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.seq = c->next_seq++;
     if (c->next_seq == 0) c->next_seq = 1;
     sl.scan_seq = ++c->scan_counter;
-    sl.ev[0] = c->scan_ev[sl.scan_seq % (kSlots + 1)][0];
-    sl.ev[1] = c->scan_ev[sl.scan_seq % (kSlots + 1)][1];
+    sl.ev[0] = c->scan_ev[sl.scan_seq % kScanEvRing][0];
+    sl.ev[1] = c->scan_ev[sl.scan_seq % kScanEvRing][1];
     sl.h_sum->seq = 0;  // the records kernel overwrites it, last, with sl.seq
     p.seq = sl.seq;
     if (sl.device_scored) {
@@ -569,17 +570,29 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
         st.ms_scan += ms;
-        // the part of it after the previous pass's scan had ended (that pass's events are intact:
-        // its slot is not reused before this pass is collected)
+        // The device time this launch adds: the part of it after the latest scan end seen so far (the
+        // "frontier": normally the previous pass's; scans on the two scan streams can also finish out of
+        // order, and one that ended before the frontier adds nothing -- the union of the launches'
+        // intervals is what is being summed).  The frontier's events are intact for kScanEvRing - kSlots
+        // passes back: the ring is that much longer than what can be in flight.
         float excl = ms;
-        if (c->last_stop && c->last_scan_seq + 1 == sl.scan_seq) {
-            // time since the previous scan ended, when that is shorter than this scan's own duration
-            float tail = 0;
-            if (hipEventElapsedTime(&tail, c->last_stop, sl.ev[1]) == hipSuccess && tail >= 0 && tail < excl) excl = tail;
+        bool advance = true;
+        if (c->last_stop && sl.scan_seq - c->last_scan_seq <= (uint64_t)(kScanEvRing - kSlots)) {
+            float since = 0;
+            if (hipEventElapsedTime(&since, c->last_stop, sl.ev[1]) == hipSuccess) {
+                if (since <= 0) {
+                    excl = 0;
+                    advance = false;
+                } else if (since < excl) {
+                    excl = since;
+                }
+            }
         }
         st.ms_scan_exclusive += excl;
-        c->last_stop = sl.ev[1];
-        c->last_scan_seq = sl.scan_seq;
+        if (advance) {
+            c->last_stop = sl.ev[1];
+            c->last_scan_seq = sl.scan_seq;
+        }
         if (sl.profiled > 1) {  // per-kernel split of the tail (events cost a few us each)
             HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
             st.ms_match += ms;
@@ -899,13 +912,19 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
         if (!reuse) {
             // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
-            // default) and two streams on one queue run strictly one after the other; queues
-            // are pooled per priority, so giving the two scan streams different priorities
-            // guarantees that they can overlap whatever else the process has created.
-            // (Which of the three levels each stream gets made no measurable difference.)
+            // default, per priority) and two streams on one queue run strictly one after the other.
+            // Both scan streams take the highest priority: that pool holds nothing else of this
+            // process (the null stream, torch's and the caller's streams are of normal priority), so
+            // the two get a queue each and consecutive scans can overlap.  They must have the SAME
+            // priority: with different ones, whenever two scans are pending at once (after any hiccup
+            // of the host) the higher one's starts first, its successor on that stream is then free
+            // earlier too, and the stream settles into finishing passes in the order 2, 1, 4, 3, ...
+            // for thousands of passes, 8-10 % slower (passes are collected in order), until another
+            // hiccup flips it back; measured over 22 000 passes: (mid, high) spends a third of the
+            // time in that mode, (high, high) and (mid, mid) none.
             int least = 0, greatest = 0;
             HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            int pt = least, p0 = (least + greatest) / 2, p1 = greatest;
+            int pt = least, p0 = greatest, p1 = greatest;
             if (const char *e = tuning_env("ADSB_STREAM_PRIO")) {  // measurement aid: "tail,scan0,scan1" as 0 (least) .. 2
                 int a = 0, b = 1, d = 2;
                 if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
