@@ -479,6 +479,43 @@ def test_device_side_scoring_follows_the_filter_across_pipelined_passes(hip_lib,
             assert_same(g, orc.demod_iq(host[k])[0])
         assert 3 <= c._L.adsb_host_replays(c._h) <= 5         # the first one to three of these five, not all
 
+def test_device_side_scoring_hands_over_before_the_filter_table_fills(hip_lib, oracle_mod):
+    """icao_filter_add gives up silently once its 4096-slot table is full (src/icao_filter.rs:46-62) --
+    the one behaviour the parallel scoring cannot reproduce, so the device's result is only taken while
+    the host's table is at least 64 entries from full; past that the host scores the passes itself, from
+    the records the device kept.  A dense stream with more distinct addresses than the table holds and
+    no flush: identical to the oracle through the hand-over and on with a full table (where most
+    frames stay at 1400: their address is never stored)."""
+    import torch
+    from dump1090_rs_amd import Context
+    n = 20 * 131072
+    host = [synth.make_iq(n, n_bursts=1400, seed=900 + k, n_icao=20000) for k in range(6)]
+    bufs = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want = [orc.demod_iq(h)[0] for h in host]
+    seen = set()
+    for ws in want:
+        seen |= {int.from_bytes(w["msg"][1:4], "big") for w in ws if w["score"] >= 1400}
+    assert len(seen) > 6000                                                     # more addresses than slots
+    assert sum(w["score"] == 1400 for w in want[5]) > sum(w["score"] == 1800 for w in want[5])   # the table is full
+    with Context(0, 32) as c:
+        c.icao_flush()
+        got = [c.demod_iq_device(bufs[0].data_ptr(), n)]      # (tells the context how dense this stream is)
+        assert c._L.adsb_host_replays(c._h) == 1
+        for k in range(1, 6):
+            c.submit_iq_device(bufs[k].data_ptr(), n)
+            if k >= 2:
+                got.append(c.collect())
+        got.append(c.collect())
+        for g, w in zip(got, want):
+            assert_same(g, w)
+        # the first pass and every pass from the hand-over on are the host's; at least one in between
+        # was the device's
+        assert 3 <= c._L.adsb_host_replays(c._h) <= 5, c._L.adsb_host_replays(c._h)
+
+
 # ----------------------------------------------------------------------------- stages
 def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod, golden, fixture_iq):
     """Not only frames: the device's magnitudes, the list of positions its gates let through and its
