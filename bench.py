@@ -198,7 +198,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     out = (AdsbMsg * cap)()
     depth = max(1, min(4, args.depth))
 
-    def run_steps(first: int, count: int, level: int):
+    def run_steps(first: int, count: int, level: int, blocking: bool = args.sync):
         """`count` steps starting at step index `first`.  A step is ONE icao_flush
         (benches/demod_benchmark.rs:9 flushes per call) + the whole pass over one 256 MiB buffer.
         Pipelined form: step i is submitted before step i - (depth-1) is collected, so the host part
@@ -217,7 +217,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
         for i in range(count):
             b = bufs[(first + i) % len(bufs)]
             ctx.icao_flush()
-            if args.sync:
+            if blocking:
                 frames += ctx.demod_iq_device_raw(b.data_ptr(), n, out, cap)
                 account()
             else:
@@ -225,7 +225,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
                 if i >= depth - 1:
                     frames += ctx.collect_raw(out, cap)
                     account()
-        if not args.sync:
+        if not blocking:
             for _ in range(min(count, depth - 1)):
                 frames += ctx.collect_raw(out, cap)
                 account()
@@ -250,11 +250,18 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
         _, tot2, _ = run_steps(warmup, steps, 2)
         if args.timed_profiling == 0:
             tot = tot2
+    # untimed: the same steps with blocking calls, where launches do not overlap and a launch's own
+    # start-to-stop time is the kernel alone (what `bench.py --sync` and profiles/*_sync_* report)
+    alone_ms = None
+    if level2 and not args.sync:
+        _, tot3, _ = run_steps(warmup, steps, 1, blocking=True)
+        alone_ms = tot3["ms_scan"] / steps
     ctx.set_profiling(1)
     # step-to-step intervals between consecutive collects (steady state of the pipeline)
     iv = [b - a for a, b in zip(stamps, stamps[1:])]
     return {"ctx": ctx, "bufs": bufs, "n": n, "n_bursts": n_bursts, "cap": cap, "frames": frames, "elapsed": elapsed,
-            "tot": tot, "tot2": tot2, "stats": stats, "intervals": iv, "depth": depth, "ramp": ramp}
+            "tot": tot, "tot2": tot2, "stats": stats, "intervals": iv, "depth": depth, "ramp": ramp,
+            "alone_ms": alone_ms}
 
 
 def clock_ramp(env: Env, args, run) -> dict:
@@ -381,6 +388,10 @@ def resident_result(env: Env, args, r, workload: str):
                                 "device time per launch: union of the overlapping launches' intervals / launches "
                                 "(HIP events stamped by the launches; adsb_stats.ms_scan_exclusive)",
             "kernel_own_duration_avg_ms": round(own_ms, 4),
+            "kernel_alone_avg_ms": round(r["alone_ms"], 4) if r.get("alone_ms") else None,
+            "frac_alone": round(BYTES_PER_SAMPLE * n / (r["alone_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if r.get("alone_ms") else None,
+            "kernel_alone_is": "the same steps once more, untimed, with blocking calls: launches do not overlap, so a "
+                               "launch's start-to-stop time is the kernel alone (profiles/*_sync_kernel_stats.csv)",
             "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
             "other_kernels_avg_ms": {"k_match_and_order": round(tot2["ms_match"] / steps, 4),
                                      "k_records": round(tot2["ms_records"] / steps, 4)},
