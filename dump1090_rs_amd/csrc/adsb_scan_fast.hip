@@ -362,15 +362,14 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
     const int shift = lead ? kCarrySamples : 0;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)(iq - shift), 0, (r.len + shift) * 4, 0x00020000);
-    // (the offsets below are [a register part >= 0] + 4096 i - 1312: the compiler puts the constant's
-    // low 12 bits into the instruction's immediate offset only for i >= 1, where what stays in the
-    // register is still >= 0, so the range check sees what it should -- see the note in the branch
-    // above; a step below 4096 would be folded whole and break the check for the lanes before sample 0)
-    static_assert(kThreads * 16 > 4095, "the per-pass step must not fit the 12-bit immediate offset");
+    // (offsets opaque to the compiler, as in the branch above: a constant folded into the
+    // instruction's immediate offset would break the range check for the lanes before sample 0)
     const int k0 = r.jbase - kPad - kLead + shift;  // IQ sample index of slot 0 (multiple of 4)
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; i++) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k0 + 4 * (tid + i * kThreads)) * 4, 0, 0);
+        int off = (k0 + 4 * (tid + i * kThreads)) * 4;
+        asm volatile("" : "+v"(off));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         pre[i] = make_uint4(v.x, v.y, v.z, v.w);
     }
     if (p.carry != nullptr && !lead && r.tile == 0) {
