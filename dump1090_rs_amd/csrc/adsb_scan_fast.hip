@@ -55,6 +55,9 @@ namespace {
 
 using namespace fastgeo;
 
+#ifndef ADSB_PRIO_LATE
+#define ADSB_PRIO_LATE 1   // wave priority during P3..P5 (0 = leave it alone)
+#endif
 #ifndef ADSB_SCAN_THREADS
 #define ADSB_SCAN_THREADS 256
 #endif
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
 #endif
 
+    const bool late_prio = ADSB_PRIO_LATE != 0 && p.order_cnt == nullptr;
     uint32_t iter = 0;
     for (uint32_t t = t_first; t < t_end; t += t_stride, iter++) {
     const TileRef cur = tile_ref<FROM_MAG>(p, t);
@@ -646,6 +650,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     ACCT(3);
     STAMP(2);
     if (ADSB_STOP_AT(p, 2)) continue;
+    // The wave-private stages are chains of LDS round trips with few instructions between them:
+    // at a raised issue priority they get through their dependent steps without queueing behind the
+    // other workgroups' P1 / P2 on the same SIMD, which have instructions to spare for every slot
+    // those chains leave (measured: pipelined -2 %, a launch on its own 105 -> 100 us; levels 1, 2
+    // and 3 alike).  Not on dense streams: there the tail kernels beside the scan are the ones that
+    // must not wait (adsb_aux.hip: TAIL_PRIO), and the step got 3 % longer.
+    if (late_prio) __builtin_amdgcn_s_setprio(ADSB_PRIO_LATE);
 
     // ================================================================ P3..P5, wave-private
     // From here to the end of the tile every wave works alone on the positions of its own
@@ -783,6 +794,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     }
     }
 tile_end:
+    if (late_prio) __builtin_amdgcn_s_setprio(0);
     ACCT(4);
     lds_barrier();
     ACCT(5);
