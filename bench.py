@@ -254,6 +254,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     # start-to-stop time is the kernel alone (what `bench.py --sync` and profiles/*_sync_* report)
     alone_ms = None
     if level2 and not args.sync:
+        run_steps(warmup, 30, 1, blocking=True)   # (the switch from pipelined to blocking calls settles first)
         _, tot3, _ = run_steps(warmup, steps, 1, blocking=True)
         alone_ms = tot3["ms_scan"] / steps
     ctx.set_profiling(1)
