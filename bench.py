@@ -24,6 +24,7 @@ parity flag.  Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -239,11 +240,14 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     run_steps(0, warmup, 1)
     # Timed region: K steps with HIP events around the scan kernel only (level 1), stamped by the
     # scan launch itself on the stream it runs on.
+    gc.collect()
+    gc.disable()   # (no collector pause inside a 2 ms timed region)
     env.fence()
     t0 = time.perf_counter()
     frames, tot, stamps = run_steps(warmup, steps, args.timed_profiling)
     env.fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     stats = ctx.stats()
     tot2 = None
     if level2:  # untimed: the same steps once more with an event after every kernel, for the split
