@@ -49,6 +49,16 @@ def test_product_package_never_imports_the_oracle():
     assert "oracle" not in (ROOT / "dump1090_rs_amd" / "synth.py").read_text().lower()
 
 
+def test_release_library_reads_no_environment_switches(hip_lib):
+    """The measurement knobs (ADSB_DEBUG_STOP, ADSB_STREAM_PRIO, ...) exist only in a library built
+    with -DADSB_TUNING: a stray variable cannot change what the release build computes."""
+    from dump1090_rs_amd.build import LIB
+    blob = LIB.read_bytes()
+    if b"ADSB_HOST_TIMES" in blob:
+        pytest.skip("a tuning build (-DADSB_TUNING) is installed")
+    assert b"ADSB_" not in blob and b"getenv" not in blob
+
+
 def test_version_string(hip_lib):
     assert hip_lib.adsb_version().startswith(b"adsb_hip")
 
