@@ -340,7 +340,7 @@ def resident_result(env: Env, args, r, workload: str):
     tot, tot2 = r["tot"], r["tot2"] or r["tot"]
     own_ms = tot["ms_scan"] / steps
     # Consecutive pipelined scans overlap (the next one's workgroups fill the CUs as the previous grid
-    # drains, and with three passes in flight the next launch is dispatched while its predecessor still
+    # drains, and with several passes in flight the next launch is dispatched while its predecessor still
     # runs): a launch's own start-to-stop time then counts the shared stretch twice.  The device time
     # per launch is the union of the launches' intervals / launches = ms_scan_exclusive.
     excl_ms = tot["ms_scan_exclusive"] / steps
