@@ -110,9 +110,13 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
             if (e[k] == ~0ull || !((coarse[(c[k] & 4095u) >> 5] >> (c[k] & 31)) & 1u)) continue;
             if ((p.bitmap[c[k] >> 5] >> (c[k] & 31)) & 1u) {  // rare: one atomic each
                 const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
-                if (idx < p.hits_cap) {
+                if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
+                    const uint32_t ch = (uint32_t)entry_chunk(e[k]);
+                    const uint32_t at = atomicAdd(&p.order_cnt[ch], 1u);
+                    if (at < kOrderBucket) p.order_tmp[(size_t)ch * kOrderBucket + at] = e[k];
+                    else atomicOr(&p.ctr->overflow, 1u);
+                } else if (idx < p.hits_cap) {
                     p.hits[idx] = e[k];
-                    if (p.order_cnt) atomicAdd(&p.order_cnt[entry_chunk(e[k])], 1u);
                 } else {
                     atomicOr(&p.ctr->overflow, 1u);
                 }
@@ -127,11 +131,10 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
 // src/demod_2400.rs:121,158).  Sorting it here is a counting sort by buffer followed by a rank
 // sort inside each buffer's handful of hits: a busy airspace leaves tens of hits per buffer, and
 // keys are unique (a trial is either self-validating or address/parity, never both).
-//   producers       whoever stores a hit also counts it for its buffer (order_cnt)
+//   producers       whoever finds a hit puts it into its buffer's bucket (order_tmp, order_cnt)
 //   k_order_prefix  one workgroup: exclusive prefix of the counts (order_base)
-//   k_order_scatter one thread per hit: into its buffer's bucket in order_tmp; the counts run
-//                   back down to zero, which is how the next pass must find them
-//   k_order_rank    one thread per hit: rank among its buffer's hits -> final place in p.hits
+//   k_order_buckets one workgroup per buffer: the bucket sorted into its place in p.hits; the
+//                   count goes back to zero, which is how the next pass must find it
 // A pass whose lists overflowed is redone by the host anyway: its counts are only zeroed.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t order_key(uint64_t e)
@@ -169,31 +172,26 @@ __global__ __launch_bounds__(1024) void k_order_prefix(ScanParams p)
     }
 }
 
-__global__ __launch_bounds__(256) void k_order_scatter(ScanParams p)
+// one block per buffer: its bucket sorted (a rank sort in LDS: a busy airspace leaves tens of hits per
+// buffer) into its place in the hit list; the count goes back to zero for the slot's next pass
+__global__ __launch_bounds__(256) void k_order_buckets(ScanParams p)
 {
     TAIL_PRIO();
-    if (p.ctr->overflow) return;
-    const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t e = p.hits[i];
-        const uint32_t c = (uint32_t)entry_chunk(e);
-        p.order_tmp[p.order_base[c] + atomicSub(&p.order_cnt[c], 1u) - 1u] = e;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_order_rank(ScanParams p)
-{
-    TAIL_PRIO();
-    if (p.ctr->overflow) return;
-    const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t e = p.order_tmp[i];
-        const uint32_t c = (uint32_t)entry_chunk(e);
-        const uint32_t lo = p.order_base[c], hi = p.order_base[c + 1];
-        const uint64_t key = order_key(e);
-        uint32_t rank = 0;
-        for (uint32_t k = lo; k < hi; k++) rank += order_key(p.order_tmp[k]) < key;
-        p.hits[lo + rank] = e;
+    if (p.ctr->overflow) return;  // (k_order_prefix has cleaned the counts)
+    __shared__ uint64_t key[kOrderBucket];
+    for (uint32_t c = blockIdx.x; c < p.n_chunks; c += gridDim.x) {
+        const uint32_t cnt = min(p.order_cnt[c], kOrderBucket), lo = p.order_base[c];
+        const uint64_t *bucket = p.order_tmp + (size_t)c * kOrderBucket;
+        __syncthreads();  // (the previous buffer's keys are done with, and so is its count)
+        if (threadIdx.x == 0) p.order_cnt[c] = 0;
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) key[i] = bucket[i];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const uint64_t e = key[i], k = order_key(e);
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < cnt; q++) rank += order_key(key[q]) < k;
+            p.hits[lo + rank] = e;
+        }
     }
 }
 
@@ -886,11 +884,7 @@ int launch_order_hits(const ScanParams &p, void *stream)
     hip_clear();
     if (!p.order_cnt || !p.order_base || !p.order_tmp) return 0;
     hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
-    // the count lives on the device: grid-stride loops over whatever there is
-    uint32_t blocks = (p.hits_cap + 255) / 256;
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(k_order_rank, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_order_buckets, dim3(std::min<uint32_t>(p.n_chunks, 2048u)), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

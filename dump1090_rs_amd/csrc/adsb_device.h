@@ -199,9 +199,11 @@ struct ScanParams {
     // previous call), or from src[-kCarrySamples..] when lead_from_src is set.
     const uint32_t *carry;
     uint32_t lead_from_src;
-    // device-side ordering of the hit list (k_order_bucket / k_order_rank; null: the host sorts):
-    // per-buffer hit counts (n_chunks + 1, all zero between passes), their exclusive prefix
-    // (n_chunks + 1) and a second list of hits_cap entries
+    // device-side ordering of the hit list (k_order_prefix / k_order_buckets; null: the host sorts).
+    // Whoever finds a hit puts it straight into its buffer's bucket -- order_tmp[chunk * kOrderBucket +
+    // order_cnt[chunk]++] -- and the hit list proper is written by k_order_buckets, each bucket sorted,
+    // at the buckets' exclusive prefix (order_base).  order_cnt / order_base: n_chunks + 1 entries,
+    // the counts all zero between passes; order_tmp: hits_cap >= n_chunks * kOrderBucket entries.
     uint32_t *order_cnt, *order_base;
     uint64_t *order_tmp;
     // self-test only (adsb_selftest_stage_lists): every position that passes the gates is also
@@ -221,6 +223,9 @@ struct ScanParams {
 constexpr uint32_t kBitmapWords = 1u << 19, kCoarseWords = 128;
 constexpr uint32_t kBitmapAllocWords = kBitmapWords + kCoarseWords;
 
+// hits one buffer's bucket holds on a dense stream (device-side ordering): ~20x a busy airspace;
+// a fuller one is an overflow like any other list's (the pass is redone buffer by buffer)
+constexpr uint32_t kOrderBucket = 1024;
 constexpr int kCarrySamples = 328;  // kLead rounded up to whole 16-byte loads
 
 // launches; all asynchronous on `stream`, return a hipError_t as int

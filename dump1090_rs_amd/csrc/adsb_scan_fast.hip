@@ -298,9 +298,13 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool 
             s.hit[at] = entry;
         } else {  // more hits in one tile than the staging holds: one by one
             const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
-            if (gi < p.hits_cap) {
+            if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
+                const uint32_t c = (uint32_t)entry_chunk(entry);
+                const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
+                if (k < kOrderBucket) p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
+                else atomicOr(&p.ctr->overflow, 1u);
+            } else if (gi < p.hits_cap) {
                 p.hits[gi] = entry;
-                if (p.order_cnt) atomicAdd(&p.order_cnt[entry_chunk(entry)], 1u);
             } else {
                 atomicOr(&p.ctr->overflow, 1u);
             }
@@ -808,13 +812,18 @@ tile_end:
     // (the AP fill counts are registers; they are written back when the workgroup retires)
     const uint32_t nhit = min(s.nhit[par], (uint32_t)kHitCap);
     if (nhit) {  // rare: a handful per chunk
-        if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
+        // (a tile's hits share its buffer: on a dense stream they go into that buffer's bucket)
+        uint64_t *const dst = p.order_cnt ? p.order_tmp + (size_t)chunk * kOrderBucket : p.hits;
+        const uint32_t dst_cap = p.order_cnt ? kOrderBucket : p.hits_cap;
+        if (tid == 0) {
+            const uint32_t at = atomicAdd(&p.ctr->n_hits, nhit);
+            s.hit_base = p.order_cnt ? atomicAdd(&p.order_cnt[chunk], nhit) : at;
+        }
         lds_barrier();
-        if (s.hit_base + nhit > p.hits_cap) {
+        if (s.hit_base + nhit > dst_cap) {
             if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
         } else {
-            for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
-            if (tid == 0 && p.order_cnt) atomicAdd(&p.order_cnt[chunk], nhit);  // a tile's hits share its buffer
+            for (uint32_t i = tid; i < nhit; i += kThreads) dst[s.hit_base + i] = s.hit[i];
         }
     }
     ACCT(6);
