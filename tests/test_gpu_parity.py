@@ -516,6 +516,37 @@ def test_device_side_scoring_hands_over_before_the_filter_table_fills(hip_lib, o
         assert 3 <= c._L.adsb_host_replays(c._h) <= 5, c._L.adsb_host_replays(c._h)
 
 
+def test_dense_stream_with_one_overfull_buffer_bucket_falls_back_and_stays_exact(hip_lib, oracle_mod):
+    """On a dense stream every hit goes into its buffer's bucket of 1024 (device-side ordering).  One
+    buffer packed with back-to-back frames holds more than that while no other list is anywhere near
+    full: the pass must be flagged and redone buffer by buffer, identical to the oracle, and the passes
+    around it must not notice."""
+    import torch
+    from dump1090_rs_amd import Context
+    n = 20 * 131072
+    host = [synth.make_iq(n, n_bursts=1500, seed=1200 + k, n_icao=40) for k in range(3)]
+    packed = synth.noise_numpy(131072, seed=77)
+    synth.add_bursts(packed, [synth.Burst(5 * (200 + 300 * q) + q % 5, 14000 + 10 * q, q % 16,
+                                          synth.df17_frame(0xA00000 + 0x101 * (q % 40), q)) for q in range(430)])
+    host[1][5 * 131072:6 * 131072] = packed
+    bufs = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want = [orc.demod_iq(h)[0] for h in host]
+    assert sum(w["chunk"] == 5 for w in want[1]) >= 400
+    with Context(0, 32) as c:
+        c.icao_flush()
+        got = [c.demod_iq_device(bufs[0].data_ptr(), n)]      # (tells the context how dense this stream is)
+        c.submit_iq_device(bufs[1].data_ptr(), n)
+        c.submit_iq_device(bufs[2].data_ptr(), n)
+        got.append(c.collect())
+        assert c.stats()["retries"] >= 1                        # the overfull bucket did overflow
+        got.append(c.collect())
+        for g, w in zip(got, want):
+            assert_same(g, w)
+
+
 # ----------------------------------------------------------------------------- stages
 def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod, golden, fixture_iq):
     """Not only frames: the device's magnitudes, the list of positions its gates let through and its
