@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
 // keys are unique (a trial is either self-validating or address/parity, never both).
 //   producers       whoever finds a hit puts it into its buffer's bucket (order_tmp, order_cnt)
 //   k_order_prefix  one workgroup: exclusive prefix of the counts (order_base)
-//   k_order_buckets one workgroup per buffer: the bucket sorted into its place in p.hits; the
-//                   count goes back to zero, which is how the next pass must find it
+//   k_records       takes whole buckets: a workgroup sorts a buffer's bucket in LDS (rank sort) and
+//                   writes its records at the bucket's place; the count goes back to zero, which
+//                   is how the next pass must find it.  (The sorted hit list itself is never stored.)
 // A pass whose lists overflowed is redone by the host anyway: its counts are only zeroed.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t order_key(uint64_t e)
@@ -169,29 +170,6 @@ __global__ __launch_bounds__(1024) void k_order_prefix(ScanParams p)
         __syncthreads();
         if (tid == 1023) carry += part[1023];
         __syncthreads();
-    }
-}
-
-// one block per buffer: its bucket sorted (a rank sort in LDS: a busy airspace leaves tens of hits per
-// buffer) into its place in the hit list; the count goes back to zero for the slot's next pass
-__global__ __launch_bounds__(256) void k_order_buckets(ScanParams p)
-{
-    TAIL_PRIO();
-    if (p.ctr->overflow) return;  // (k_order_prefix has cleaned the counts)
-    __shared__ uint64_t key[kOrderBucket];
-    for (uint32_t c = blockIdx.x; c < p.n_chunks; c += gridDim.x) {
-        const uint32_t cnt = min(p.order_cnt[c], kOrderBucket), lo = p.order_base[c];
-        const uint64_t *bucket = p.order_tmp + (size_t)c * kOrderBucket;
-        __syncthreads();  // (the previous buffer's keys are done with, and so is its count)
-        if (threadIdx.x == 0) p.order_cnt[c] = 0;
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) key[i] = bucket[i];
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const uint64_t e = key[i], k = order_key(e);
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < cnt; q++) rank += order_key(key[q]) < k;
-            p.hits[lo + rank] = e;
-        }
     }
 }
 
@@ -501,7 +479,7 @@ constexpr int kRecBatch = 64;     // records a block stages before writing them 
 #endif
 constexpr int kRecGroup = ADSB_REC_GROUP;  // hits a wave works on at once
 
-template <bool FROM_MAG>
+template <bool FROM_MAG, bool BUCKETS>
 __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 {
     if (p.order_cnt) TAIL_PRIO();  // dense streams only: elsewhere the scan is what bounds the step
@@ -523,9 +501,68 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t first = blockIdx.x * per, last = min(n, first + per);
     unsigned long long my_sum = 0;  // of the u64 words this thread sent to the host
-    const bool do_score = p.score.si && n <= p.score.cap && !p.ctr->overflow;  // (uniform) k_score follows
-    for (uint32_t b0 = first; b0 < last; b0 += kRecBatch) {
-        const uint32_t cnt = min((uint32_t)kRecBatch, last - b0);
+    const bool overflowed = p.ctr->overflow != 0;                             // (uniform) the host redoes the pass
+    const bool do_score = p.score.si && n <= p.score.cap && !overflowed;      // (uniform) k_score follows
+    // The hits come in runs.  Host-ordered passes: one run, this block's share of the hit list as it
+    // was filled.  Device-ordered passes (dense streams): one run per buffer this block takes -- the
+    // buffer's bucket, sorted here by (j, try_phase) with a rank sort in LDS, its records written at the
+    // bucket's place order_base[buffer]: the sorted hit list as such is never stored.
+    // (two instantiations: the host-ordered one keeps its plain loads from the hit list and none of the
+    // run bookkeeping -- as one kernel the sparse stream's step was 1.7 % longer)
+    constexpr bool buckets = BUCKETS;
+    // (dynamic LDS, only asked for by device-ordered launches: with 8 KB more a block of a sparse
+    // stream's launch held up the next scan's workgroups on its CU -- sparse step +3.6 %)
+    extern __shared__ uint64_t sorted[];
+    uint32_t next_chunk = blockIdx.x;
+    bool flat_done = false;
+    for (;;) {
+    const uint64_t *src;
+    uint32_t src_off, run_first, run_last;
+    if constexpr (buckets) {
+        if (overflowed || next_chunk >= p.n_chunks) break;
+        const uint32_t c = next_chunk;
+        next_chunk += gridDim.x;
+        const uint32_t bn = min(p.order_cnt[c], kOrderBucket), lo = p.order_base[c];
+        const uint64_t *bucket = p.order_tmp + (size_t)c * kOrderBucket;
+        __syncthreads();  // (the previous run is through with `sorted`, everyone has read this count)
+        if (threadIdx.x == 0) p.order_cnt[c] = 0;
+        uint64_t mine[kOrderBucket / 256];
+        uint32_t rank[kOrderBucket / 256];
+#pragma unroll
+        for (int k = 0; k < (int)kOrderBucket / 256; k++) {
+            const uint32_t i = threadIdx.x + 256u * k;
+            mine[k] = i < bn ? bucket[i] : 0ull;
+            if (i < bn) sorted[i] = mine[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < (int)kOrderBucket / 256; k++) {
+            const uint32_t i = threadIdx.x + 256u * k;
+            rank[k] = 0;
+            if (i < bn) {
+                const uint64_t key = order_key(mine[k]);
+                for (uint32_t q = 0; q < bn; q++) rank[k] += order_key(sorted[q]) < key;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < (int)kOrderBucket / 256; k++)
+            if (threadIdx.x + 256u * k < bn) sorted[rank[k]] = mine[k];
+        __syncthreads();
+        src = sorted;
+        src_off = lo;
+        run_first = lo;
+        run_last = lo + bn;
+    } else {
+        if (flat_done) break;
+        flat_done = true;
+        src = p.hits;
+        src_off = 0;
+        run_first = first;
+        run_last = last;
+    }
+    for (uint32_t b0 = run_first; b0 < run_last; b0 += kRecBatch) {
+        const uint32_t cnt = min((uint32_t)kRecBatch, run_last - b0);
         // A wave takes kRecGroup hits at a time and lane h writes the record of the group's hit h.
         // Beside a scan only one wave of this kernel fits a SIMD (the scan leaves 96 registers), so the
         // group is the wave's only source of independent work: its hits' memory latencies (entry, IQ
@@ -540,7 +577,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
 #pragma unroll
             for (int h = 0; h < kRecGroup; h++) {
                 // (every lane reads the same entry; made wave-uniform for the buffer resource below)
-                const uint64_t v = p.hits[b0 + g0 + min((uint32_t)h, ng - 1u)];  // (past ng: a repeat, unused)
+                const uint64_t v = src[b0 - src_off + g0 + min((uint32_t)h, ng - 1u)];  // (past ng: a repeat, unused)
                 e[h] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
             }
@@ -714,9 +751,10 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         }
         __syncthreads();  // stage is refilled by the next batch
     }
+    }  // runs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's records have left
     // the pass's record checksum (the host recomputes it over what it finds in its memory)
-    if (first < last) {
+    {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) my_sum += __shfl_down(my_sum, off);
         if (lane == 0 && my_sum) atomicAdd((unsigned long long *)p.ctr->rec_sum, my_sum);
@@ -872,10 +910,12 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
     // instruction count per hit: see the hit loop.
     uint32_t blocks = p.n_chunks + 8u;
     if (blocks > 4096) blocks = 4096;
-    if (from_mag)
-        hipLaunchKernelGGL(k_records<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+    if (from_mag)  // (one caller-supplied buffer: never device-ordered)
+        hipLaunchKernelGGL((k_records<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+    else if (p.order_cnt)  // device-ordered: dynamic LDS for the bucket being sorted
+        hipLaunchKernelGGL((k_records<false, true>), dim3(blocks), dim3(256), kOrderBucket * sizeof(uint64_t), (hipStream_t)stream, p, d_rec);
     else
-        hipLaunchKernelGGL(k_records<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
+        hipLaunchKernelGGL((k_records<false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     return hip_ok(hipGetLastError());
 }
 
@@ -884,7 +924,6 @@ int launch_order_hits(const ScanParams &p, void *stream)
     hip_clear();
     if (!p.order_cnt || !p.order_base || !p.order_tmp) return 0;
     hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(k_order_buckets, dim3(std::min<uint32_t>(p.n_chunks, 2048u)), dim3(256), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 
