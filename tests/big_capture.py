@@ -25,5 +25,11 @@ out = (AdsbMsg * (1 << 20))()
 for rep in range(3):  # without the Python-side unpacking of the frame list
     ctx.icao_flush(); t = time.time(); k = ctx.demod_iq_device_raw(dev.data_ptr(), n, out, 1 << 20)
     print(f"  raw call {rep}: {(time.time() - t) * 1e3:.2f} ms, {k} frames")
+    # (from the second call on the context knows the stream is dense: ordered -- k_order_prefix, more
+    #  than 1024 buffers -- and scored on the device)
+    again = [(m.chunk, m.j, m.try_phase, m.score, bytes(m.msg), m.signal_level) for m in out[:k]]
+    if again != b:
+        print("  MISMATCH in raw call", rep)
+        sys.exit(1)
 print(f"{chunks} buffers, {n} samples: {len(b)} frames, identical={a == b}, oracle (64 threads) {t_cpu:.2f} s, GPU call {t_gpu * 1e3:.1f} ms, stats {ctx.stats()}")
 sys.exit(0 if a == b else 1)
