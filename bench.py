@@ -236,12 +236,14 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     # is, and finishes the passes then in flight early to rebuild the device's copy of the filter: that
     # transition belongs to the warm-up, not to the steady state being timed)
     run_steps(0, 6 if workload == "dense" else 0, 1)
+    # (no collector pause inside a 2 ms timed region -- and none between the ramp and it either: the
+    # GPU must not idle there, a full collection takes milliseconds)
+    gc.collect()
+    gc.disable()
     ramp = clock_ramp(env, args, lambda first, count: run_steps(first, count, 1))
     run_steps(0, warmup, 1)
     # Timed region: K steps with HIP events around the scan kernel only (level 1), stamped by the
     # scan launch itself on the stream it runs on.
-    gc.collect()
-    gc.disable()   # (no collector pause inside a 2 ms timed region)
     env.fence()
     t0 = time.perf_counter()
     frames, tot, stamps = run_steps(warmup, steps, args.timed_profiling)
