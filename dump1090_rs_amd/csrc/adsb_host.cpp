@@ -106,6 +106,9 @@ struct adsb_ctx {
     // behind an in-order queue's end-of-kernel barrier.  `stream` (the caller's) only orders
     // the input: each scan waits for the point `stream` had reached at submit.
     hipStream_t scan_stream[2] = {nullptr, nullptr};
+    hipEvent_t prev_scanned = nullptr;      // the latest submission's scan-end event and the stream it is on
+    hipStream_t prev_scan_stream = nullptr;
+    bool prev_inline = false;               // ... and whether its match ran there rather than on the tail stream
     hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;
@@ -440,10 +443,21 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         for (Slot &other : c->slot)
             if (&other != &sl && other.busy && other.tail_q != ts) HIP_TRY(c, hipStreamWaitEvent(ts, other.recorded, 0));
     }
-    if (!inline_tail) {
-        HIP_TRY(c, hipEventRecord(sl.scanned, ss));
-        HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
-    }
+    // The match must see every bit the scans of this and of all earlier passes set in the bitmap
+    // (addresses their clean DF11 / DF17 frames will add).  Behind its own scan it is in stream order or
+    // waits for `scanned`.  Behind the previous pass's scan it is in order when both matches run on the
+    // tail stream (that pass's match waited for its scan); but a small pass matches on its own scan
+    // stream, beside the other one -- where the previous pass may still be scanning, or, the other way
+    // round, where a small previous pass may not even have started (its input still being copied) when
+    // this one's scan is over.  Then the match waits for the previous scan explicitly.  (Scans before the
+    // previous one are behind this pass's scan or the previous pass's, on the same two streams.)
+    HIP_TRY(c, hipEventRecord(sl.scanned, ss));
+    if (!inline_tail) HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+    if (c->prev_scanned && c->prev_scan_stream != ss && (inline_tail || c->prev_inline))
+        HIP_TRY(c, hipStreamWaitEvent(ts, c->prev_scanned, 0));
+    c->prev_scanned = sl.scanned;
+    c->prev_scan_stream = ss;
+    c->prev_inline = inline_tail;
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
     if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
     if (int e = launch_order_hits(p, ts)) return fail(c, (hipError_t)e, "launch_order_hits");

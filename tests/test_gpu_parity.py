@@ -258,6 +258,38 @@ def test_address_parity_hit_from_later_learned_address_is_ordered(ctx, oracle_mo
     assert ctx.stats()["n_records"] > len(want)  # the early DF4 was handed back and rejected
 
 
+@pytest.mark.parametrize("big_chunks", [12, 96])
+def test_small_pass_behind_a_pass_still_scanning_sees_its_addresses(hip_lib, oracle_mod, big_chunks):
+    """Pipelined: a long pass whose LAST buffer teaches an address, and right behind it a one-buffer pass
+    of address/parity frames for that address.  Small passes match on their own scan stream, beside the
+    other scan stream: their match must still wait for every earlier pass's scan (the bits it sets in
+    the bitmap), or the frames are dropped before the host replay ever sees them.  (Found by the
+    randomised soak: one ring case in 5 000.)"""
+    import torch
+    from dump1090_rs_amd import Context
+    icao = 0x3C6589
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    n_big = big_chunks * 131072
+    big = synth.noise_numpy(n_big, seed=31 + big_chunks)
+    synth.add_bursts(big, [synth.Burst(5 * (n_big - 3000), 22000, 3, synth.df17_frame(icao, 99))])
+    small = synth.noise_numpy(131072, seed=32)
+    synth.add_bursts(small, [synth.Burst(5 * (4000 + 9000 * q) + q, 21000, q, df4) for q in range(6)])
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want = [orc.demod_iq(big)[0], orc.demod_iq(small)[0]]
+    assert sum(w["buffer"] == df4 and w["score"] == 1000 for w in want[1]) >= 6
+    d_big, d_small = torch.from_numpy(big).cuda(), torch.from_numpy(small).cuda()
+    torch.cuda.synchronize()
+    with Context(0, big_chunks) as c:
+        for rep in range(10):
+            c.icao_flush()
+            c.submit_iq_device(d_big.data_ptr(), n_big)
+            c.submit_iq_device(d_small.data_ptr(), 131072)
+            assert_same(c.collect(), want[0])
+            assert_same(c.collect(), want[1])
+
+
 def test_device_resident_entry_point_and_determinism(ctx, oracle_mod):
     import torch
     n = 32 * 131072
