@@ -467,7 +467,9 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
         return fail(c, (hipError_t)e, "launch_records");
     sl.tail_q = ts;
-    if (sl.device_scored || ts != c->tail_stream) HIP_TRY(c, hipEventRecord(sl.recorded, ts));
+    // (always: a later pass whose own tail runs on another stream -- a small one behind an icao_flush --
+    // waits for this event before its records kernel clears the bitmap this pass matched against)
+    HIP_TRY(c, hipEventRecord(sl.recorded, ts));
     if (sl.device_scored) {
         // Scoring runs on its own in-order stream behind this pass's records kernel, so that the next
         // pass's match / order / records (tail stream) overlap it: every kernel beside the persistent

@@ -290,6 +290,43 @@ def test_small_pass_behind_a_pass_still_scanning_sees_its_addresses(hip_lib, ora
             assert_same(c.collect(), want[1])
 
 
+def test_small_flushed_pass_does_not_clear_the_bitmap_under_a_long_pass_in_flight(hip_lib, oracle_mod):
+    """A long pass in flight still has to match its address/parity trials against the addresses learned
+    before it; an icao_flush and a one-buffer pass right behind it retire that bitmap, and the small pass's
+    records kernel -- which runs long before the long pass's scan is over -- is the one that clears it: not
+    before the long pass's match is through."""
+    import torch
+    from dump1090_rs_amd import Context
+    icao = 0xABCDEF
+    body = bytes([0x28, 0x00, 0x1A, 0x30])
+    df5 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    first = synth.noise_numpy(131072, seed=51)
+    synth.add_bursts(first, [synth.Burst(5 * 30000, 20000, 4, synth.df17_frame(icao, 5))])
+    n_long = 160 * 131072
+    long_ = synth.noise_numpy(n_long, seed=52)
+    synth.add_bursts(long_, [synth.Burst(5 * (131072 * (3 + 13 * q) + 7000) + q % 5, 20000, q, df5) for q in range(12)])
+    small = synth.noise_numpy(131072, seed=53)
+    synth.add_bursts(small, [synth.Burst(5 * 50000, 20000, 7, synth.df17_frame(0x111111, 6))])
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    w_first = orc.demod_iq(first)[0]
+    w_long = orc.demod_iq(long_)[0]
+    orc.icao_flush()
+    w_small = orc.demod_iq(small)[0]
+    assert sum(w["buffer"] == df5 and w["score"] == 1000 for w in w_long) >= 12
+    d_first, d_long, d_small = (torch.from_numpy(x).cuda() for x in (first, long_, small))
+    torch.cuda.synchronize()
+    with Context(0, 160) as c:
+        for rep in range(6):
+            c.icao_flush()
+            assert_same(c.demod_iq_device(d_first.data_ptr(), 131072), w_first)
+            c.submit_iq_device(d_long.data_ptr(), n_long)
+            c.icao_flush()
+            c.submit_iq_device(d_small.data_ptr(), 131072)
+            assert_same(c.collect(), w_long)
+            assert_same(c.collect(), w_small)
+
+
 def test_device_resident_entry_point_and_determinism(ctx, oracle_mod):
     import torch
     n = 32 * 131072
