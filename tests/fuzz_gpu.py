@@ -127,6 +127,84 @@ def dense_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
     ctx.close()
 
 
+def mixed_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
+    """Cross-pass ordering: a stream of passes of very different sizes -- one to six buffers (their match
+    and records run on their own scan stream) between passes of 17-48 (tail stream) -- over captures that
+    share a handful of addresses, so that address/parity frames keep depending on what earlier passes
+    learned; random icao_flush between submissions, up to four in flight, device-resident or through the
+    ring (whose copy delays a pass's start).  Every pass against the oracle fed the same sequence."""
+    icaos = [int(x) for x in rng.integers(1, 1 << 24, size=int(rng.integers(2, 6)))]
+
+    def capture(chunks):
+        n = chunks * CHUNK - (int(rng.integers(0, 3000)) // 4 * 4 if rng.random() < 0.5 else 0)
+        iq = synth.noise_numpy(n, seed=int(rng.integers(1, 1 << 30)))
+        bursts = []
+        for _ in range(int(rng.integers(2, 14)) * chunks // 2 + 2):
+            icao = icaos[int(rng.integers(0, len(icaos)))]
+            kind = rng.random()
+            if kind < 0.35:
+                frame = synth.df17_frame(icao, int(rng.integers(0, 1 << 56)))
+            elif kind < 0.45:
+                frame = synth.df11_frame(icao)
+            elif kind < 0.8:
+                body = bytes([int(rng.choice([0x00, 0x20, 0x28])) | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 3).tolist())
+                frame = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+            else:
+                body = bytes([int(rng.choice([0x80, 0xA0, 0xA8])) | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 10).tolist())
+                frame = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+            # (late in the capture as often as early: what the NEXT pass needs is learned at the end)
+            tick = int(5 * n * (1 - rng.random() ** 2)) if rng.random() < 0.5 else int(rng.integers(0, 5 * n))
+            bursts.append(synth.Burst(min(tick, 5 * (n - 400)), int(rng.integers(6000, 30000)), int(rng.integers(0, 16)), frame))
+        synth.add_bursts(iq, bursts)
+        return iq
+
+    sizes = [int(rng.integers(1, 7)) if rng.random() < 0.6 else int(rng.integers(17, 49)) for _ in range(4)]
+    host = [capture(c) for c in sizes]
+    dev = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    ring_cap = 6 * CHUNK
+    ctx = Context(0, 48)
+    ctx.ring_create(ring_cap)
+    orc = Oracle()
+    orc.icao_flush()
+    ctx.icao_flush()
+    depth = int(rng.integers(2, 5))
+    pending = []
+
+    def check(got, want, what):
+        if [key(m) for m in got] != [okey(w) for w in want]:
+            print(f"MISMATCH mixed pipeline {case} (fuzz seed {seed}) at {what}: sizes {sizes}, {len(got)} frames, {len(want)} expected")
+            for x, y in zip([okey(w) for w in want], [key(m) for m in got]):
+                if x != y:
+                    print(" first difference:", x, y)
+                    break
+            sys.exit(1)
+
+    steps = int(rng.integers(6, 16))
+    for step in range(steps):
+        if rng.random() < 0.25:
+            orc.icao_flush()
+            ctx.icao_flush()
+        k = int(rng.integers(0, len(host)))
+        if len(pending) == depth:
+            check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
+        n = len(host[k])
+        if n <= ring_cap and rng.random() < 0.4:
+            buf = ctx.ring_acquire()
+            buf[:n] = host[k]
+            ctx.ring_submit(n)
+        else:
+            ctx.submit_iq_device(dev[k].data_ptr(), n)
+        pending.append(orc.demod_iq(host[k], cap=1 << 18)[0])
+        if rng.random() < 0.3:
+            check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
+    while pending:
+        check(ctx.collect(cap=1 << 18), pending.pop(0), "drain")
+    modes[("mixed_pipeline", False)] = modes.get(("mixed_pipeline", False), 0) + 1
+    modes[("mixed_pipeline:passes", False)] = modes.get(("mixed_pipeline:passes", False), 0) + steps
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -138,6 +216,9 @@ def main():
     ap.add_argument("--dense", type=int, default=8,
                     help="also run this many dense pipelines: passes of 17-30 buffers with thousands of trial records "
                          "each (ordered and scored on the device), random flushes, small and sparse passes between")
+    ap.add_argument("--mixed", type=int, default=8,
+                    help="also run this many mixed pipelines: small and large passes in flight together over "
+                         "captures that share addresses, random flushes, device-resident and ring-fed")
     args = ap.parse_args()
     import torch
     from dump1090_rs_amd import Context, sharding, synth
@@ -253,6 +334,8 @@ def main():
     if args.only < 0:
         for k in range(args.dense):
             dense_pipeline_case(np.random.default_rng([args.seed, k]), synth, Context, binding.Oracle, torch, modes, k, args.seed)
+        for k in range(args.mixed):
+            mixed_pipeline_case(np.random.default_rng([args.seed, 1000003, k]), synth, Context, binding.Oracle, torch, modes, k, args.seed)
     print(f"{args.cases} cases identical in {time.time() - t0:.1f} s; modes: "
           + ", ".join(f"{k[0]}{'+carry' if k[1] else ''}={v}" for k, v in sorted(modes.items())))
 

@@ -290,6 +290,38 @@ def test_small_pass_behind_a_pass_still_scanning_sees_its_addresses(hip_lib, ora
             assert_same(c.collect(), want[1])
 
 
+def test_pass_behind_a_ring_fed_small_pass_waits_for_its_scan(hip_lib, oracle_mod):
+    """The other direction: a ring-fed pass of six buffers (3 MB still crossing PCIe when it is submitted)
+    teaches an address; a device-resident pass of twenty buffers submitted right behind it -- its scan and
+    match are over before that copy is -- holds the address/parity frames that need it."""
+    import torch
+    from dump1090_rs_amd import Context
+    icao = 0x7C1234
+    body = bytes([0x20, 0x00, 0x11, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    n_w, n_x = 6 * 131072, 20 * 131072
+    w = synth.noise_numpy(n_w, seed=61)
+    synth.add_bursts(w, [synth.Burst(5 * (131072 * q + 40000), 20000, q, synth.df17_frame(icao, q)) for q in range(6)])
+    x = synth.noise_numpy(n_x, seed=62)
+    synth.add_bursts(x, [synth.Burst(5 * (131072 * (2 * q) + 9000) + q % 5, 20000, q, df4) for q in range(10)])
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want = [orc.demod_iq(w)[0], orc.demod_iq(x)[0]]
+    assert sum(f["buffer"] == df4 and f["score"] == 1000 for f in want[1]) >= 10
+    d_x = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    with Context(0, 20) as c:
+        c.ring_create(n_w)
+        for rep in range(5):
+            c.icao_flush()
+            buf = c.ring_acquire()
+            buf[:n_w] = w
+            c.ring_submit(n_w)
+            c.submit_iq_device(d_x.data_ptr(), n_x)
+            assert_same(c.collect(), want[0])
+            assert_same(c.collect(), want[1])
+
+
 def test_small_flushed_pass_does_not_clear_the_bitmap_under_a_long_pass_in_flight(hip_lib, oracle_mod):
     """A long pass in flight still has to match its address/parity trials against the addresses learned
     before it; an icao_flush and a one-buffer pass right behind it retire that bitmap, and the small pass's
@@ -984,7 +1016,7 @@ def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
     import subprocess
     import sys
     from tests.conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "80", "--seed", "7", "--dense", "5"],
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "80", "--seed", "7", "--dense", "5", "--mixed", "5"],
                        capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "80 cases identical" in r.stdout and "dense_pipeline=5" in r.stdout   # (+ 5 dense pipelines: device-side order / score)
