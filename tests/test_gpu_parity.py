@@ -322,6 +322,44 @@ def test_pass_behind_a_ring_fed_small_pass_waits_for_its_scan(hip_lib, oracle_mo
             assert_same(c.collect(), want[1])
 
 
+def test_flushed_small_pass_waits_for_a_ring_fed_long_pass_before_clearing_its_bitmap(hip_lib, oracle_mod):
+    """A twenty-buffer pass fed through the ring (10 MB still crossing PCIe) has address/parity frames for
+    an address learned before it; an icao_flush and a one-buffer device-resident pass behind it are through
+    long before that copy is -- and the small pass's records kernel is the one that clears the retired
+    bitmap: it has to wait for the long pass's match."""
+    import torch
+    from dump1090_rs_amd import Context
+    icao = 0x5A5A5A
+    body = bytes([0x28, 0x00, 0x07, 0x31])
+    df5 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    first = synth.noise_numpy(131072, seed=71)
+    synth.add_bursts(first, [synth.Burst(5 * 30000, 20000, 4, synth.df17_frame(icao, 5))])
+    n_long = 20 * 131072
+    long_ = synth.noise_numpy(n_long, seed=72)
+    synth.add_bursts(long_, [synth.Burst(5 * (131072 * (2 * q) + 7000) + q % 5, 20000, q, df5) for q in range(10)])
+    small = synth.noise_numpy(131072, seed=73)
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    w_first, w_long = orc.demod_iq(first)[0], orc.demod_iq(long_)[0]
+    orc.icao_flush()
+    w_small = orc.demod_iq(small)[0]
+    assert sum(f["buffer"] == df5 and f["score"] == 1000 for f in w_long) >= 10
+    d_first, d_small = torch.from_numpy(first).cuda(), torch.from_numpy(small).cuda()
+    torch.cuda.synchronize()
+    with Context(0, 20) as c:
+        c.ring_create(n_long)
+        for rep in range(4):
+            c.icao_flush()
+            assert_same(c.demod_iq_device(d_first.data_ptr(), 131072), w_first)
+            buf = c.ring_acquire()
+            buf[:n_long] = long_
+            c.ring_submit(n_long)
+            c.icao_flush()
+            c.submit_iq_device(d_small.data_ptr(), 131072)
+            assert_same(c.collect(), w_long)
+            assert_same(c.collect(), w_small)
+
+
 def test_small_flushed_pass_does_not_clear_the_bitmap_under_a_long_pass_in_flight(hip_lib, oracle_mod):
     """A long pass in flight still has to match its address/parity trials against the addresses learned
     before it; an icao_flush and a one-buffer pass right behind it retire that bitmap, and the small pass's
