@@ -103,24 +103,43 @@ def dense_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
     orc.icao_flush()
     ctx.icao_flush()
     pending = []   # expected outputs of the passes in flight
+    # (sequence and expected outputs first: the submissions then follow each other at the host's pace)
+    plan = []
+    in_flight = 0
     for step in range(int(rng.integers(6, 14))):
-        if rng.random() < 0.15 and not pending:     # a small blocking call in between (host-scored)
+        if rng.random() < 0.15 and in_flight == 0:     # a small blocking call in between (host-scored)
             k = int(rng.integers(0, 3))
             m = int(rng.integers(1, 4)) * CHUNK
-            check(ctx.demod_iq(host[k][:m]), orc.demod_iq(host[k][:m])[0], f"step {step} (small)")
+            plan.append(("small", k, m, orc.demod_iq(host[k][:m])[0]))
             continue
-        if rng.random() < 0.3:
+        flush = rng.random() < 0.3
+        if flush:
             orc.icao_flush()
-            ctx.icao_flush()
         k = int(rng.integers(0, 3))
-        if len(pending) == 3:
+        pre = in_flight == 3
+        if pre:
+            in_flight -= 1
+        in_flight += 1
+        post = rng.random() < 0.4
+        if post:
+            in_flight -= 1
+        plan.append(("pass", k, (flush, pre, post), orc.demod_iq(host[k], cap=1 << 18)[0]))
+    for step, (what, k, arg, want) in enumerate(plan):
+        if what == "small":
+            check(ctx.demod_iq(host[k][:arg]), want, f"step {step} (small)")
+            continue
+        flush, pre, post = arg
+        if flush:
+            ctx.icao_flush()
+        if pre:
             check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
         ctx.submit_iq_device(bufs[k].data_ptr(), n)
-        pending.append(orc.demod_iq(host[k], cap=1 << 18)[0])
-        if rng.random() < 0.4:
+        pending.append(want)
+        if post:
             check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
     while pending:
         check(ctx.collect(cap=1 << 18), pending.pop(0), "drain")
+    step = len(plan)
     modes[("dense_pipeline", False)] = modes.get(("dense_pipeline", False), 0) + 1
     modes[("dense_pipeline:host_replays", False)] = modes.get(("dense_pipeline:host_replays", False), 0) + int(ctx._L.adsb_host_replays(ctx._h))
     modes[("dense_pipeline:passes", False)] = modes.get(("dense_pipeline:passes", False), 0) + int(step)
@@ -133,7 +152,9 @@ def mixed_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
     share a handful of addresses, so that address/parity frames keep depending on what earlier passes
     learned; random icao_flush between submissions, up to four in flight, device-resident or through the
     ring (whose copy delays a pass's start).  Every pass against the oracle fed the same sequence."""
-    icaos = [int(x) for x in rng.integers(1, 1 << 24, size=int(rng.integers(2, 6)))]
+    # (enough addresses that passes keep learning new ones, and flushes often enough that "new" recurs)
+    icaos = [int(x) for x in rng.integers(1, 1 << 24, size=int(rng.integers(4, 40)))]
+    p_flush = float(rng.choice([0.15, 0.4, 0.6]))
 
     def capture(chunks):
         n = chunks * CHUNK - (int(rng.integers(0, 3000)) // 4 * 4 if rng.random() < 0.5 else 0)
@@ -180,23 +201,32 @@ def mixed_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
                     break
             sys.exit(1)
 
+    # the whole sequence is drawn and its expected output computed first, so that the submissions below
+    # follow each other as fast as the host can issue them (the oracle takes milliseconds per pass)
     steps = int(rng.integers(6, 16))
+    plan = []
     for step in range(steps):
-        if rng.random() < 0.25:
-            orc.icao_flush()
-            ctx.icao_flush()
+        flush = rng.random() < p_flush
         k = int(rng.integers(0, len(host)))
+        ring = len(host[k]) <= ring_cap and rng.random() < 0.4
+        early = rng.random() < 0.3
+        if flush:
+            orc.icao_flush()
+        plan.append((flush, k, ring, early, orc.demod_iq(host[k], cap=1 << 18)[0]))
+    for step, (flush, k, ring, early, want) in enumerate(plan):
+        if flush:
+            ctx.icao_flush()
         if len(pending) == depth:
             check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
         n = len(host[k])
-        if n <= ring_cap and rng.random() < 0.4:
+        if ring:
             buf = ctx.ring_acquire()
             buf[:n] = host[k]
             ctx.ring_submit(n)
         else:
             ctx.submit_iq_device(dev[k].data_ptr(), n)
-        pending.append(orc.demod_iq(host[k], cap=1 << 18)[0])
-        if rng.random() < 0.3:
+        pending.append(want)
+        if early:
             check(ctx.collect(cap=1 << 18), pending.pop(0), f"step {step}")
     while pending:
         check(ctx.collect(cap=1 << 18), pending.pop(0), "drain")
