@@ -181,9 +181,15 @@ def mixed_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
 
     sizes = [int(rng.integers(1, 7)) if rng.random() < 0.6 else int(rng.integers(17, 49)) for _ in range(4)]
     host = [capture(c) for c in sizes]
+    # some of the large ones dense (thousands of trial records): the context then moves between host- and
+    # device-side ordering / scoring as the stream's density changes, with passes of both kinds in flight
+    for k, c in enumerate(sizes):
+        if c >= 17 and rng.random() < 0.5:
+            host[k] = synth.make_iq(c * CHUNK, n_bursts=int(c * rng.integers(70, 110)), seed=int(rng.integers(1, 1 << 30)),
+                                    n_icao=int(rng.integers(3, 40)), df11_every=int(rng.integers(0, 5)))
     dev = [torch.from_numpy(h).cuda() for h in host]
     torch.cuda.synchronize()
-    ring_cap = 6 * CHUNK
+    ring_cap = int(rng.choice([6, 24])) * CHUNK
     ctx = Context(0, 48)
     ctx.ring_create(ring_cap)
     orc = Oracle()
