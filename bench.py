@@ -376,7 +376,7 @@ def resident_result(env: Env, args, r, workload: str):
             "host_api": "blocking adsb_demod_iq_device per step" if args.sync else
                         f"adsb_submit_iq_device / adsb_collect, {r['depth']} passes in flight",
             "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_match -> "
-                       "k_order_* -> k_records -> host replay",
+                       "k_order_prefix -> k_records (bucket sort) -> host replay, or k_score -> k_emit on dense streams",
             "library": _lib.lib().adsb_version().decode(),
             "clock_ramp": {**r["ramp"], "what": "untimed passes of this workload before the W warm-up steps, until the "
                            "GPU holds its clocks under the load (bench.py: clock_ramp); ms_per_step_cold = the first 20 "
