@@ -48,8 +48,6 @@ FEED_SRC = CSRC / "adsb_feed.cpp"
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and not stale() and FEED.exists() and FEED.stat().st_mtime >= FEED_SRC.stat().st_mtime:
-        if not ABI_HOST.exists() or ABI_HOST.stat().st_mtime < ABI_HOST_SRC.stat().st_mtime:
-            build_abi_host(verbose)
         return LIB
     # ADSB_HIPCC_FLAGS: extra flags, e.g. -DADSB_KERNEL_ACCT for the in-kernel phase accounting
     extra = os.environ.get("ADSB_HIPCC_FLAGS", "").split()
@@ -64,7 +62,6 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    build_abi_host(verbose)
     return LIB
 
 
@@ -72,9 +69,15 @@ ABI_HOST_SRC = PKG.parent / "tests" / "abi_host.c"
 ABI_HOST = PKG.parent / "tests" / "abi_host"
 
 
-def build_abi_host(verbose: bool = False) -> Path:
+def build_abi_host(verbose: bool = False, force: bool = False) -> Path:
     """tests/abi_host.c: the reference's test routine from a plain-C host over include/adsb_hip.h
-    (gcc, no Python in between); the GPU tests run it against the golden frames."""
+    (gcc, no Python in between); the GPU tests run it against the golden frames.  Test
+    infrastructure: built by __graft_entry__.build() and the test fixtures, never by
+    build_library() -- the product does not depend on the test tree or on gcc."""
+    if not force and ABI_HOST.exists() and ABI_HOST.stat().st_mtime >= max(
+            ABI_HOST_SRC.stat().st_mtime, LIB.stat().st_mtime if LIB.exists() else 0,
+            (PKG.parent / "include" / "adsb_hip.h").stat().st_mtime):
+        return ABI_HOST
     cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", f"-I{PKG.parent / 'include'}", str(ABI_HOST_SRC),
            "-o", str(ABI_HOST), f"-L{PKG}", "-ladsb_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/../dump1090_rs_amd"]
     if verbose:
@@ -85,4 +88,6 @@ def build_abi_host(verbose: bool = False) -> Path:
 
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)
+    if ABI_HOST_SRC.exists():
+        build_abi_host(verbose=True)
     print(LIB)

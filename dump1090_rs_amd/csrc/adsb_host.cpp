@@ -621,9 +621,13 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     st.n_candidates += sl.h_sum->n_cand_total;
     st.n_ap_entries += sl.h_sum->n_ap_total;
     st.n_records += n;
-    if (sl.hits_cap == c->hits_cap) {  // (not the fallback's one-buffer passes)
-        if (n >= 4096) c->dense_mode = true;
-        else if (n < 1024) c->dense_mode = false;
+    // Density is records per buffer (8 and more: device-side order + score; under 2: the host does
+    // it), so that a context of 64 buffers decides like one of 512.  Passes too small to be ordered on
+    // the device anyway (and the fallback's one-buffer passes) say nothing about the stream: a small
+    // pass between large dense ones must not flip the mode, each flip drains the pipeline.
+    if (sl.hits_cap == c->hits_cap && sl.n_chunks > kInlineTailChunks) {
+        if (n >= 8u * (size_t)sl.n_chunks) c->dense_mode = true;
+        else if (n < 2u * (size_t)sl.n_chunks) c->dense_mode = false;
     }
     if (take_device_result(c, sl, chunk_offset, out)) return 0;
     if (rec_on_device && n) {
@@ -1608,6 +1612,11 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
         c->cur_bitmap = (c->cur_bitmap + 1) % kBitmaps;
         c->filter.flush();
         c->flush_pending = false;
+        // the device-side copy of the filter (exact bitmap, k_score) still holds the addresses from
+        // before the flush and was not rotated here: it is rebuilt from the (now empty) host table
+        // before the next device-scored pass -- the context is idle, nothing in flight to disown
+        c->exact_valid = false;
+        ++c->score_epoch;
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;

@@ -58,6 +58,9 @@ using namespace fastgeo;
 #ifndef ADSB_PRIO_LATE
 #define ADSB_PRIO_LATE 1   // wave priority during P3..P5 (0 = leave it alone)
 #endif
+#ifndef ADSB_GATE_ASM
+#define ADSB_GATE_ASM 1    // P4: the 19 magnitudes of a match as opaque zero-extended LDS reads (0 = C++ u16 loads)
+#endif
 #ifndef ADSB_SCAN_THREADS
 #define ADSB_SCAN_THREADS 256
 #endif
@@ -170,10 +173,33 @@ __device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
     // 8/16-byte reads at a 2-byte aligned address, which the LDS replays at 64 cycles each.
     const uint16_t *pm = mag + (ent & 0x1FFFu);
     const uint32_t br = (ent >> 13) & 7u;  // which branch's pattern matched, with "<=" for "<"
+#if ADSB_GATE_ASM
+    // The reads as the instructions themselves, results as plain 32-bit values: left to the compiler
+    // the u16 loads become "any-extending" ones whose users are SDWA forms (4.2 cycles where the
+    // plain add / sub takes 2.7) plus six v_and 0xffff in front of the max3 chain.  One block, one
+    // wait: nothing else of this wave's is in flight here (the pattern entry was waited for).
+    int p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, q14, q15, q16, q17, q18;
+    {
+        const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t *)pm;
+        asm volatile(
+            "ds_read_u16 %0, %18\n\tds_read_u16 %1, %18 offset:2\n\tds_read_u16 %2, %18 offset:4\n\t"
+            "ds_read_u16 %3, %18 offset:6\n\tds_read_u16 %4, %18 offset:8\n\tds_read_u16 %5, %18 offset:10\n\t"
+            "ds_read_u16 %6, %18 offset:12\n\tds_read_u16 %7, %18 offset:14\n\tds_read_u16 %8, %18 offset:16\n\t"
+            "ds_read_u16 %9, %18 offset:18\n\tds_read_u16 %10, %18 offset:20\n\tds_read_u16 %11, %18 offset:22\n\t"
+            "ds_read_u16 %12, %18 offset:24\n\tds_read_u16 %13, %18 offset:28\n\tds_read_u16 %14, %18 offset:30\n\t"
+            "ds_read_u16 %15, %18 offset:32\n\tds_read_u16 %16, %18 offset:34\n\tds_read_u16 %17, %18 offset:36\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7), "=&v"(p8),
+              "=&v"(p9), "=&v"(p10), "=&v"(p11), "=&v"(p12), "=&v"(q14), "=&v"(q15), "=&v"(q16), "=&v"(q17), "=&v"(q18)
+            : "v"(a)
+            : "memory");
+    }
+#else
     const int p0 = pm[0];
     const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
               p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
     const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
+#endif
     // high / base_signal / base_noise of the five branches (:227-317), written around what they
     // share: with X = p3+p9 (branches 1-3) or p4+p10 (branches 4, 5)
     //   high  = (p1 + p12 + X + [1]p11 + [3](p4+p10) + [5]p2) / 4

@@ -98,10 +98,17 @@ typedef struct {
 /* Create a context on HIP device `device` (>= 0), sized to demodulate up to
  * `max_chunks` 131072-sample buffers per call (host-pointer calls stage through
  * a device buffer of that size; device-pointer calls only size the lists).
- * Device memory: ~7.5 MB for max_chunks = 1 (three 2 MiB address bitmaps and the
- * lists of four passes in flight), ~300 MB for 512; input denser than the lists are
- * sized for (several times a busy airspace) is still demodulated exactly, buffer
- * by buffer through worst-case lists allocated on first use (stats.retries). */
+ * Footprint (ADSB_MAX_IN_FLIGHT = 4 passes in flight, each with its own lists):
+ *   device   seven 2 MiB address bitmaps (five in rotation for the superset test, two for the
+ *            device-side copy of the filter) = 14.7 MB, plus per pass in flight the address/parity
+ *            list, hit lists and scoring buffers: ~1.1 MB each for max_chunks = 1 (~19 MB in all),
+ *            ~84 MB each for 512 (~350 MB in all);
+ *   pinned host (mapped, written by the kernels)  per pass in flight 32 B per trial record
+ *            (4096 + 1024 max_chunks of them) + 44 B per scored message slot (min(that, 131072)):
+ *            ~1.6 MB in all for max_chunks = 1, ~90 MB for 512.
+ * Input denser than the lists are sized for (several times a busy airspace) is still
+ * demodulated exactly, buffer by buffer through worst-case lists allocated on first use
+ * (another 10 MB of device and 20 MB of pinned memory; stats.retries). */
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks);
 void adsb_destroy(adsb_ctx *ctx);
 
@@ -166,11 +173,11 @@ int adsb_pending(const adsb_ctx *ctx);
 int adsb_fetch_messages(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 
 /* Streaming ring for a host that produces IQ (an SDR read loop, dump1090_rs/src/main.rs:
- * 154-167): two pinned host buffers of `samples_per_slot` samples with a device staging
- * buffer each.  Fill the buffer adsb_ring_acquire hands out (e.g. read the SDR straight
- * into it), adsb_ring_submit(n) starts its host-to-device copy on a copy stream and the
- * pass behind it, adsb_collect returns the oldest pass's messages.  While one slot's pass
- * runs, the other slot's transfer is in flight.  samples_per_slot may not exceed the
+ * 154-167): ADSB_MAX_IN_FLIGHT (4) pinned host buffers of `samples_per_slot` samples (4 bytes
+ * each) with a device staging buffer each.  Fill the buffer adsb_ring_acquire hands out (e.g.
+ * read the SDR straight into it), adsb_ring_submit(n) starts its host-to-device copy on a copy
+ * stream and the pass behind it, adsb_collect returns the oldest pass's messages.  While one
+ * slot's pass runs, the next slots' transfers are in flight.  samples_per_slot may not exceed the
  * context's max_chunks buffers; adsb_ring_acquire returns ADSB_ERR_BUSY until the pass
  * that last used the slot has been collected. */
 int adsb_ring_create(adsb_ctx *ctx, size_t samples_per_slot);

@@ -62,4 +62,5 @@ def hip_lib():
     """libadsb_hip.so, built if stale (hipcc cross-compiles without a GPU)."""
     from dump1090_rs_amd import _lib, build
     build.build_library()
+    build.build_abi_host()   # the compiled-C host of test_compiled_c_host_runs_the_reference_test_routine
     return _lib.lib()

@@ -616,7 +616,59 @@ def test_device_side_scoring_follows_the_filter_across_pipelined_passes(hip_lib,
         outs += [c.collect(), c.collect()]
         for k, g in zip(seq, outs):
             assert_same(g, orc.demod_iq(host[k])[0])
-        assert 3 <= c._L.adsb_host_replays(c._h) <= 5         # the first one to three of these five, not all
+        # (the small pass does not change the context's idea of the stream's density: the first large
+        # pass behind it finds the device's copy of the filter stale, rebuilds it and is scored there)
+        assert c._L.adsb_host_replays(c._h) == 2
+
+
+def test_shard_pass_behind_a_flush_between_device_scored_passes_resyncs_the_device_filter(hip_lib, oracle_mod):
+    """icao_flush + adsb_shard_scan / adsb_shard_finish between dense, device-scored passes: the shard call
+    consumes the flush (host filter emptied), so the device's copy of the filter must be disowned and
+    rebuilt too -- or the passes after it are scored against the pre-flush addresses (1600 / 1800 /
+    address-parity 1000 for addresses a flushed filter does not know)."""
+    import torch
+    from dump1090_rs_amd import Context
+    from dump1090_rs_amd.context import replay_records
+    n = 20 * 131072
+    icao = 0x4840D6
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    host = [synth.make_iq(n, n_bursts=1600, seed=1500 + k, n_icao=5, df11_every=3) for k in range(3)]
+    synth.add_bursts(host[0], [synth.Burst(5 * (131072 * 2 + 4000) + 1, 21000, 1, synth.df17_frame(icao, 3))])
+    # host[2] carries address/parity frames for an address only host[0] teaches: after the flush they must vanish
+    synth.add_bursts(host[2], [synth.Burst(5 * (131072 * (1 + q) + 700 * q + 211) + q, 21000, q, df4) for q in range(1, 6)])
+    shard_iq = synth.make_iq(4 * 131072, n_bursts=30, seed=1599)
+    bufs = [torch.from_numpy(h).cuda() for h in host]
+    sdev = torch.from_numpy(shard_iq).cuda()
+    torch.cuda.synchronize()
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want = [orc.demod_iq(host[k])[0] for k in (1, 0, 2)]
+    assert sum(w["buffer"] == df4 for w in want[2]) >= 3          # known before the flush ...
+    orc.icao_flush()
+    want += [orc.demod_iq(host[k])[0] for k in (2, 1)]
+    # (a shard's records are replayed by whoever holds all shards, through a filter of their own: the
+    # context's filter only sees the flush the shard call consumed)
+    want_shard = oracle_mod.Oracle().demod_iq(shard_iq)[0]
+    assert not any(w["buffer"] == df4 for w in want[3])            # ... and not after it
+    with Context(0, 32) as c:
+        c.icao_flush()
+        got = [c.demod_iq_device(bufs[1].data_ptr(), n)]          # (tells the context how dense this stream is)
+        c.submit_iq_device(bufs[0].data_ptr(), n)
+        c.submit_iq_device(bufs[2].data_ptr(), n)
+        got += [c.collect(), c.collect()]
+        replays = c._L.adsb_host_replays(c._h)
+        assert replays == 1                                        # the two pipelined passes were the device's
+        c.icao_flush()
+        c.shard_scan(sdev.data_ptr(), 4 * 131072)
+        assert_same(replay_records(c.shard_finish(np.zeros(0, np.uint32))), want_shard)
+        c.submit_iq_device(bufs[2].data_ptr(), n)
+        c.submit_iq_device(bufs[1].data_ptr(), n)
+        got += [c.collect(), c.collect()]
+        for g, w in zip(got, want):
+            assert_same(g, w)
+        # scored on the device again, against a copy of the filter rebuilt after the flush
+        assert c._L.adsb_host_replays(c._h) == replays
 
 def test_device_side_scoring_hands_over_before_the_filter_table_fills(hip_lib, oracle_mod):
     """icao_filter_add gives up silently once its 4096-slot table is full (src/icao_filter.rs:46-62) --

@@ -5,6 +5,6 @@
 for rep in $(seq 1 ${AB_REPS:-3}); do
   for tag in "$@"; do
     cp gpurun_lib_$tag.so dump1090_rs_amd/libadsb_hip.so
-    echo -n "$tag: "; timeout 120 python bench.py --steps ${AB_STEPS:-40} --warmup 3 --no-cpu-baseline $AB_ARGS 2>/dev/null | grep -o "\"ms_per_step\": [0-9.]*\|kernel_avg_ms\": [0-9.]*\|exclusive_avg_ms\": [0-9.]*" | tr '\n' ' '; echo
+    echo -n "$tag: "; timeout 120 python bench.py --steps ${AB_STEPS:-40} --warmup 3 --no-cpu-baseline --no-also $AB_ARGS 2>/dev/null | grep -o "\"ms_per_step\": [0-9.]*\|kernel_avg_ms\": [0-9.]*\|exclusive_avg_ms\": [0-9.]*" | tr '\n' ' '; echo
   done
 done

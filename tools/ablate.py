@@ -1,6 +1,14 @@
-import os, sys, subprocess, json
-for stop in (1,2,3,4,5,0):
-    env=dict(os.environ, ADSB_DEBUG_STOP=str(stop))
-    out=subprocess.run([sys.executable,'bench.py','--steps','10','--warmup','3','--no-cpu-baseline','--buffers','2'],env=env,capture_output=True,text=True).stdout.strip().splitlines()[-1]
-    r=json.loads(out)
-    print(stop, r['roofline']['kernel_avg_ms'], r['ms_per_step'], r['device_stats_last_step'])
+"""ADSB_DEBUG_STOP=n ablation of k_scan_fast (needs a library built with -DADSB_TUNING): the kernel cut
+short after P1 / P2 / P3 patterns / P4 gates / P5 (no epilogue) / whole.  Extra arguments go to bench.py
+(e.g. --sync).  usage: python tools/ablate.py [--sync]"""
+import json
+import os
+import subprocess
+import sys
+
+for stop in (1, 2, 3, 4, 5, 0):
+    env = dict(os.environ, ADSB_DEBUG_STOP=str(stop))
+    out = subprocess.run([sys.executable, 'bench.py', '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-also',
+                          '--buffers', '2', *sys.argv[1:]], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+    r = json.loads(out[-1])
+    print(stop, r['roofline']['kernel_avg_ms'], r['ms_per_step'], flush=True)

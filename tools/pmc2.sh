@@ -4,7 +4,7 @@ rocprofv3 -L 2>/dev/null | grep -o "SQ_LDS_[A-Z_]*\|SQ_INST_CYCLES_[A-Z_]*\|SQ_I
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$N/s$i -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --buffers 2 > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$N/s$i -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --buffers 2 > /dev/null 2>&1
   python3 - <<PY
 import csv, collections
 rows=list(csv.DictReader(open('$R/gpurun_out/$N/s$i/p_counter_collection.csv')))

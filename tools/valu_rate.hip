@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
             if (OP == 45) asm volatile("v_pk_mad_i16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 46) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 47) asm volatile("v_mad_u32_u16 %0, %0, %1, %1 op_sel:[1,0,0,0]" : "+v"(a[i]) : "v"(b));
+            if (OP == 48) asm volatile("v_ashr_pk_i8_i32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(b));
+            if (OP == 49) asm volatile("v_dot4_i32_i8 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 50) asm volatile("v_dot4c_i32_i8_e32 %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 51) asm volatile("v_dot2_i32_i16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 52) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 53) asm volatile("v_sad_u16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 54) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a[i]) : "v"(b));
+            if (OP == 55) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 56) asm volatile("v_ffbl_b32_e32 %0, %0" : "+v"(a[i]));
+            if (OP == 57) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]));
+            if (OP == 58) asm volatile("v_bfe_i32 %0, %0, 3, 1" : "+v"(a[i]));
+            if (OP == 59) asm volatile("v_lshrrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(a[i]) : "v"(b));
+            if (OP == 60) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d2[i]) : "v"(db));
+            if (OP == 61) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 62) asm volatile("v_min3_i32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 63) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
         }
     }
     uint32_t r = 0;
@@ -142,5 +158,21 @@ int main()
     run<45>("v_pk_mad_i16", d);
     run<46>("v_pk_max_i16", d);
     run<47>("v_mad_u32_u16", d);
+    run<48>("v_ashr_pk_i8_i32", d);
+    run<49>("v_dot4_i32_i8", d);
+    run<50>("v_dot4c_i32_i8", d);
+    run<51>("v_dot2_i32_i16", d);
+    run<52>("v_cvt_pk_i16_i32", d);
+    run<53>("v_sad_u16", d);
+    run<54>("v_bitop3_b32", d);
+    run<55>("v_mbcnt_lo", d);
+    run<56>("v_ffbl_b32", d);
+    run<57>("v_add_u32_dpp", d);
+    run<58>("v_bfe_i32", d);
+    run<59>("v_lshrrev_sdwa", d);
+    run<60>("v_pk_add_f32", d);
+    run<61>("v_mul_lo_u32", d);
+    run<62>("v_min3_i32", d);
+    run<63>("v_or3_b32", d);
     return 0;
 }
