@@ -1,0 +1,975 @@
+// adsb_scan_fast.hip -- the gfx950 scan kernel: IQ in, trial syndromes out, magnitudes
+// never leave the CU.
+//
+// One workgroup (256 threads = 4 wave64) owns a tile of 7712 preamble positions j of
+// one chunk; the 8004 magnitudes those positions can touch (j .. j+290) live in LDS.
+// The reference walks j serially and slices 5 x 112 bits per surviving j with a small
+// state machine (src/demod_2400.rs:121-207).  Here the same decisions are taken densely
+// and bit-parallel:
+//
+//  P1 magnitudes   dwordx4 IQ loads (4 samples / lane, aligned, coalesced) -> exact f32
+//                  magnitude (src/utils.rs:47-55) -> u16 in LDS.
+//  P2 sign planes  every decision the reference can ever take on this tile is the sign of
+//                  a short integer correlation of neighbouring magnitudes:
+//                    slicer phase ph at sample s (demod_2400.rs:72-83)   5 kinds
+//                    m[s] > m[s+1] (check_preamble :221-317)              1 kind
+//                  (check_preamble's "<" is taken as "<=", the complement of ">", and made
+//                  strict again in P4).  All six are taken for every sample.  A lane walks samples 12 apart
+//                  (bit n and bit n+5 of a message are 12 samples apart), four
+//                  neighbouring residues at a time so the first differences are shared,
+//                  and shifts each sign into an accumulator with one v_alignbit -- no
+//                  compare, no cross-lane traffic.  The accumulators are stored as bytes
+//                  of bit planes: plane (kind, s mod 12), bit s div 12.
+//  P3 preamble     check_preamble's five patterns are AND/OR of the ">" planes and their
+//                  complements at fixed offsets: one lane evaluates 32 positions j per instruction.
+//  P4 gates        the ~4.5 % of positions that match a pattern get the value tests
+//                  (high/SNR/quiet, :129-146) from LDS magnitudes, one lane each, and the
+//                  strict form of the "<" tests of the branch they matched (equal neighbours:
+//                  the reference's own test sequence decides).
+//  P5 trials       for the ~1 % that survive, each (j, try_phase) is one lane: the five
+//                  bit classes n mod 5 of the message are five 23-bit fields cut out of the
+//                  sign planes with two dword loads and a funnel shift; DF and the CRC-24
+//                  syndrome come from table lookups on the fields (adsb_tables.h); the
+//                  message bytes are never assembled here.
+//
+// The kernel is VALU-issue bound (tools/valu_rate.hip: ~4.2 cycles per wave64 VOP3 /
+// mad / cvt / compare, ~2.7 for plain VOP2 add/and/shift), so the code below is written
+// to the instruction: 24-bit multiplies with magic constants instead of divisions,
+// shifts and masks instead of bit-field extracts, u16 LDS reads instead of unpacking.
+//
+// Nothing in the kernel has a capacity that input density could exceed: each wave keeps
+// its matches and candidates in its own small LDS regions and drains them in rounds
+// (P3..P5 below), so exactness never depends on how dense the signal is.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include <hip/hip_ext.h>
+
+#include "adsb_dev_common.h"
+#include "adsb_scan_geometry.h"
+
+namespace adsb {
+
+namespace {
+
+using namespace fastgeo;
+
+#ifndef ADSB_PRIO_LATE
+#define ADSB_PRIO_LATE 1   // wave priority during P3..P5 (0 = leave it alone)
+#endif
+#ifndef ADSB_GATE_ASM
+#define ADSB_GATE_ASM 1    // P4: the 19 magnitudes of a match as opaque zero-extended LDS reads (0 = C++ u16 loads)
+#endif
+#ifndef ADSB_SCAN_THREADS
+#define ADSB_SCAN_THREADS 256
+#endif
+constexpr int kThreads = ADSB_SCAN_THREADS;   // 256 (512 was measured: 7 % slower)
+#ifndef ADSB_SCAN_OCC
+#define ADSB_SCAN_OCC 4
+#endif
+#ifndef ADSB_SCAN_RES
+#define ADSB_SCAN_RES 4
+#endif
+constexpr int kWavesPerSimd = kThreads == 512 ? 8 : ADSB_SCAN_OCC;  // = workgroups per CU
+constexpr int kResPerItem = kThreads == 512 ? 2 : ADSB_SCAN_RES;  // residues one P2 lane walks
+constexpr int kAllocSlots = 96 * kPlaneBytes + 16;  // 8080 magnitudes P2 may read
+constexpr int kPlaneGT = 60;                  // planes 0..59: slicer sign, kind*12 + residue
+constexpr int kPlanes = 84;                   // 60..83: GT ("m[s] > m[s+1]") residues 0..23
+                                              //   (residue r+12 = residue r advanced one bit)
+constexpr int kItems2 = (12 / kResPerItem) * kPlaneBytes;  // P2 items: (residue group, plane byte)
+constexpr int kItems3 = 12 * (kPlaneBytes / 4);  // 252 P3 items: (residue, plane dword)
+static_assert(kItems3 <= 256, "one P3 item per thread");
+static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
+constexpr int kWaves = kThreads / 64;
+constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
+constexpr int kRoundBits = 4;                 // plane bits per round when they do not fit: 64 x 4 <= 256
+// A wave's candidates waiting for the trial stage: a ring of slot | plane buffer << 13.  With deferred
+// trials (adsb_scan_geometry.h: kDefer) a tile leaves fewer than 64 trials behind and the next
+// tile's gates add to them.
+constexpr int kCandPerWave = kDefer ? 256 : 128;
+constexpr int kRingTrials = 5 * kCandPerWave;  // the ring in units of (candidate, try_phase)
+static_assert((kCandPerWave & (kCandPerWave - 1)) == 0 && kRingTrials + 64 < 3277, "ring index arithmetic (split5)");
+static_assert(64 * kRoundBits <= kPatPerWave, "wave-private regions");
+constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
+
+// LDS accesses wider than their address is aligned are legal on gfx950 but replayed at 64
+// cycles (SQ_LDS_UNALIGNED_STALL); with unaligned-access-mode on (the default) the
+// compiler merges neighbouring u16 / u32 LDS reads into exactly those.  The scan kernel is
+// compiled with the mode off: merges only happen where alignment is known.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ADSB_NO_UNALIGNED __attribute__((target("no-unaligned-access-mode")))
+#else
+#define ADSB_NO_UNALIGNED
+#endif
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for the next tile's IQ prefetch at every phase boundary; here only LDS
+// traffic (lgkmcnt) is drained before s_barrier, global loads stay in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Order this wave's own LDS traffic: writes before, reads after.  LDS operations of one
+// wave complete in order, so draining lgkmcnt is all it takes; "memory" keeps the
+// compiler from moving LDS accesses across.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh)[31:0], sh in 0..31
+}
+
+// shift the sign bit of v into acc from the right
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, int v)
+{
+    return alignbit(acc, (uint32_t)v, 31);
+}
+
+// inclusive prefix sum across the 64 lanes of a wave, in registers (DPP row shifts and
+// row broadcasts; lanes with no source add 0)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)v;
+}
+
+// base + rank of this lane among the set bits of a wave mask (the base rides in mbcnt's addend)
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m, uint32_t base = 0u)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+}
+
+__device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped to 0..32
+{
+    return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
+}
+
+
+struct alignas(16) FastLds {
+    uint16_t mag[kAllocSlots];         // P1..P4
+    uint32_t plane[kPlanes * kRowDw];
+    uint32_t tab[3 * 256];             // F'0 F'1 F'2 (adsb_tables.h)
+    uint32_t r16[16];                  // x^24..x^27 reduction
+    uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
+    uint16_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
+    uint16_t cand[kWaves * kCandPerWave];  // per wave: slot | plane buffer << 13 (cand_entry() expands it for the trial stage)
+    uint64_t hit[kHitCap];
+    uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
+    uint32_t tile_j[2], tile_chunk[2];  // per plane buffer: jbase - kPad and chunk of the tile whose planes it holds
+};
+
+// P4, one pattern match: high / base_signal / base_noise of the branch that matched first
+// (demod_2400.rs:227-317), the 3.5 dB test (:129) and the quiet samples (:135-146).
+// Branch-free; returns 1 when the position goes on to be sliced.
+__device__ __forceinline__ uint32_t gate_eval(const uint16_t *mag, uint32_t ent)
+{
+    // one u16 LDS read per magnitude (no unpacking on the VALU).  The kernel is compiled
+    // without unaligned-access-mode (ADSB_NO_UNALIGNED below), or these would be merged into
+    // 8/16-byte reads at a 2-byte aligned address, which the LDS replays at 64 cycles each.
+    const uint16_t *pm = mag + (ent & 0x1FFFu);
+    const uint32_t br = (ent >> 13) & 7u;  // which branch's pattern matched, with "<=" for "<"
+#if ADSB_GATE_ASM
+    // The reads as the instructions themselves, results as plain 32-bit values: left to the compiler
+    // the u16 loads become "any-extending" ones whose users are SDWA forms (4.2 cycles where the
+    // plain add / sub takes 2.7) plus six v_and 0xffff in front of the max3 chain.  One block, one
+    // wait: nothing else of this wave's is in flight here (the pattern entry was waited for).
+    int p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, q14, q15, q16, q17, q18;
+    {
+        const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t *)pm;
+        asm volatile(
+            "ds_read_u16 %0, %18\n\tds_read_u16 %1, %18 offset:2\n\tds_read_u16 %2, %18 offset:4\n\t"
+            "ds_read_u16 %3, %18 offset:6\n\tds_read_u16 %4, %18 offset:8\n\tds_read_u16 %5, %18 offset:10\n\t"
+            "ds_read_u16 %6, %18 offset:12\n\tds_read_u16 %7, %18 offset:14\n\tds_read_u16 %8, %18 offset:16\n\t"
+            "ds_read_u16 %9, %18 offset:18\n\tds_read_u16 %10, %18 offset:20\n\tds_read_u16 %11, %18 offset:22\n\t"
+            "ds_read_u16 %12, %18 offset:24\n\tds_read_u16 %13, %18 offset:28\n\tds_read_u16 %14, %18 offset:30\n\t"
+            "ds_read_u16 %15, %18 offset:32\n\tds_read_u16 %16, %18 offset:34\n\tds_read_u16 %17, %18 offset:36\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7), "=&v"(p8),
+              "=&v"(p9), "=&v"(p10), "=&v"(p11), "=&v"(p12), "=&v"(q14), "=&v"(q15), "=&v"(q16), "=&v"(q17), "=&v"(q18)
+            : "v"(a)
+            : "memory");
+    }
+#else
+    const int p0 = pm[0];
+    const int p1 = pm[1], p2 = pm[2], p3 = pm[3], p4 = pm[4], p5 = pm[5], p6 = pm[6], p7 = pm[7],
+              p8 = pm[8], p9 = pm[9], p10 = pm[10], p11 = pm[11], p12 = pm[12];
+    const int q14 = pm[14], q15 = pm[15], q16 = pm[16], q17 = pm[17], q18 = pm[18];
+#endif
+    // high / base_signal / base_noise of the five branches (:227-317), written around what they
+    // share: with X = p3+p9 (branches 1-3) or p4+p10 (branches 4, 5)
+    //   high  = (p1 + p12 + X + [1]p11 + [3](p4+p10) + [5]p2) / 4
+    //   sig   = X*not[3] + p1*not[5] + p12*not[1]
+    //   noise = p6 + p7 + [1,2,4]p5 + [2,4,5]p8
+    // five 0 / -1 masks per branch, 5 bits each in one constant: A=[1] B=[3] C=[5] G=[1,2,4] H=[2,4,5]
+    constexpr uint32_t kMasksPacked = 9u | (24u << 5) | (2u << 10) | (24u << 15) | (20u << 20);
+    const int mk = (int)(kMasksPacked >> (5u * br));
+#define MASK(bit) __builtin_amdgcn_sbfe(mk, (bit), 1)
+    const int mA = MASK(0), mB = MASK(1), mC = MASK(2), mG = MASK(3), mH = MASK(4);
+#undef MASK
+    const int s39 = p3 + p9, s410 = p4 + p10;
+    const int X = br >= 3u ? s410 : s39;
+    const int high = (p1 + p12 + X + (p11 & mA) + (s410 & mB) + (p2 & mC)) >> 2;
+    const int sig = (X & ~mB) + (p1 & ~mC) + (p12 & ~mA);
+    const int noise = p6 + p7 + (p5 & mG) + (p8 & mH);
+    const int loud = max(max(max(p5, p6), max(p7, p8)), max(max(q14, q15), max(max(q16, q17), q18)));
+    uint32_t pass = (uint32_t)(2 * sig >= 3 * noise) & (uint32_t)(loud < high);  // :129, :135-146
+    // The pattern stage has no "<" plane: it took p[o] <= p[o+1] for the four "<" of the branch
+    // (:221 and the branch's own three).  Equal neighbours are rare; when one of those four
+    // pairs is equal the reference may have taken a later branch or none, so that position is
+    // decided by the reference's own sequence of tests (preamble_gates, adsb_dev_common.h).
+    const int dx = br >= 3u ? p4 - p3 : p3 - p2;      // branches 4, 5: p3 < p4;  1-3: p2 < p3
+    const int dy = br >= 3u ? p10 - p9 : p9 - p8;     //               p9 < p10;      p8 < p9
+    const int dz = br == 0u ? p11 - p10 : p12 - p11;  // branch 1: p10 < p11;  others: p11 < p12
+    if (min(min(p1 - p0, dx), min(dy, dz)) <= 0) pass = (uint32_t)preamble_gates(pm);
+    return pass;
+}
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32: a ^ b ^ c in one op
+}
+
+// candidate entry: slot | plane bit (slot/12, + 32 kPlaneDw in the second plane buffer) << 13 | slot%12 << 24
+__device__ __forceinline__ uint32_t cand_entry(uint32_t w)
+{
+    const uint32_t slot = w & 0x1FFFu;
+    const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
+    const uint32_t rs = slot - 12u * qs;
+    const uint32_t qb = kDefer ? qs + __umul24(w >> 13, 32u * kPlaneDw) : qs;
+    return slot | (qb << 13) | (rs << 24) | (kDefer ? (w >> 13) << 28 : 0u);
+}
+
+// P5, one trial.  Message bit n = 5k + r of trial phase tp sits at 5x-oversampled position
+// 5*(slot+19) + tp + 12n, i.e. sample slot + 19 + (tp+12r)/5 + 12k with slicer phase
+// (tp+12r) % 5: field r is 23 consecutive bits of one sign plane; which plane and where
+// comes from s.field.  Branch-free so that two trials per lane interleave.
+struct Trial {
+    uint32_t f[5];   // the five bit classes n mod 5 (bit k = message bit 5k + r)
+    uint32_t h;      // x^51 * H reduced: short messages' CRC residual as is (adsb_tables.h)
+    uint32_t code;   // try_phase - 4, + 5 for 112-bit messages
+    uint32_t cslot;
+    bool is_ap, is_hit, learn;  // address/parity trial; self-validating hit; hit that adds its address
+};
+
+__device__ __forceinline__ void trial_eval(const FastLds &s, uint32_t ce, uint32_t tpi, Trial &o)
+{
+    const uint32_t qs = (ce >> 13) & 0x7FFu, rs = (ce >> 24) & 15u;
+    o.cslot = ce & 0x1FFFu;
+    const uint32_t *ft = s.field + __umul24(tpi, 60u) + rs;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t fe = ft[r * 12];       // LDS address of the plane row | bit offset << 16 (P0)
+        const uint32_t qq = qs + (fe >> 16);  // plane bit of message bit r
+        // 4-byte aligned only: becomes one ds_read2_b32 (not an 8-byte read off its alignment,
+        // which is replayed at 64 cycles -- ADSB_NO_UNALIGNED)
+        typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+        lds_u32 pl = (lds_u32)(uintptr_t)((fe & 0xFFFFu) + ((qq >> 3) & 0xFCu));  // (a row is < 256 bytes)
+        const uint32_t lo = pl[0], hi = pl[1];
+        o.f[r] = alignbit(hi, lo, qq);  // the shift is qq mod 32
+    }
+    const uint32_t *f = o.f;
+    // mod.rs:41: DF = message bits 0..4 = bit 0 of the five fields
+    const uint32_t df = ((f[0] & 1u) << 4) | ((f[1] & 1u) << 3) | ((f[2] & 1u) << 2) | ((f[3] & 1u) << 1) | (f[4] & 1u);
+    const uint32_t lng = f[0] & 1u;  // DF >= 16: 112 bits
+    // 112 bits: n <= 111 -> k <= 22 for r < 2, k <= 21 otherwise; 56 bits: n <= 55 -> k <= 11
+    // for r = 0, k <= 10 otherwise.  (The reference's all-zero-message test, mod.rs:51, is left
+    // to the host replay: an all-zero trial is DF 0 with residual 0, goes out as an address/
+    // parity entry, matches address 0 and is dropped there -- it cannot arise in bulk, zero
+    // samples match no preamble.)
+    const uint32_t mk0 = lng ? 0x7FFFFFu : 0xFFFu, mk1 = lng ? 0x7FFFFFu : 0x7FFu, mk2 = lng ? 0x3FFFFFu : 0x7FFu;
+    const uint32_t fm[5] = {f[0] & mk0, f[1] & mk1, f[2] & mk2, f[3] & mk2, f[4] & mk2};
+    // sum_r x^(4-r) * F'(f_r) as a 28-bit polynomial, reduced once (adsb_tables.h)
+    const uint32_t *tF = s.tab;
+    uint32_t g[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++)  // one byte-select-and-shift per index, one three-way XOR per field
+        g[r] = xor3(tF[fm[r] & 0xFFu], tF[256 + ((fm[r] >> 8) & 0xFFu)], tF[512 + ((fm[r] >> 16) & 0xFFu)]);
+    const uint32_t hp = xor3(g[0] << 4, g[1] << 3, xor3(g[2] << 2, g[3] << 1, g[4]));
+    const uint32_t h = (hp & 0xFFFFFFu) ^ s.r16[hp >> 24];
+    o.h = h;
+    o.code = tpi + 5u * lng;
+    // DF classes as bit sets indexed by DF (mod.rs:56-135).  Comparisons, so that the class
+    // logic lives in lane masks on the scalar unit rather than in VALU arithmetic.
+    const bool ap = ((0xFF310031u >> df) & 1u) != 0;        // 0,4,5,16,20,21,24..31: address/parity
+    const bool d1718 = ((0x00060000u >> df) & 1u) != 0;     // clean iff residual == 0
+    const bool d11 = df == 11u;                             // clean iff residual & 0xFFFF80 == 0
+    const bool z = h == 0, z11 = (h & 0xFFFF80u) == 0;
+    o.is_ap = ap;
+    o.is_hit = (d1718 && z) || (d11 && z11);
+    // DF17 and DF11 with IID 0 add their address; DF18 adds addr | 1 << 25, never matched
+    o.learn = z && (d11 || df == 17u);
+}
+
+__device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 8..31
+{
+    uint32_t addr = 0;
+#pragma unroll
+    for (int n = 8; n < 32; n++) addr |= ((t.f[n % 5] >> (n / 5)) & 1u) << (31 - n);
+    return addr;
+}
+
+// a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
+__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane,
+                                          uint32_t par)
+{
+    const unsigned long long mh = __ballot(is_hit);
+    if (!mh) return;
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&s.nhit[par], (uint32_t)__popcll(mh));
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + mask_rank(mh);
+    if (is_hit) {
+        if (at < (uint32_t)kHitCap) {
+            s.hit[at] = entry;
+        } else {  // more hits in one tile than the staging holds: one by one
+            const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
+            if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
+                const uint32_t c = (uint32_t)entry_chunk(entry);
+                const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
+                if (k < kOrderBucket) p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
+                else atomicOr(&p.ctr->overflow, 1u);
+            } else if (gi < p.hits_cap) {
+                p.hits[gi] = entry;
+            } else {
+                atomicOr(&p.ctr->overflow, 1u);
+            }
+        }
+    }
+}
+
+// IQ of one tile, as each thread holds it between the load and the magnitude pass:
+// 8 aligned dwordx4 = 32 samples per thread, 8080 per workgroup.
+constexpr int kLoadsPerThread = (kAllocSlots / 4 + kThreads - 1) / kThreads;  // 8
+
+struct TileRef {
+    uint32_t chunk;
+    int tile, len, jbase;
+};
+
+template <bool FROM_MAG>
+__device__ __forceinline__ TileRef tile_ref(const ScanParams &p, uint32_t t)
+{
+    TileRef r;
+    r.chunk = t / kTilesPerChunk;
+    r.tile = (int)(t % kTilesPerChunk);
+    // a caller-supplied MagnitudeBuffer is one buffer: n_samples is its `length`
+    r.len = FROM_MAG ? (int)p.n_samples : chunk_len(p.n_samples, r.chunk);
+    r.jbase = r.tile * kTile;
+    return r;
+}
+
+// The tile's IQ through a buffer resource that spans exactly this chunk's samples: the
+// hardware range check returns zero for every dword outside [0, len) -- the 326-sample
+// lead-in before the chunk (negative offsets wrap to huge unsigned ones), the zero tail
+// and the ragged end of a short last chunk -- so the eight dwordx4 loads are issued
+// back to back with no branch and no wait between them.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool FROM_MAG>
+__device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef &r, int tid,
+                                             uint4 (&pre)[kLoadsPerThread])
+{
+    if (FROM_MAG) {
+        // caller-supplied magnitudes (adsb_demodulate2400): MagnitudeBuffer.data as handed in,
+        // lead-in included; 4 u16 per load, zero outside [0, kMagDataLen) by the range check
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.src, 0, kMagDataLen * 2, 0x00020000);
+        const int d0 = r.jbase - kPad;  // data index of slot 0
+#pragma unroll
+        for (int i = 0; i < kLoadsPerThread; i++) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            // (opaque: a "+ 2048 i" folded into the instruction's immediate offset is added to a
+            // negative register offset without wrapping, i.e. out of range -- adsb_aux.hip: k_records)
+            int off = (d0 + 4 * (tid + i * kThreads)) * 2;
+            asm volatile("" : "+v"(off));
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+            pre[i] = make_uint4(v.x, v.y, 0u, 0u);
+        }
+        return;
+    }
+    const uint32_t *iq = (const uint32_t *)p.src + r.chunk * (uint64_t)kChunkSamples;
+    // carry-over mode: the resource starts kCarrySamples before the buffer when those samples
+    // exist in src, so the lead-in is simply in range (the reference's mode: it is not)
+    const bool lead = p.carry != nullptr && (r.chunk > 0 || p.lead_from_src);
+    const int shift = lead ? kCarrySamples : 0;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(iq - shift), 0, (r.len + shift) * 4, 0x00020000);
+    // (offsets opaque to the compiler, as in the branch above: a constant folded into the
+    // instruction's immediate offset would break the range check for the lanes before sample 0)
+    const int k0 = r.jbase - kPad - kLead + shift;  // IQ sample index of slot 0 (multiple of 4)
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; i++) {
+        int off = (k0 + 4 * (tid + i * kThreads)) * 4;
+        asm volatile("" : "+v"(off));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        pre[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    if (p.carry != nullptr && !lead && r.tile == 0) {
+        // first buffer of a call: its lead-in is the end of the previous call (out of range of
+        // one resource = zero from it, so the two loads just OR together)
+        const __amdgpu_buffer_rsrc_t crsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.carry, 0, kCarrySamples * 4, 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(crsrc, (k0 + kCarrySamples + 4 * tid) * 4, 0, 0);
+        pre[0].x |= v.x;
+        pre[0].y |= v.y;
+        pre[0].z |= v.z;
+        pre[0].w |= v.w;
+    }
+}
+
+// A lane writes its own matches (bits of m; the branch 0..4 of each from the three code planes)
+// into the wave's pattern region from index `at` on: slot | branch << 13.
+__device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint32_t code1, uint32_t code2,
+                                                uint32_t slot0, uint16_t *wpat, uint32_t at)
+{
+    while (m) {
+        const uint32_t bit = (uint32_t)__ffs(m) - 1u;
+        m &= m - 1;
+        // three single-bit extracts and two shift-ors (left to itself the compiler shifts and
+        // masks each plane separately: eight ops)
+        uint32_t k = __builtin_amdgcn_ubfe(code0, bit, 1u);
+        k |= __builtin_amdgcn_ubfe(code1, bit, 1u) << 1;
+        k |= __builtin_amdgcn_ubfe(code2, bit, 1u) << 2;
+        wpat[at++] = (uint16_t)((slot0 + 12u * bit) | (k << 13));
+    }
+}
+
+// One 64-lane pass of the gates: `ent` is this lane's pattern match (valid lanes only count),
+// passing positions are appended to the wave's candidate region.
+__device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s, uint32_t ent, bool valid,
+                                          uint16_t *wcand, uint32_t &ncand_w, int jbase, uint32_t chunk, uint32_t tag)
+{
+    const bool pass = (gate_eval(s.mag, ent) & (uint32_t)valid) != 0;
+    const unsigned long long mask = __ballot(pass);
+    if (mask) {
+        // (ncand_w: where the next candidate goes -- a plain count, or the ring's write index)
+        if (pass) wcand[mask_rank(mask, ncand_w) & (uint32_t)(kCandPerWave - 1)] = (uint16_t)((ent & 0x1FFFu) | tag);
+        ncand_w += (uint32_t)__popcll(mask);
+        if (p.cand_out && pass) {  // self-test only: the candidate list itself (adsb_selftest_stage_lists)
+            const uint32_t at = atomicAdd(p.cand_count, 1u);
+            if (at < p.cand_cap) p.cand_out[at] = (uint64_t)chunk << 32 | (uint32_t)(jbase - kPad + (int)(ent & 0x1FFFu));
+        }
+    }
+}
+
+// One 64-lane pass of the trials: lane = (candidate entry ce, try_phase 4 + tpi).
+__device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint32_t ce, uint32_t tpi, bool live,
+                                           int jbase, uint32_t chunk, uint64_t *seg, uint32_t seg_cap,
+                                           uint32_t &ap_count, int lane, uint32_t par)
+{
+    // (jbase / chunk: of the tile this lane's candidate belongs to -- with deferred trials a pass can
+    // hold the previous tile's leftovers beside this tile's)
+    Trial tr;
+    trial_eval(s, ce, tpi, tr);
+    const bool is_ap = live && tr.is_ap, is_hit = live && tr.is_hit, learn = live && tr.learn;
+    // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
+    uint32_t j = (uint32_t)(jbase - kPad) + tr.cslot;
+    if (kDefer) {  // the candidate's own tile: by the plane buffer its entry names (bit 28 of ce)
+        const uint32_t b = ce >> 28;
+        j = s.tile_j[b] + tr.cslot;
+        chunk = s.tile_chunk[b];
+    }
+    const uint64_t entry = ((uint64_t)((j >> 4) | (chunk << 13)) << 32) | (tr.h | (tr.code << 24) | (j << 28));
+    // AP entries: straight into this wave's own segment of the list (no atomic, no shared
+    // counter: the fill count is a wave-uniform register)
+    const unsigned long long ma = __ballot(is_ap);
+    if (ma) {
+        const uint32_t mine = mask_rank(ma, ap_count);
+        if (is_ap && mine < seg_cap) seg[mine] = entry;
+        ap_count += (uint32_t)__popcll(ma);
+    }
+    if (__ballot(is_hit)) stage_hit(p, s, is_hit, entry, lane, par);  // rare
+    if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
+        if (learn) bitmap_set(p.bitmap, trial_addr(tr));
+    }
+}
+
+// t5 = 5 c + tpi for t5 < 3277 (24-bit multiply, not the slow 32-bit one)
+__device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
+{
+    c = __umul24(t5, 13108u) >> 16;
+    tpi = t5 - __umul24(5u, c);
+}
+
+// profiling aids, compiled in with -DADSB_KERNEL_ACCT only (they cost registers):
+// wave 0 of a few workgroups stamps the shader clock at phase boundaries
+#ifdef ADSB_KERNEL_ACCT
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        if (p.timeline && !ADSB_STOP_AT(p, 100) && tid == 0 && (blockIdx.x & 127) == 0 && iter < 8)                   \
+            p.timeline[((blockIdx.x >> 7) * 8 + iter) * 8 + (slot)] = (unsigned long long)clock64(); \
+    } while (0)
+
+// (ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2): every wave totals the clocks it spends in each
+// phase and waiting at each workgroup barrier
+#define ACCT(k)                                                   \
+    do {                                                          \
+        if (acct) {                                               \
+            const unsigned long long now_ = clock64();            \
+            acc_t[k] += now_ - acc_last;                          \
+            acc_last = now_;                                      \
+        }                                                         \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#define ACCT(k) do {} while (0)
+#endif
+
+// Persistent: the grid is what is resident at once and each workgroup walks tiles
+// t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
+// after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
+template <bool FROM_MAG>
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
+{
+    __shared__ FastLds s;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
+
+    // ---------------------------------------------------------------- P0 once per workgroup
+    for (int i = tid; i < 3 * 256; i += kThreads) s.tab[i] = p.tables[kTabF * 256 + i];
+    for (int i = tid; i < 316; i += kThreads) {
+        const uint32_t v = p.tables[kTabR16Off + i];
+        if (i < 16)
+            s.r16[i] = v;
+        else  // plane row byte offset -> its LDS address, so that the trial stage adds nothing
+            s.field[i - 16] = v + (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s.plane;
+    }
+    if (tid < kPlanes)  // read slack behind each buffer of a row
+        for (int b = 0; b < kPlaneBufs; b++) s.plane[tid * kRowDw + b * kPlaneDw + kPlaneDw - 1] = 0;
+    for (int i = tid; i < kWaves * kCandPerWave; i += kThreads) s.cand[i] = 0;  // (idle lanes of a trial pass read stale entries)
+    if (tid < 2) s.nhit[tid] = 0;
+
+    const uint32_t seg_cap = p.seg_cap;
+    const uint32_t my_seg = blockIdx.x * kWaves + (uint32_t)(tid >> 6);
+    uint64_t *const seg = p.ap + (uint64_t)my_seg * seg_cap;  // this wave's own AP segment
+    uint32_t ap_count = 0, cand_count = 0;  // wave-uniform running totals of this wave
+
+    uint4 pre[kLoadsPerThread];
+    // Which tiles this workgroup walks.  Blocks b, b + 8, b + 16, ... run on the same XCD (observed
+    // placement, used for speed only), so each XCD gets one contiguous eighth of the tiles and its
+    // blocks walk it side by side: the 368 samples two neighbouring tiles share are then read from
+    // HBM once and found in that XCD's L2 by the neighbour.  Any other grid: plain round robin.
+    uint32_t t_first = blockIdx.x, t_end = n_tiles, t_stride = gridDim.x;
+    if ((gridDim.x & 7u) == 0 && n_tiles >= gridDim.x) {
+        const uint32_t x = blockIdx.x & 7u;
+        t_first = ((x * n_tiles) >> 3) + (blockIdx.x >> 3);
+        t_end = ((x + 1u) * n_tiles) >> 3;
+        t_stride = gridDim.x >> 3;
+    }
+    if (t_first < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t_first), tid, pre);
+
+    // Workgroups that share a CU start a fraction of a tile period apart, so that the
+    // VALU-dense phases of one overlap the latency-bound phases of the others instead of
+    // all of them marching through the same phase together.
+#ifdef ADSB_TUNING
+    if (p.stagger_ticks) {
+        const uint32_t k = (blockIdx.x * 4u) / gridDim.x;  // 0..3: which quarter of the grid
+        const unsigned long long until = clock64() + (unsigned long long)k * p.stagger_ticks;
+        while ((unsigned long long)clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+
+#ifdef ADSB_KERNEL_ACCT
+    const bool acct = ADSB_STOP_AT(p, 100) && p.timeline != nullptr;
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
+#endif
+
+    const bool late_prio = ADSB_PRIO_LATE != 0 && p.order_cnt == nullptr;
+    const int wave = tid >> 6;
+    uint16_t *const wpat = s.pat + wave * kPatPerWave;
+    uint16_t *const wcand = s.cand + wave * kCandPerWave;
+    // The wave's ring of candidates (all wave-uniform): `pend` trials wait, the first of them at ring
+    // position t_head (in units of (candidate, try_phase)); the gates write candidates at c_tail.
+    uint32_t pend = 0, t_head = 0, c_tail = 0;
+    uint32_t cur_pbuf = kPlaneBufs - 1;  // plane buffer of the tile processed last
+    // The staged hits of a tile (s.hit, counted in s.nhit[par_]) to the hit list.  Whole workgroup.
+    auto flush_hits = [&](uint32_t par_) {
+        const uint32_t nhit = min(s.nhit[par_], (uint32_t)kHitCap);
+        if (nhit == 0) return;  // the usual case: a handful of hits per chunk
+        if (p.order_cnt) {
+            // dense stream: every hit into its own buffer's bucket (a pass of trials may hold the previous
+            // tile's leftovers, and that tile may belong to another buffer)
+            if (tid == 0) atomicAdd(&p.ctr->n_hits, nhit);
+            for (uint32_t i = tid; i < nhit; i += kThreads) {
+                const uint64_t e = s.hit[i];
+                const uint32_t c = (uint32_t)entry_chunk(e);
+                const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
+                if (k < kOrderBucket) p.order_tmp[(size_t)c * kOrderBucket + k] = e;
+                else atomicOr(&p.ctr->overflow, 1u);
+            }
+        } else {
+            if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
+            lds_barrier();
+            if (s.hit_base + nhit > p.hits_cap) {
+                if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
+            } else {
+                for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
+            }
+        }
+    };
+    uint32_t iter = 0;
+    // (with deferred trials one more turn of the loop after the last tile: nothing but the trials it
+    // left over -- one short pass per wave and launch -- and their hits)
+    bool drain = false;
+    for (uint32_t t = t_first;; t += t_stride, iter++) {
+    if (t >= t_end) {
+        if (drain || !kDefer) break;
+        drain = true;
+    }
+    const TileRef cur = tile_ref<FROM_MAG>(p, drain ? t_first : t);
+    STAMP(0);
+    const uint32_t chunk = cur.chunk;
+    const int len = cur.len, jbase = cur.jbase;
+    const int jn = min(kTile, len - jbase);  // <= 0 for tiles past the end of a short chunk
+
+    const uint32_t par = iter & 1u;  // which copy of the tile counters this tile uses
+
+    uint32_t pbuf = cur_pbuf;
+    if (!drain) {
+    // ---------------------------------------------------------------- P1 magnitudes
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; i++) {
+        const int g = tid + i * kThreads;
+        if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = FROM_MAG ? make_uint2(pre[i].x, pre[i].y) : mag4_of(pre[i]);
+    }
+    if (t + t_stride < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t + t_stride), tid, pre);
+    ACCT(0);
+    lds_barrier();
+    // every thread is past the previous tile's epilogue: its counters can be zeroed for the next
+    // tile (this tile counts in the other copy), so the tile needs no barrier at its end
+    if (tid == 0) s.nhit[par ^ 1u] = 0;
+    ACCT(1);
+    STAMP(1);
+    if (jn <= 0 || ADSB_STOP_AT(p, 1)) {
+        lds_barrier();
+        continue;
+    }
+
+    // This tile is processed: it gets the other plane buffer (the trials the previous tile left over
+    // still read theirs, and find their tile's position base by it).
+    cur_pbuf = kDefer ? cur_pbuf ^ 1u : 0u;
+    pbuf = cur_pbuf;
+    if (kDefer && tid == 0) {  // (read from the wave-private stages on: two barriers away)
+        s.tile_j[pbuf] = (uint32_t)(jbase - kPad);
+        s.tile_chunk[pbuf] = chunk;
+    }
+
+    // ---------------------------------------------------------------- P2 sign planes
+    // item = (g, kw): residues 4g..4g+3, plane bits k = 8kw..8kw+7, i.e. samples
+    // 12k + 4g + {0..3} (+3 of look-ahead).  Bit k of plane (kind, r) is the sign taken
+    // at sample 12k + r.  Walking k downwards leaves bit (k & 7) of the byte = k.
+    for (int item = tid; item < kItems2; item += kThreads) {
+        constexpr int R = kResPerItem, G = 12 / R;
+        const int g = item % G, kw = item / G;
+        const uint16_t *base = s.mag + 96 * kw + R * g;  // 4-byte aligned (R even)
+        uint32_t acc[6][R];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[q][r] = 0;
+#pragma unroll
+        for (int kk = 8; kk >= 0; --kk) {
+            // m[0 .. R+2]: the R samples of this lane and three of look-ahead.  Explicit
+            // 8-byte reads (the address is 8-byte aligned, no more): left to itself the
+            // compiler merges dword reads into one 16-byte read, and an LDS access off its
+            // natural alignment is replayed at 64 cycles (SQ_LDS_UNALIGNED_STALL).
+            int m[R + 4];
+            if constexpr (R == 4) {
+                const uint2 lo = *(const uint2 *)(base + 12 * kk);
+                const uint2 hi = *(const uint2 *)(base + 12 * kk + 4);
+                m[0] = (int)(lo.x & 0xFFFFu);
+                m[1] = (int)(lo.x >> 16);
+                m[2] = (int)(lo.y & 0xFFFFu);
+                m[3] = (int)(lo.y >> 16);
+                m[4] = (int)(hi.x & 0xFFFFu);
+                m[5] = (int)(hi.x >> 16);
+                m[6] = (int)(hi.y & 0xFFFFu);
+                m[7] = (int)(hi.y >> 16);
+            } else {  // R == 2: 4-byte aligned, three separate dword reads
+                typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+                lds_u32_ptr src = (lds_u32_ptr)(base + 12 * kk);
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const uint32_t w = src[d];
+                    m[2 * d] = (int)(w & 0xFFFFu);
+                    m[2 * d + 1] = (int)(w >> 16);
+                }
+            }
+            int e[R + 2];  // first differences m[s+1] - m[s]
+#pragma unroll
+            for (int i = 0; i < R + 2; i++) e[i] = m[i + 1] - m[i];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int ea = e[r], eb = e[r + 1], ec = e[r + 2];
+                if (kk < 8) {
+                    // slicer value D(ph) at this sample (demod_2400.rs:72-83), negated so that
+                    // "D > 0" is the sign bit: with a = m0-m1 = -e0, b = m1-m2 = -e1, c = m2-m3:
+                    //   D0 = 5a+2b  D1 = 4a+3b  D2 = 3a+4b  D3 = 2a+5b  D4 = a+6b+c
+                    const int n0 = __mul24(ea, 5) + (eb + eb);
+                    const int u = eb - ea;
+                    const int n1 = n0 + u, n2 = n1 + u, n3 = n2 + u;
+                    const int n4 = n3 + u + ec;  // a + 6b + c = (2a + 5b) + (b - a) + c: one add3
+                    acc[0][r] = push_sign(acc[0][r], n0);
+                    acc[1][r] = push_sign(acc[1][r], n1);
+                    acc[2][r] = push_sign(acc[2][r], n2);
+                    acc[3][r] = push_sign(acc[3][r], n3);
+                    acc[4][r] = push_sign(acc[4][r], n4);
+                }
+                // kk == 8 is one plane bit beyond the byte, for GT only: it completes the "advanced
+                // by one bit" copies that P3 addresses as residues 12..23.  There is no "<" plane:
+                // P3 works with "<=" (the complement of ">") and the gates re-check strictness.
+                acc[5][r] = push_sign(acc[5][r], ea);   // GT: m[s] > m[s+1]
+            }
+        }
+        uint8_t *pb = (uint8_t *)s.plane + pbuf * (kPlaneDw * 4);  // this tile's buffer of every row
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int res = R * g + r;
+#pragma unroll
+            for (int q = 0; q < 5; q++) pb[(q * 12 + res) * (kRowDw * 4) + kw] = (uint8_t)acc[q][r];
+            // 9 bits: k = 8kw .. 8kw+8.  Residue res holds bits 0..7, residue res+12 (the
+            // same plane advanced one bit) holds bits 1..8.
+            pb[(kPlaneGT + res) * (kRowDw * 4) + kw] = (uint8_t)acc[5][r];
+            pb[(kPlaneGT + 12 + res) * (kRowDw * 4) + kw] = (uint8_t)(acc[5][r] >> 1);
+        }
+    }
+    ACCT(2);
+    }  // !drain
+    lds_barrier();  // (drain: every thread is past the last tile's epilogue, whose staging area the trials reuse)
+    ACCT(3);
+    STAMP(2);
+    if (ADSB_STOP_AT(p, 2)) continue;
+    // The wave-private stages are chains of LDS round trips with few instructions between them:
+    // at a raised issue priority they get through their dependent steps without queueing behind the
+    // other workgroups' P1 / P2 on the same SIMD, which have instructions to spare for every slot
+    // those chains leave (measured: pipelined -2 %, a launch on its own 105 -> 100 us; levels 1, 2
+    // and 3 alike).  Not on dense streams: there the tail kernels beside the scan are the ones that
+    // must not wait (adsb_aux.hip: TAIL_PRIO), and the step got 3 % longer.
+    if (late_prio) __builtin_amdgcn_s_setprio(ADSB_PRIO_LATE);
+
+    // ================================================================ P3..P5, wave-private
+    // From here to the end of the tile every wave works alone on the positions of its own
+    // P3 items: matches, candidates and trials stay in the wave's own LDS regions, so there
+    // is no workgroup barrier and no shared counter between the stages, the waves of a
+    // workgroup drift apart, and their latency-bound stages overlap the VALU-dense ones of
+    // the others.  Nothing here can overflow: a wave with more matches than its region
+    // holds takes them in rounds of a few plane bits, and the trial stage runs whenever the
+    // ring of candidates could not take another pass of the gates.
+    {
+    // ---------------------------------------------------------------- P3 preamble patterns
+    // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
+    // (with 512 threads an item is half a dword, so that all eight waves own positions)
+    constexpr int kHalves = kThreads / 256;
+    uint32_t b[5] = {0u, 0u, 0u, 0u, 0u};
+    const int ptid = tid % 256, phalf = tid / 256;
+    const int pres = ptid % 12, pw = ptid / 12;
+    if (ptid < kItems3 && !drain) {
+        const int res = pres, w = pw;
+        const uint32_t *GT = s.plane + (kPlaneGT + res) * kRowDw + pbuf * kPlaneDw + w;
+#define GTO(o) GT[(o) * kRowDw]     // p[o] > p[o+1]
+#define LTO(o) (~GT[(o) * kRowDw])  // p[o] <= p[o+1]: a superset of the reference's "<"; the
+                                    // gates test the strict form of the branch they are handed
+        // positions that are real j of this tile: kPad <= slot < kPad + jn
+        // (x + 11) / 12 with a 24-bit multiply (x < 16384), not the 32-bit mul_hi the compiler would use
+        const int kmin = (int)(__umul24((uint32_t)(kPad - res + 11), 10923u) >> 17),
+                  kmax = (int)(__umul24((uint32_t)(kPad + jn - res + 11), 10923u) >> 17);
+        uint32_t ok = lowmask(kmax - 32 * w) & ~lowmask(kmin - 32 * w);
+        if (kHalves == 2) ok &= phalf ? 0xFFFF0000u : 0x0000FFFFu;
+        ok &= LTO(0) & GTO(12);                               // demod_2400.rs:221
+        const uint32_t A = GTO(1) & LTO(2);                   // p1>p2 p2<p3
+        const uint32_t C = LTO(8) & GTO(9);                   // p8<p9 p9>p10
+        const uint32_t E = GTO(4) & LTO(9) & GTO(10) & LTO(11);
+        const uint32_t b1 = ok & A & GTO(3) & C & LTO(10);                    // :227
+        const uint32_t b2 = ok & A & GTO(3) & C & LTO(11) & ~b1;              // :242
+        const uint32_t b3 = ok & A & GTO(4) & LTO(8) & GTO(10) & LTO(11) & ~(b1 | b2);  // :262
+        const uint32_t b4 = ok & GTO(1) & LTO(3) & E & ~(b1 | b2 | b3);       // :280
+        const uint32_t b5 = ok & GTO(2) & LTO(3) & E & ~(b1 | b2 | b3 | b4);  // :300
+#undef LTO
+#undef GTO
+        b[0] = b1;
+        b[1] = b2;
+        b[2] = b3;
+        b[3] = b4;
+        b[4] = b5;
+    }
+    const uint32_t slot0 = (uint32_t)(12 * 32 * pw + pres);
+    const uint32_t any_all = b[0] | b[1] | b[2] | b[3] | b[4];
+    // which branch matched, as three planes of a 3-bit code (0..4), so that compaction is one
+    // loop over the union instead of one per branch
+    const uint32_t code0 = b[1] | b[3], code1 = b[2] | b[3], code2 = b[4];
+    const uint32_t cnt_all = (uint32_t)__popc(any_all);
+    const uint32_t incl_all = wave_inclusive_scan(cnt_all);
+    const uint32_t total_all = (uint32_t)__builtin_amdgcn_readlane((int)incl_all, 63);
+    // all matches in one round when they fit the wave's region (the normal case: ~90 of
+    // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
+    const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
+    if (ADSB_STOP_AT(p, 3)) goto tile_end;  // profiling: patterns only
+
+    // One loop, one copy of each stage: take the next round of matches when the previous one
+    // is used up, run one 64-lane pass of the gates while the ring has room for what it may add,
+    // else one pass of the trials.  Trials run in FULL passes: what a tile leaves over (fewer than
+    // 64, a fifth of a pass's worth of candidates on average) waits in the ring and runs with the
+    // next tile's -- 1.6 passes per tile instead of 2.1 (a tile's ~20 candidates are 100 trials).  The
+    // leftovers are the oldest entries of the ring, so the next tile's first pass takes them all;
+    // a tile with too few candidates of its own to fill that pass runs it short, because the tile
+    // after it overwrites the plane buffer they read.
+    const uint32_t old_trials = pend;  // the previous tile's leftovers (< 64)
+    uint32_t taken = 0;                // trials run during this tile
+    const uint32_t tag = pbuf << 13;
+    int round = 0;
+    uint32_t npat_w = 0, base = 0;
+    bool in_round = false;
+    for (;;) {
+        if (round < nrounds) {
+            if (!in_round) {
+                // ---- compaction of this round's matches into wpat: exclusive scan of the lane
+                // counts (DPP, no LDS traffic), then every lane writes its own
+                const uint32_t rmask = nrounds == 1 ? 0xFFFFFFFFu
+                                                    : (((1u << kRoundBits) - 1u) << (round * kRoundBits));
+                uint32_t cnt = cnt_all, incl = incl_all;
+                npat_w = total_all;
+                if (nrounds != 1) {
+                    cnt = (uint32_t)__popc(any_all & rmask);
+                    incl = wave_inclusive_scan(cnt);
+                    npat_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                if (npat_w == 0) {
+                    round++;
+                    continue;
+                }
+                compact_matches(any_all & rmask, code0, code1, code2, slot0, wpat, incl - cnt);
+                wave_lds_fence();
+                in_round = true;
+                base = 0;
+            }
+            // room in the ring for the 64 candidates a pass of the gates can add (a pending trial
+            // may be the last of its candidate: + 4)
+            if (pend + 5u * 64u + 4u <= (uint32_t)kRingTrials) {
+                // -------------------------------------------------------- P4 value gates
+                // one lane per pattern match (gate_pass)
+                const uint32_t idx = base + (uint32_t)lane;
+                const uint32_t before = c_tail;
+                gate_pass(p, s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, c_tail, jbase, chunk, tag);
+                pend += 5u * (c_tail - before);
+                cand_count += c_tail - before;
+                base += 64;
+                if (base >= npat_w) {
+                    in_round = false;
+                    round++;
+                }
+                continue;
+            }
+        } else if (ADSB_STOP_AT(p, 4)) {  // profiling: gates only
+            pend = 0;
+            t_head = 5u * (c_tail & (uint32_t)(kCandPerWave - 1));
+            break;
+        } else if (pend < 64u && (pend == 0 || (kDefer && !drain && taken >= old_trials))) {
+            break;  // the gates are through, less than a pass is left and none of it is the previous tile's
+        }
+        // ---------------------------------------------------------------- P5 trials
+        // lane = (candidate, try_phase) (trial_pass)
+        wave_lds_fence();  // the candidates the gates wrote
+        {
+            const uint32_t take = min(pend, 64u);
+            uint32_t T = t_head + (uint32_t)lane;
+            T = min(T, T - (uint32_t)kRingTrials);  // mod kRingTrials (unsigned wrap-around)
+            uint32_t c, tpi;
+            split5(T, c, tpi);
+            trial_pass(p, s, cand_entry(wcand[c]), tpi, (uint32_t)lane < take, jbase, chunk, seg, seg_cap, ap_count, lane, par);
+            t_head += take;
+            if (t_head >= (uint32_t)kRingTrials) t_head -= (uint32_t)kRingTrials;
+            pend -= take;
+            taken += take;
+        }
+    }
+    }
+tile_end:
+    if (late_prio) __builtin_amdgcn_s_setprio(0);
+    ACCT(4);
+    lds_barrier();
+    ACCT(5);
+    STAMP(5);
+    if (ADSB_STOP_AT(p, 5)) {
+        lds_barrier();
+        continue;
+    }
+
+    // ---------------------------------------------------------------- tile epilogue
+    // (the AP fill counts are registers; they are written back when the workgroup retires)
+    flush_hits(par);
+    ACCT(6);
+    STAMP(6);
+    }  // tile loop
+#ifdef ADSB_KERNEL_ACCT
+    if (acct && lane == 0)
+        for (int k = 0; k < 8; k++) p.timeline[((size_t)blockIdx.x * kWaves + (tid >> 6)) * 8 + k] = acc_t[k];
+#endif
+    // candidate counts were kept per wave (diagnostic): lane 0 of each wave adds its own
+    if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
+    if (lane == 0) {
+        if (ap_count > seg_cap) atomicOr(&p.ctr->overflow, 2u);
+        p.ctr->seg_ap[my_seg] = min(ap_count, seg_cap);
+    }
+}
+
+inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+// hipGetLastError is sticky across unrelated calls (the caller's too): start every launch clean
+inline void hip_clear() { (void)hipGetLastError(); }
+
+}  // namespace
+
+// persistent grid = what is resident at once (occupancy API x CUs), found once
+int scan_resident_blocks()
+{
+    // (a function-local static: initialised once, also when two threads create contexts at once)
+    static const int resident = [] {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast<false>, kThreads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            per_cu <= 0 || cus <= 0) {
+            per_cu = 2;
+            cus = 256;
+        }
+        int r = per_cu * cus;
+        if (const char *e = tuning_env("ADSB_SCAN_BLOCKS_PER_CU")) r = std::atoi(e) * cus;
+        if (r > kApSegments) r = kApSegments;  // four private AP segments (one per wave) each
+        if (r < 1) r = 1;
+        if (tuning_env("ADSB_TIMELINE"))
+            std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
+        return r;
+    }();
+    return resident;
+}
+
+int launch_scan(const ScanParams &p, bool from_mag, void *stream)
+{
+    hip_clear();
+    const uint32_t tiles = p.n_chunks * kTilesPerChunk;
+    if (tiles == 0) return 0;
+    const int resident = scan_resident_blocks();
+    const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
+    // With events, the launch itself carries them (hipExtLaunchKernelGGL): the dispatch
+    // packet's own begin/end timestamps, no barrier packets in the stream around it.
+    if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
+        hipLaunchKernelGGL(k_scan_fast<true>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else if (p.ev_start && p.ev_stop)
+        hipExtLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                              (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
+    else
+        hipLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
+}
+
+}  // namespace adsb
