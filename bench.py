@@ -62,6 +62,10 @@ def parse(argv=None):
                          "demodulator's throughput is what it sustains, not what the first 25 passes after "
                          "idling make; 0 = none.  Reported under config.clock_ramp with the cold step time.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="leave the rank's CPU affinity alone (default: the cores of its GPU's NUMA node, from sysfs)")
+    ap.add_argument("--stream-seconds", type=float, default=10.0,
+                    help="--workload stream and the config-3 leg: run at least this long at the headline slot size")
     ap.add_argument("--no-also", action="store_true", help="skip the short legs for BASELINE configs 1, 3 and 5")
     ap.add_argument("--timed-profiling", type=int, default=1,
                     help="HIP-event level inside the timed region (1 = scan kernel stamped by its "
@@ -132,6 +136,14 @@ class Env:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # Before anything touches the GPU: this rank onto the cores of its GPU's NUMA node (a step is
+        # ~60 us of HIP calls on one host thread out of ~95; eight ranks left to the scheduler on a
+        # two-socket box contend and cross the socket link).  Reads sysfs only.
+        from dump1090_rs_amd import sharding
+        self.cpus_before = sorted(os.sched_getaffinity(0))
+        self.affinity = None
+        if not args.no_pin:
+            self.affinity = sharding.pin_to_gpu_numa_node(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world))))
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a GPU: the demod_2400 path has no CPU fallback")
         # (ADSB_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than
@@ -172,6 +184,37 @@ class Env:
             return elapsed, frames
         from dump1090_rs_amd import sharding
         return sharding.reduce_timing(self.dist, elapsed, frames, device=self.reduce_device)
+
+    def gather(self, value: float):
+        """One float per rank, on every rank (per-rank step times: a straggler must not hide behind the MAX)."""
+        if self.dist is None:
+            return [value]
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.reduce_device)
+        out = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.reduce_device)
+        self.dist.all_gather_into_tensor(out, t)
+        return [float(x) for x in out.cpu().tolist()]
+
+    def all_cores(self):
+        """Context manager: the affinity this process started with (the CPU baseline uses every core)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            now = os.sched_getaffinity(0)
+            try:
+                os.sched_setaffinity(0, self.cpus_before)
+                yield
+            finally:
+                os.sched_setaffinity(0, now)
+        return cm()
+
+    def affinity_summary(self):
+        a = self.affinity
+        if not a:
+            return None
+        return {"numa_node": a["numa_node"], "cpus": len(a["cpus"]), "first_cpu": a["cpus"][0] if a["cpus"] else None,
+                "cpus_before": a["cpus_before"], "ranks_on_node": a["ranks_on_node"], "gpu": a["gpu"],
+                "applied": a["applied"], "source": a["source"]}
 
     def finish(self):
         if self.dist is not None:
@@ -297,9 +340,10 @@ def clock_ramp(env: Env, args, run) -> dict:
     return out
 
 
-def parity_leg(r, chunks: int):
-    """CPU baseline on buffer 0 (the C restatement of the reference, 1 thread and all threads) and
-    the parity gate: the GPU frame list for that buffer must be identical."""
+def parity_leg(env: Env, r, chunks: int, baseline: bool = True):
+    """The parity gate -- the GPU frame list of buffer 0 must be identical to the CPU oracle's -- and,
+    with `baseline`, the CPU baseline on that buffer (the C restatement of the reference, 1 thread and
+    all threads, built -O3 -march=native on this box for the timing)."""
     from oracle import binding
     ctx, bufs, n, cap = r["ctx"], r["bufs"], r["n"], r["cap"]
     host = bufs[0].cpu().numpy()
@@ -308,36 +352,69 @@ def parity_leg(r, chunks: int):
     c0 = time.perf_counter()
     want, _ = orc.demod_iq(host, cap=cap)
     cpu_s = time.perf_counter() - c0
-    n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), chunks))
-    mt_s = None
-    if n_thr > 1:
-        orc_mt = binding.Oracle()
-        orc_mt.icao_flush()
-        orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
-        orc_mt.icao_flush()
-        c0 = time.perf_counter()
-        want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr)
-        mt_s = time.perf_counter() - c0
-        if want_mt != want:
-            raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
     ctx.icao_flush()
     got = ctx.demod_iq_device(bufs[0].data_ptr(), n, cap=cap)
+    same = _same(got, want)
+    if not baseline:
+        return None, same, len(want)
+    built = "-O3 -march=x86-64-v3 (the checker's own build)"
+    native = binding.build_native()
+    L = None
+    if native is not None:
+        L = binding.load(native)
+        t = binding.Oracle(L)
+        t.icao_flush()
+        c0 = time.perf_counter()
+        want_n, _ = t.demod_iq(host, cap=cap)
+        native_s = time.perf_counter() - c0
+        if want_n != want:
+            raise SystemExit("cpu_baseline: the -march=native build of the oracle disagrees with the checker's build")
+        cpu_s, built = native_s, "-O3 -march=native on this box"
+    mt_s, n_thr = None, 1
+    with env.all_cores():   # (the rank itself is pinned to its GPU's NUMA node; the baseline gets the whole box)
+        n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), chunks))
+        if n_thr > 1:
+            orc_mt = binding.Oracle(L)
+            orc_mt.icao_flush()
+            orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
+            orc_mt.icao_flush()
+            c0 = time.perf_counter()
+            want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr)
+            mt_s = time.perf_counter() - c0
+            if want_mt != want:
+                raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
     base = {
         "value": round(n / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": f"buffer 0 of the workload, all {chunks} x 131072 samples once, {cpu_s:.2f} s; "
-                  "C restatement of dump1090_rs (oracle/), not the Rust binary",
+                  f"C restatement of dump1090_rs (oracle/), not the Rust binary; built {built}",
         "cpu": _cpu_model(), "host_cores_available": os.cpu_count(),
     }
     if mt_s:
         base["all_cores"] = {"value": round(n / mt_s / 1e6, 2), "unit": "Msamples/s", "cores": n_thr,
                              "sample": f"the same buffer, {n_thr} threads over the 131072-sample buffers + "
                                        f"ordered replay, {mt_s:.2f} s"}
-    return base, _same(got, want), len(want)
+    if native is not None:
+        try:
+            os.unlink(native)
+        except OSError:
+            pass
+    return base, same, len(want)
+
+
+def _profile_json(name: str, library: str, chunks: int):
+    """A committed measurement under profiles/ for THIS library build and workload size, or None."""
+    f = ROOT / "profiles" / name
+    try:
+        d = json.loads(f.read_text())
+    except (OSError, ValueError):
+        return None
+    return d if d.get("library") == library and d.get("chunks", chunks) == chunks else None
 
 
 def resident_result(env: Env, args, r, workload: str):
     from dump1090_rs_amd import _lib
     n, steps = r["n"], args.steps
+    per_rank_ms = env.gather(r["elapsed"] / steps * 1e3)
     elapsed, frames = env.reduce(r["elapsed"], r["frames"])
     tot, tot2 = r["tot"], r["tot2"] or r["tot"]
     own_ms = tot["ms_scan"] / steps
@@ -346,9 +423,18 @@ def resident_result(env: Env, args, r, workload: str):
     # runs): a launch's own start-to-stop time then counts the shared stretch twice.  The device time
     # per launch is the union of the launches' intervals / launches = ms_scan_exclusive.
     excl_ms = tot["ms_scan_exclusive"] / steps
-    kernel_ms = own_ms if args.sync else excl_ms
-    achieved = BYTES_PER_SAMPLE * n / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else 0.0
+    # roofline.achieved = algorithmic bytes per launch / the kernel's average launch duration, where a
+    # launch's duration is its own: launches that do NOT overlap (blocking calls), measured here with the
+    # HIP events the launch stamps on its stream -- the figure `rocprofv3 --kernel-trace --stats` gives
+    # for `bench.py --sync` (profiles/*_sync_kernel_stats.csv).  The pipelined figures (what a stream
+    # sustains) are under roofline.sustained.
+    alone_ms = own_ms if args.sync else r.get("alone_ms")
+    kernel_ms = alone_ms if alone_ms else excl_ms
+    algo = BYTES_PER_SAMPLE * n
+    gbs = lambda ms: algo / (ms / 1e3) / 1e9 if ms and ms > 0 else 0.0
+    achieved = gbs(kernel_ms)
     iv = r["intervals"]
+    library = _lib.lib().adsb_version().decode()
     result = {
         "metric": "IQ Msamples/s demodulated",
         "value": round(n * steps * env.world / elapsed / 1e6, 1),
@@ -366,6 +452,9 @@ def resident_result(env: Env, args, r, workload: str):
         "data": "synthetic",
         "frames_per_s": round(frames / elapsed, 1),
         "frames_per_step": frames // max(1, steps * env.world),
+        "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+        "backend": env.backend if env.world > 1 else None,
+        "world_size_seen": env.world,
         "config": {
             "workload": f"{args.chunks} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB synthetic 2.4 MSPS "
                         f"i16 IQ resident in HBM, {r['n_bursts']} injected Mode-S bursts ({workload}); a step = one "
@@ -377,7 +466,8 @@ def resident_result(env: Env, args, r, workload: str):
                         f"adsb_submit_iq_device / adsb_collect, {r['depth']} passes in flight",
             "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_match -> "
                        "k_order_prefix -> k_records (bucket sort) -> host replay, or k_score -> k_emit on dense streams",
-            "library": _lib.lib().adsb_version().decode(),
+            "library": library,
+            "host_affinity": env.affinity_summary(),
             "clock_ramp": {**r["ramp"], "what": "untimed passes of this workload before the W warm-up steps, until the "
                            "GPU holds its clocks under the load (bench.py: clock_ramp); ms_per_step_cold = the first 20 "
                            "of them, i.e. what a run without the ramp reports"},
@@ -391,33 +481,48 @@ def resident_result(env: Env, args, r, workload: str):
             "traffic": None,
             "kernel": "k_scan_fast",
             "kernel_avg_ms": round(kernel_ms, 4),
-            "kernel_avg_ms_is": "launch start -> stop (launches do not overlap)" if args.sync else
-                                "device time per launch: union of the overlapping launches' intervals / launches "
-                                "(HIP events stamped by the launches; adsb_stats.ms_scan_exclusive)",
-            "kernel_own_duration_avg_ms": round(own_ms, 4),
-            "kernel_alone_avg_ms": round(r["alone_ms"], 4) if r.get("alone_ms") else None,
-            "frac_alone": round(BYTES_PER_SAMPLE * n / (r["alone_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if r.get("alone_ms") else None,
-            "kernel_alone_is": "the same steps once more, untimed, with blocking calls: launches do not overlap, so a "
-                               "launch's start-to-stop time is the kernel alone (profiles/*_sync_kernel_stats.csv)",
-            "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+            "kernel_avg_ms_is": "a launch's own start -> stop with blocking calls (launches do not overlap), HIP events "
+                                "stamped by the launch on its stream" + ("" if args.sync else
+                                ": the same steps once more after the timed region, untimed") +
+                                "; what rocprofv3 --kernel-trace --stats shows for `bench.py --sync` "
+                                "(profiles/*_sync_kernel_stats.csv)" if alone_ms else
+                                "device time per launch: union of the overlapping launches' intervals / launches",
+            "algorithmic_bytes_per_launch": algo,
+            "launches_overlap_in_timed_region": not args.sync,
+            "sustained": {
+                "is": "what the pipelined stream of the timed region sustains (consecutive launches overlap on two streams)",
+                "achieved_over_steps": round(algo * steps / r["elapsed"] / 1e9, 1),
+                "frac_over_steps": round(algo * steps / r["elapsed"] / 1e9 / HBM_PEAK_GBS, 4),
+                "device_ms_per_launch": round(excl_ms, 4),
+                "device_ms_per_launch_is": "union of the overlapping launches' intervals / launches "
+                                           "(adsb_stats.ms_scan_exclusive, HIP events stamped by the launches)",
+                "frac_device": round(gbs(excl_ms) / HBM_PEAK_GBS, 4),
+                "launch_own_duration_avg_ms": round(own_ms, 4),
+            },
             "other_kernels_avg_ms": {"k_match_and_order": round(tot2["ms_match"] / steps, 4),
                                      "k_records": round(tot2["ms_records"] / steps, 4)},
             "device_chain_avg_ms": round(tot2["ms_total_device"] / steps, 4),
-            "launches_overlap": not args.sync,
-            "achieved_over_steps": round(BYTES_PER_SAMPLE * n * steps / r["elapsed"] / 1e9, 1),
         },
         "device_stats_last_step": {k: r["stats"][k] for k in
                                    ("n_candidates", "n_ap_entries", "n_records", "n_messages", "retries")},
     }
-    traffic_file = ROOT / "profiles" / "scan_hbm_traffic.json"
-    if traffic_file.exists():
-        try:
-            tf = json.loads(traffic_file.read_text())
-            if tf.get("library") == result["config"]["library"] and tf.get("chunks") == args.chunks:
-                result["roofline"]["traffic"] = tf.get("bytes_per_launch")
-                result["roofline"]["traffic_source"] = tf.get("source")
-        except Exception:
-            pass
+    # Not measured in this run: counter passes cannot share a process with the timing.  Both come from
+    # files committed under profiles/ for exactly this library build (PMC passes, tools/traffic.sh and
+    # tools/sq_counters.py) and say so.
+    tf = _profile_json("scan_hbm_traffic.json", library, args.chunks)
+    if tf:
+        result["roofline"]["traffic"] = tf.get("bytes_per_launch")
+        result["roofline"]["traffic_source"] = ("read from profiles/scan_hbm_traffic.json (not measured in this run): "
+                                                + str(tf.get("source")))
+    sq = _profile_json("scan_sq_counters.json", library, args.chunks)
+    if sq and sq.get("valu_roofline"):
+        v = sq["valu_roofline"]
+        result["roofline"]["valu"] = {
+            "wave_insts": v["wave_insts"], "cycles_per_inst": v["busy_clocks_per_inst"],
+            "simd_cycles_available": v["simd_cycles_available"], "frac": v["frac"],
+            "is": v.get("is"), "wave_cycle_split": v.get("wave_cycle_split"),
+            "source": "read from profiles/scan_sq_counters.json (rocprofv3 --pmc passes over `bench.py --sync` of this "
+                      "library build, tools/sq_counters.py; not measured in this run)"}
     return result
 
 
@@ -517,16 +622,46 @@ def stream_result(env: Env, args, s):
     }
 
 
+def config3_leg(env: Env, args):
+    """BASELINE config 3 as written -- a ring of 512 KB chunks, one read and one demodulation at a time
+    (the reference's call shape, dump1090_rs/src/main.rs:161-167) -- next to larger slots: the ring at
+    1, 4, 16 and 64 buffers per slot, the headline size (64 = 32 MiB) for --stream-seconds (>= 10 s,
+    SURVEY 8d), the others for a quarter of that; every size checked against one oracle stream."""
+    sweep = []
+    for chunks in (1, 4, 16, 64):
+        secs = args.stream_seconds if chunks == 64 else max(1.0, args.stream_seconds / 4)
+        s = run_stream(env, chunks, 50, 3, min_seconds=secs, check=True)
+        sr = stream_result(env, args, s)
+        sweep.append({"buffers_per_slot": chunks, "slot_MiB": chunks * CHUNK * 4 / (1 << 20), "value": sr["value"],
+                      "unit": "Msamples/s", "seconds": round(s["elapsed"], 2), "steps": s["steps"],
+                      "ms_per_slot": sr["ms_per_step"], "h2d_GBps": sr["config"]["h2d_GBps"],
+                      "frames_per_s": sr["frames_per_s"], "parity_checked": s["parity"]})
+    head = sweep[-1]
+    return {"workload": "streaming ring (adsb_ring_*: pinned host slots, hipMemcpyAsync on a copy stream, three passes "
+                        "in flight), host-resident IQ, H2D inside the timed region (BASELINE config 3)",
+            "value": head["value"], "unit": "Msamples/s", "seconds": head["seconds"], "steps": head["steps"],
+            "ms_per_step": head["ms_per_slot"], "h2d_GBps": head["h2d_GBps"],
+            "value_512KB_slots": sweep[0]["value"],
+            "parity_checked": all(x["parity_checked"] for x in sweep),
+            "slot_sweep": sweep,
+            "note": "PCIe-inclusive (host-resident IQ): never the headline value.  One 512 KB buffer per slot is the "
+                    "reference's own call shape and is latency-bound (one pass = one launch chain per 131072 samples); "
+                    "larger slots amortise it until the PCIe link bounds the stream"}
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE config 4: one capture cut into contiguous buffer ranges, one per GPU
 # ------------------------------------------------------------------------------------------------
 def run_shard(env: Env, args):
     """ONE capture of world x --chunks buffers; rank r owns buffers [r*chunks, (r+1)*chunks).  A step =
     icao_flush + adsb_shard_scan on every rank, a host-side exchange of the addresses the shards
-    learned (a few KB, two tensor all-gathers: the one real exchange step), adsb_shard_finish, the trial records
-    gathered on rank 0 and replayed once in global (buffer, j, try_phase) order: the reference's loop
-    dump1090_rs/src/main.rs:161-167 over the whole capture.  Checked: the merged frame list equals
-    the single-stream result of rank 0 demodulating the whole capture alone."""
+    learned (a few KB over a gloo group: the one real exchange step, and it goes through the host --
+    no RCCL collective on the data path), adsb_shard_finish, the trial records gathered on rank 0 and
+    replayed once in global (buffer, j, try_phase) order: the reference's loop
+    dump1090_rs/src/main.rs:161-167 over the whole capture.  The second half of step i (finish, gather,
+    replay) runs on a worker thread while the main thread scans step i + 1 on a second context
+    (sharding.ShardPipeline).  Checked: the merged frame list equals the single-stream result of rank 0
+    demodulating the whole capture alone."""
     torch = env.torch
     from dump1090_rs_amd import Context, sharding, synth, _lib
 
@@ -538,27 +673,49 @@ def run_shard(env: Env, args):
 
     mine = shard_iq(env.rank, env.dev)
     torch.cuda.synchronize()
-    ctx = Context(device=env.local_rank, max_chunks=args.chunks)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # (each context on its own stream: the worker thread's finish must not wait for the other context's scan)
+    ctxs = [Context(device=env.local_rank, max_chunks=args.chunks) for _ in range(2)]
+    base = env.rank * args.chunks
 
-    def step():
-        ctx.icao_flush()
-        return sharding.demod_sharded(ctx, mine.data_ptr(), n, env.rank * args.chunks, env.dist)
+    def blocking_step():
+        ctxs[0].icao_flush()
+        return sharding.demod_sharded(ctxs[0], mine.data_ptr(), n, base, env.dist)
 
-    ramp = clock_ramp(env, args, lambda first, count: [step() for _ in range(count)])
-    for _ in range(args.warmup):
-        step()
+    # the two blocking phases, one step at a time (what round 2 timed): for comparison, and as the ramp
+    ramp = clock_ramp(env, args, lambda first, count: [blocking_step() for _ in range(count)])
     env.fence()
     t0 = time.perf_counter()
-    frames = 0
-    stamps = []
     for _ in range(args.steps):
-        msgs = step()
-        frames += len(msgs) if msgs is not None else 0
-        stamps.append(time.perf_counter())
+        blocking_step()
+    env.fence()
+    blocking_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
+    # Overlapping the two halves of consecutive steps pays when there is an exchange to hide (N > 1:
+    # 0.79 vs 0.87 ms with two gloo ranks on one GPU); at N = 1 the hand-over to the worker thread costs
+    # more than it hides (0.37 vs 0.31 ms), so a single rank keeps the blocking form.
+    overlapped = env.world > 1
+    pipe = sharding.ShardPipeline(ctxs, env.dist)
+    for _ in range(max(2, args.warmup)):
+        pipe.submit(mine.data_ptr(), n, base)
+    pipe.drain()
+    env.fence()
+    t0 = time.perf_counter()
+    frames, results = 0, 0
+    for _ in range(args.steps):
+        out = pipe.submit(mine.data_ptr(), n, base) if overlapped else blocking_step()
+        if out is not None:
+            frames += len(out)
+            results += 1
+    for out in pipe.drain():
+        if out is not None:
+            frames += len(out)
+            results += 1
     env.fence()
     elapsed = time.perf_counter() - t0
-    merged = step()
+    per_rank_ms = env.gather(elapsed / args.steps * 1e3)
+    pipe.submit(mine.data_ptr(), n, base)
+    merged = pipe.drain()[-1]       # (checked below: the overlapped form's result, whichever form was timed)
+    pipe.close()
     # the single-stream answer: rank 0 demodulates the whole capture alone (untimed)
     same, n_frames = None, None
     if env.rank == 0:
@@ -567,16 +724,17 @@ def run_shard(env: Env, args):
             solo.icao_flush()
             want = solo.demod_iq_device(whole.data_ptr(), n * env.world, cap=1 << 20)
         key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
-        same = [key(m) for m in merged] == [key(m) for m in want]
+        same = [key(m) for m in merged] == [key(m) for m in want] and results == args.steps
         n_frames = len(want)
         del whole
     elapsed, frames = env.reduce(elapsed, frames)
-    iv = [b - a for a, b in zip(stamps, stamps[1:])]
     result = {
         "metric": "IQ Msamples/s demodulated", "value": round(n * env.world * args.steps / elapsed / 1e6, 1),
         "unit": "Msamples/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "ms_per_step_median": round(_median(iv) * 1e3, 4) if iv else None,
+        "ms_per_step_two_blocking_phases": round(env.reduce(blocking_ms / 1e3, 0)[0] * 1e3, 4),
+        "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+        "backend": env.backend if env.world > 1 else None, "world_size_seen": env.world,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "frames_per_s": round(frames / elapsed, 1),
         "config": {"workload": f"one capture of {env.world} x {args.chunks} buffers = {env.world * n * 4 // (1 << 20)} MiB "
@@ -585,13 +743,19 @@ def run_shard(env: Env, args):
                                "exchange of learned addresses + match + records gathered and replayed once on rank 0",
                    "per_gpu_samples_per_step": n,
                    "sharding": "contiguous buffer ranges, the IQ never moves; learned addresses and trial records "
-                               "exchanged with fixed-size tensor all-gathers (RCCL, or gloo)",
-                   "host_api": "adsb_shard_scan / adsb_shard_finish / adsb_replay_records (blocking, two phases)",
+                               "exchanged as host tensors over gloo groups (no RCCL collective on the data path; "
+                               "torch.distributed's default group only carries the barrier and the timing reduction)",
+                   "host_api": "adsb_shard_scan / adsb_shard_finish / adsb_replay_records; " +
+                               ("finish + gather + replay of step i on a worker thread beside the scan of step i + 1 "
+                                "(two contexts, sharding.ShardPipeline)" if overlapped else
+                                "two blocking phases per step (a single rank has no exchange to hide)"),
                    "library": _lib.lib().adsb_version().decode(),
+                   "host_affinity": env.affinity_summary(),
                    "clock_ramp": ramp},
         "shard_merge_equals_single_stream": same, "parity_frames": n_frames,
     }
-    ctx.close()
+    for c in ctxs:
+        c.close()
     return result
 
 
@@ -688,14 +852,20 @@ def main():
 
     if args.workload == "stream":
         chunks = args.chunks if args.chunks != 512 else 64
-        result = stream_result(env, args, run_stream(env, chunks, args.steps, args.warmup))
+        s = run_stream(env, chunks, args.steps, args.warmup, min_seconds=args.stream_seconds, check=env.rank == 0)
+        result = stream_result(env, args, s)
+        result["parity_checked"] = s["parity"]
     elif args.workload == "shard":
         result = run_shard(env, args)
     else:
         r = run_resident(env, args, args.workload, args.steps, args.warmup)
         result = resident_result(env, args, r, args.workload)
-        if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"], same, n_frames = parity_leg(r, args.chunks)
+        if env.rank == 0 and not args.no_cpu_baseline:
+            # N = 1: the CPU baseline beside the line; N > 1: the parity gate alone (rank 0's buffer 0
+            # against the oracle), so that the line verifies itself wherever the driver runs it
+            base, same, n_frames = parity_leg(env, r, args.chunks, baseline=env.world == 1)
+            if base is not None:
+                result["cpu_baseline"] = base
             result["parity_checked"] = bool(same)
             result["parity_frames"] = n_frames
             if not same:
@@ -706,20 +876,15 @@ def main():
         if env.rank == 0 and env.world == 1 and not args.no_also and not args.sync and args.workload == "sparse":
             also = {}
             also["config1_cargo_bench_case"] = run_config1(env)
-            s = run_stream(env, 64, 200, 3, min_seconds=2.0, check=True)
-            sr = stream_result(env, args, s)
-            also["config3_streaming_ring"] = {
-                "workload": sr["config"]["workload"], "value": sr["value"], "unit": "Msamples/s",
-                "seconds": round(s["elapsed"], 2), "steps": s["steps"], "ms_per_step": sr["ms_per_step"],
-                "h2d_GBps": sr["config"]["h2d_GBps"], "parity_checked": s["parity"],
-                "note": "PCIe-inclusive (host-resident IQ): never the headline value"}
+            also["config3_streaming_ring"] = config3_leg(env, args)
             d = run_resident(env, args, "dense", args.steps, args.warmup, level2=False)
             dr = resident_result(env, args, d, "dense")
-            _, dsame, dframes = parity_leg(d, args.chunks) if not args.no_cpu_baseline else (None, None, None)
+            _, dsame, dframes = parity_leg(env, d, args.chunks, baseline=False) if not args.no_cpu_baseline else (None, None, None)
             also["config5_dense"] = {
                 "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
                 "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
                 "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
+                "device_ms_per_launch": dr["roofline"]["sustained"]["device_ms_per_launch"],
                 "n_records_last_step": dr["device_stats_last_step"]["n_records"],
                 "parity_checked": dsame, "parity_frames": dframes}
             d["ctx"].close()

@@ -42,12 +42,39 @@ def build(force: bool = False) -> Path:
 _lib = None
 
 
+def build_native() -> Optional[Path]:
+    """The same sources with -march=native, into a scratch directory: for TIMING the CPU baseline on
+    the box it runs on (SURVEY 8d asks for -O3 -march=native; the tree's liboracle.so is x86-64-v3 so
+    that one build runs on every box and stays the checker).  None when it cannot be built."""
+    import tempfile
+    out = Path(tempfile.gettempdir()) / f"liboracle_native_{__import__('os').getpid()}.so"
+    cmd = ["gcc", "-O3", "-march=native", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fno-math-errno", "-fPIC",
+           "-pthread", "-shared", "-o", str(out), str(HERE / "dump1090_oracle.c"), str(HERE / "dump1090_oracle_mt.c"), "-lm"]
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+    except (OSError, subprocess.SubprocessError):
+        return None
+    return out
+
+
+def load(path: Path) -> C.CDLL:
+    """A second instance of the oracle library (build_native), prototypes set like lib()'s."""
+    return _bind(C.CDLL(str(path)))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not LIB_PATH.exists():
             build()
-        L = C.CDLL(str(LIB_PATH))
+        _lib = _bind(C.CDLL(str(LIB_PATH)))
+    return _lib
+
+
+def _bind(L: C.CDLL) -> C.CDLL:
+    if True:
+        if True:
+            pass
         vp, sz = C.c_void_p, C.c_size_t
         L.orc_icao_flush.argtypes = [vp]
         L.orc_icao_hash.argtypes = [C.c_uint32]
@@ -85,8 +112,7 @@ def lib() -> C.CDLL:
         L.orc_mag_x_digest.restype = C.c_uint64
         L.orc_all_trials.argtypes = [vp, C.c_uint64, vp, sz]
         L.orc_all_trials.restype = sz
-        _lib = L
-    return _lib
+    return L
 
 
 def as_iq(iq) -> np.ndarray:
@@ -97,8 +123,8 @@ def as_iq(iq) -> np.ndarray:
 class Oracle:
     """One stream of the reference algorithm on the CPU (own ICAO filter)."""
 
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, L: Optional[C.CDLL] = None):
+        self.L = L if L is not None else lib()
         self.filter = OrcFilter()
 
     def icao_flush(self) -> None:

@@ -211,3 +211,110 @@ def test_bench_parent_process_never_imports_torch_before_launching():
             "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+# --- world size 4, uneven ranges; the exchange over the host group; core affinity -----------------
+def _ws4_worker(rank, world, port, n_chunks, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from dump1090_rs_amd.context import TRIAL_DTYPE
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        a, b = sharding.chunk_range(n_chunks, world, rank)
+        # a rank's "learned addresses" and "trial records": sized by its (uneven) range, rank 3's empty
+        mine = np.arange(a, b, dtype=np.uint32) * 7 + 1 if rank != 3 else np.zeros(0, np.uint32)
+        recs = np.zeros(3 * (b - a) if rank != 3 else 0, dtype=TRIAL_DTYPE)
+        recs["chunk"] = np.repeat(np.arange(b - a, dtype=np.uint32), 3)[: len(recs)]
+        recs["j_tp"] = (rank + 1) * 1000 + np.arange(len(recs), dtype=np.uint32)
+        group = sharding.host_group(dist)
+        union = sharding.exchange_addresses(dist, mine)
+        merged = sharding.gather_records(dist, recs, a)
+        # the same over two private groups, from two threads at once (what ShardPipeline does)
+        import threading
+        g1, g2 = dist.new_group(backend="gloo"), dist.new_group(backend="gloo")
+        box = {}
+        th = threading.Thread(target=lambda: box.__setitem__("m", sharding.gather_records(dist, recs, a, g2)))
+        th.start()
+        u2 = sharding.exchange_addresses(dist, mine, g1)
+        th.join()
+        elapsed, frames = sharding.reduce_timing(dist, 0.1 * (rank + 1), b - a)
+        q.put((rank, (a, b), union.tolist(), None if merged is None else
+               [(int(r["chunk"]), int(r["j_tp"])) for r in merged], u2.tolist() == union.tolist(),
+               (box["m"] is None) == (merged is None) and (merged is None or bool((box["m"] == merged).all())),
+               group is not None, elapsed, frames))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_ranges_exchange_over_the_host_group():
+    """World size 4 over 10 buffers (3, 3, 2, 2), one rank with nothing to contribute: the address union
+    and the record gather (fixed-size host-tensor all-gathers over a gloo group) give every rank the
+    same union and rank 0 all records re-based to global buffer numbers, also when the two exchanges run
+    from two threads over two groups as ShardPipeline issues them."""
+    import torch.multiprocessing as mp
+    world, n_chunks = 4, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ws4_worker, args=(r, world, port, n_chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    want_union = sorted(int(c) * 7 + 1 for c in range(0, 8))          # rank 3 contributed none
+    assert all(g[2] == want_union for g in got)
+    assert all(g[3] is None for g in got[1:])
+    merged = got[0][3]
+    assert len(merged) == 3 * 8
+    # re-based: rank 1's local buffers 0..2 are global 3..5, rank 2's 0..1 are 6..7
+    assert [c for c, _ in merged] == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3 + [4] * 3 + [5] * 3 + [6] * 3 + [7] * 3
+    assert [jt // 1000 for _, jt in merged] == [1] * 9 + [2] * 9 + [3] * 6
+    assert all(g[4] and g[5] and g[6] for g in got)
+    assert all(abs(g[7] - 0.4) < 1e-12 and g[8] == n_chunks for g in got)
+
+
+def test_rank_affinity_plan_follows_the_gpus_numa_nodes(tmp_path):
+    """plan_affinity / gpu_numa_nodes on a fake sysfs: eight GPUs on two NUMA nodes, ranks get disjoint
+    quarters of their node's cores; HIP_VISIBLE_DEVICES reorders; unknown topology falls back to an even split."""
+    sysfs = tmp_path / "sys"
+    for i in range(8):
+        d = sysfs / "devices" / "pci0000:00" / f"0000:{0x10 + 0x10 * i:02x}:00.0"
+        d.mkdir(parents=True)
+        (d / "vendor").write_text("0x1002\n")
+        (d / "class").write_text("0x120000\n")
+        (d / "numa_node").write_text(f"{0 if i < 4 else 1}\n")
+        card = sysfs / "class" / "drm" / f"card{7 - i}"          # card numbers do not follow PCI order
+        card.mkdir(parents=True)
+        (card / "device").symlink_to(d)
+    other = sysfs / "devices" / "pci0000:00" / "0000:05:00.0"     # another vendor's display controller
+    other.mkdir(parents=True)
+    (other / "vendor").write_text("0x1a03\n")
+    (other / "class").write_text("0x030000\n")
+    (other / "numa_node").write_text("0\n")
+    c8 = sysfs / "class" / "drm" / "card8"
+    c8.mkdir(parents=True)
+    (c8 / "device").symlink_to(other)
+    gpus = sharding.gpu_numa_nodes(str(sysfs))
+    assert [n for _, n in gpus] == [0, 0, 0, 0, 1, 1, 1, 1] and gpus[0][0] == "0000:10:00.0"
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    plans = [sharding.plan_affinity(r, 8, gpus, node_cpus, range(256)) for r in range(8)]
+    assert [p["numa_node"] for p in plans] == [0] * 4 + [1] * 4
+    assert all(len(p["cpus"]) == 32 for p in plans)
+    assert set().union(*[set(p["cpus"]) for p in plans[:4]]) == set(node_cpus[0])
+    assert not set(plans[0]["cpus"]) & set(plans[1]["cpus"]) and not set(plans[4]["cpus"]) & set(node_cpus[0])
+    # a restricted starting affinity is respected; a reordering *_VISIBLE_DEVICES maps rank -> physical GPU
+    p = sharding.plan_affinity(0, 2, gpus, node_cpus, range(0, 16), visible=[5, 1])
+    assert p["numa_node"] == 1 and p["source"].startswith("no NUMA") and len(p["cpus"]) == 8   # node 1 has none of 0..15
+    p = sharding.plan_affinity(1, 2, gpus, node_cpus, range(0, 16), visible=[5, 1])
+    assert p["numa_node"] == 0 and p["cpus"] == list(range(0, 16)) and p["gpu"] == "0000:20:00.0"
+    assert sharding.visible_devices({"HIP_VISIBLE_DEVICES": "3,1"}) == [3, 1]
+    assert sharding.visible_devices({"ROCR_VISIBLE_DEVICES": "GPU-abc"}) is None and sharding.visible_devices({}) is None
+    # no sysfs at all: even split of what the process may run on
+    p = sharding.plan_affinity(2, 4, [], {}, range(8))
+    assert p["cpus"] == [4, 5] and p["numa_node"] == -1
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and sharding.parse_cpulist("") == []

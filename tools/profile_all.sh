@@ -5,6 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }; T=$1; cd $R
 ./tools/profile_round.sh $T
 ./tools/profile_sync.sh $T
+python3 tools/sq_counters.py sq_$T > gpurun_out/sq_$T.log 2>&1; tail -12 gpurun_out/sq_$T.log | head -8
 for w in dense stream shard; do
   timeout 600 python bench.py --workload $w --no-also > gpurun_out/bench_${w}_$T.json 2> gpurun_out/bench_${w}_$T.err
   tail -1 gpurun_out/bench_${w}_$T.json | cut -c1-200

@@ -39,3 +39,8 @@ out = {"library": lib, "chunks": 512, "bytes_per_launch": int(fetch + write), "f
                  "WRITE_SIZE x 1024 uncalibrated"}
 (R / 'profiles/scan_hbm_traffic.json').write_text(json.dumps(out, indent=1) + '\n')
 print(out['bytes_per_launch'], lib)
+sq = R / f'gpurun_out/sq_{tag}/sq_counters.json'   # tools/sq_counters.py sq_<tag>
+if sq.exists():
+    (R / f'profiles/{name}_sq_counters.json').write_text(sq.read_text())
+    (R / 'profiles/scan_sq_counters.json').write_text(sq.read_text())
+    print('sq counters', json.loads(sq.read_text()).get('valu_roofline', {}).get('frac'))

@@ -66,11 +66,14 @@ def main():
         bench_args.insert(0, "--sync")
     per_dispatch = collections.defaultdict(dict)  # (pass, dispatch id) -> counter -> value
     grid, dur_ns = {}, {}
+    library = None
     lines = []
     for k, counters in enumerate(PASSES):
         rows, line, rc = run_pass(tag, k, counters, bench_args)
         lines.append({"pass": k, "rc": rc, "ms_per_step": line and line.get("ms_per_step"),
                       "kernel_avg_ms": line and line["roofline"].get("kernel_avg_ms")})
+        if line:
+            library = line["config"]["library"]
         for r in rows:
             if "k_scan_fast" not in r["Kernel_Name"]:
                 continue
@@ -91,7 +94,8 @@ def main():
             raw.append({"pass": did[0], "dispatch": did[1], **{k: int(v) for k, v in per_dispatch[did].items()}})
     avg = {k: sum(v) / len(v) for k, v in agg.items()}
     n = {k: len(v) for k, v in agg.items()}
-    out = {"what": "rocprofv3 --pmc passes over `python3 bench.py " + " ".join(bench_args) + "`, per-launch averages for "
+    out = {"library": library, "chunks": 512,
+           "what": "rocprofv3 --pmc passes over `python3 bench.py " + " ".join(bench_args) + "`, per-launch averages for "
                    "adsb::k_scan_fast<false> (full-grid launches of the 256 MiB workload only)",
            "units": "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* : quad-cycles summed over all waves (or SIMDs for BUSY); "
                     "SQ_INSTS_* : wave-instructions; GRBM_GUI_ACTIVE: shader clocks the GPU was busy",
