@@ -1,6 +1,9 @@
 //! `extern "C"` declarations for `include/adsb_hip.h` (libadsb_hip.so, gfx950).
-//! NOT COMPILED in the build image (no Rust toolchain there); layouts follow the header field by
-//! field and are the ones tests/abi_host.c (plain C, same header) runs against on the GPU box.
+//! NOT COMPILED in the build image (no Rust toolchain there).  It cannot drift from the header
+//! unnoticed: tests/test_rust_shim.py parses this file and include/adsb_hip.h and compares every
+//! function (name, arity, argument and return types), the status constants and the field order,
+//! types, offsets and sizes of the three structs (which tests/abi_host.c also pins with
+//! _Static_assert from the C side).
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -37,6 +40,24 @@ pub struct AdsbTrial {
     pub pad: u16,
 }
 
+/// `adsb_stats`: counters and timings of the most recent call.  72 bytes.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct AdsbStats {
+    pub n_samples: u64,
+    pub n_chunks: u64,
+    pub n_candidates: u64,
+    pub n_ap_entries: u64,
+    pub n_records: u64,
+    pub n_messages: u64,
+    pub ms_scan: f32,
+    pub ms_match: f32,
+    pub ms_records: f32,
+    pub ms_total_device: f32,
+    pub retries: u32,
+    pub ms_scan_exclusive: f32,
+}
+
 #[repr(C)]
 pub struct AdsbCtx {
     _private: [u8; 0],
@@ -67,6 +88,11 @@ unsafe extern "C" {
     pub fn adsb_replay_records(filter_table: *mut u32, records: *mut AdsbTrial, n: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_format_raw(msg: *const AdsbMsg, out: *mut c_char, out_size: usize) -> c_int;
     pub fn adsb_read_test_data(path: *const c_char, iq_re_im: *mut i16, max_samples: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_selftest_mag_digest(ctx: *mut AdsbCtx, first_bits: u32, count: u32, sum_out: *mut u64, xor_out: *mut u64) -> c_int;
+    pub fn adsb_selftest_stage_lists(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, cand: *mut u64, cand_cap: usize, n_cand: *mut usize, ap: *mut u64, ap_cap: usize, n_ap: *mut usize) -> c_int;
+    pub fn adsb_get_stats(ctx: *const AdsbCtx, out: *mut AdsbStats) -> c_int;
+    pub fn adsb_host_sorts(ctx: *const AdsbCtx) -> u64;
+    pub fn adsb_host_replays(ctx: *const AdsbCtx) -> u64;
     pub fn adsb_strerror(status: c_int) -> *const c_char;
     pub fn adsb_last_error(ctx: *const AdsbCtx) -> *const c_char;
     pub fn adsb_version() -> *const c_char;

@@ -21,7 +21,26 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stddef.h>
+
 #include "adsb_hip.h"
+
+/* The layouts a non-C host binds (integration/rust/src/hip_ffi.rs, dump1090_rs_amd/_lib.py): pinned here
+ * from the C side, so a change to a struct in the header fails this build; tests/test_rust_shim.py
+ * checks the Rust and ctypes declarations against the same numbers. */
+_Static_assert(sizeof(adsb_msg) == 40, "adsb_msg is 40 bytes");
+_Static_assert(offsetof(adsb_msg, msg) == 0 && offsetof(adsb_msg, len) == 14 && offsetof(adsb_msg, try_phase) == 15 &&
+               offsetof(adsb_msg, score) == 16 && offsetof(adsb_msg, j) == 20 && offsetof(adsb_msg, chunk) == 24 &&
+               offsetof(adsb_msg, signal_level) == 32, "adsb_msg field offsets");
+_Static_assert(sizeof(adsb_trial) == 32, "adsb_trial is 32 bytes");
+_Static_assert(offsetof(adsb_trial, power) == 0 && offsetof(adsb_trial, chunk) == 8 && offsetof(adsb_trial, j_tp) == 12 &&
+               offsetof(adsb_trial, msg) == 16 && offsetof(adsb_trial, pad) == 30, "adsb_trial field offsets");
+_Static_assert(sizeof(adsb_stats) == 72, "adsb_stats is 72 bytes");
+_Static_assert(offsetof(adsb_stats, n_messages) == 40 && offsetof(adsb_stats, ms_scan) == 48 &&
+               offsetof(adsb_stats, retries) == 64 && offsetof(adsb_stats, ms_scan_exclusive) == 68, "adsb_stats field offsets");
+_Static_assert(ADSB_OK == 0 && ADSB_ERR_INVALID == -1 && ADSB_ERR_NO_DEVICE == -2 && ADSB_ERR_HIP == -3 && ADSB_ERR_TOO_LONG == -4 &&
+               ADSB_ERR_CAPACITY == -5 && ADSB_ERR_NOMEM == -6 && ADSB_ERR_BUSY == -7, "status codes");
+_Static_assert(ADSB_MAG_DATA_LEN == 131398 && ADSB_MAX_IN_FLIGHT == 4, "buffer geometry");
 
 int main(int argc, char **argv)
 {
