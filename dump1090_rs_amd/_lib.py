@@ -120,6 +120,10 @@ def lib() -> C.CDLL:
     L.adsb_version.restype = C.c_char_p
     L.adsb_selftest_stage_lists.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]
     L.adsb_selftest_stage_lists.restype = C.c_int
+    L.adsb_selftest_gate_stages.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]
+    L.adsb_selftest_gate_stages.restype = C.c_int
+    L.adsb_selftest_crc_table.argtypes = [vp]
+    L.adsb_selftest_crc_table.restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]
     L.adsb_host_replays.restype = C.c_uint64
     L.adsb_host_sorts.argtypes = [vp]

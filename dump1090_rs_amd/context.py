@@ -213,6 +213,21 @@ class Context:
             self._check(st, "adsb_selftest_stage_lists")
             return cand[: nc.value].copy(), ap[: na.value].copy()
 
+    def selftest_gate_stages(self, device_ptr: int, n_samples: int):
+        """adsb_selftest_gate_stages: (positions where check_preamble returns Some, those that also pass
+        the 3.5 dB test), both as buffer << 32 | j, ascending u64 arrays."""
+        pc, sc = max(4096, n_samples // 8), max(4096, n_samples // 16)
+        while True:
+            pre, snr = np.zeros(pc, dtype=np.uint64), np.zeros(sc, dtype=np.uint64)
+            npre, nsnr = C.c_size_t(), C.c_size_t()
+            st = self._L.adsb_selftest_gate_stages(self._h, C.c_void_p(device_ptr), n_samples, pre.ctypes.data, pc,
+                                                   C.byref(npre), snr.ctypes.data, sc, C.byref(nsnr))
+            if st == _lib.ADSB_ERR_CAPACITY:
+                pc, sc = max(pc, npre.value), max(sc, nsnr.value)
+                continue
+            self._check(st, "adsb_selftest_gate_stages")
+            return pre[: npre.value].copy(), snr[: nsnr.value].copy()
+
     # -- sharded capture: two phases around a host-side exchange of learned addresses
     def shard_scan(self, device_ptr: int, n_samples: int) -> np.ndarray:
         """Phase 1 on this shard: the addresses its clean DF11 / DF17 frames will add (sorted u32)."""

@@ -188,6 +188,39 @@ __device__ __forceinline__ bool preamble_gates(Ptr p)
     return true;
 }
 
+// The same sequence stage by stage, for the self-test's position lists (adsb_selftest_gate_stages):
+// 0 = check_preamble returns None, 1 = Some, 2 = and the 3.5 dB test (:129), 3 = and the quiet
+// samples (:135-146), i.e. the position is sliced.
+template <typename Ptr>
+__device__ __forceinline__ int preamble_stage(Ptr p)
+{
+    const int p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6],
+              p7 = p[7], p8 = p[8], p9 = p[9], p10 = p[10], p11 = p[11], p12 = p[12],
+              p13 = p[13];
+    if (!(p0 < p1 && p12 > p13)) return 0;
+    int high;
+    unsigned sig, noise;
+    if (p1 > p2 && p2 < p3 && p3 > p4 && p8 < p9 && p9 > p10 && p10 < p11) {
+        high = (p1 + p3 + p9 + p11 + p12) / 4, sig = p1 + p3 + p9, noise = p5 + p6 + p7;
+    } else if (p1 > p2 && p2 < p3 && p3 > p4 && p8 < p9 && p9 > p10 && p11 < p12) {
+        high = (p1 + p3 + p9 + p12) / 4, sig = p1 + p3 + p9 + p12, noise = p5 + p6 + p7 + p8;
+    } else if (p1 > p2 && p2 < p3 && p4 > p5 && p8 < p9 && p10 > p11 && p11 < p12) {
+        high = (p1 + p3 + p4 + p9 + p10 + p12) / 4, sig = p1 + p12, noise = p6 + p7;
+    } else if (p1 > p2 && p3 < p4 && p4 > p5 && p9 < p10 && p10 > p11 && p11 < p12) {
+        high = (p1 + p4 + p10 + p12) / 4, sig = p1 + p4 + p10 + p12, noise = p5 + p6 + p7 + p8;
+    } else if (p2 > p3 && p3 < p4 && p4 > p5 && p9 < p10 && p10 > p11 && p11 < p12) {
+        high = (p1 + p2 + p4 + p10 + p12) / 4, sig = p4 + p10 + p12, noise = p6 + p7 + p8;
+    } else {
+        return 0;
+    }
+    if (sig * 2 < 3 * noise) return 1;
+    const int p14 = p[14], p15 = p[15], p16 = p[16], p17 = p[17], p18 = p[18];
+    if (p5 >= high || p6 >= high || p7 >= high || p8 >= high || p14 >= high || p15 >= high ||
+        p16 >= high || p17 >= high || p18 >= high)
+        return 2;
+    return 3;
+}
+
 // ---------------------------------------------------------------------------
 // bit slicer: src/demod_2400.rs:72-83 (+ the Phase walk :22-70 in closed form).
 // Bit n of trial phase tp at preamble j sits at 5x-oversampled position

@@ -1434,10 +1434,15 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
     return ADSB_OK;
 }
 
-int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, uint64_t *cand, size_t cand_cap,
-                              size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap)
+namespace {
+
+// One blocking pass of the self-test instantiation of the fast scan: the gate-stage position list
+// (every pattern match that is a preamble by the reference's own tests, with its stage and the
+// production gates' verdict) and the address/parity trial list.  The context's filter is not touched.
+int selftest_pass(adsb_ctx *c, const void *d_iq, size_t n_samples, std::vector<uint64_t> *pre, std::vector<uint64_t> *snr,
+                  std::vector<uint64_t> *cands, std::vector<uint64_t> *aps)
 {
-    if (!c || !d_iq || n_samples == 0 || (!cand && cand_cap) || (!ap && ap_cap)) return ADSB_ERR_INVALID;
+    if (!c || !d_iq || n_samples == 0) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     if ((uintptr_t)d_iq % 16) return ADSB_ERR_INVALID;
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
@@ -1452,8 +1457,6 @@ int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, u
         (void)hipFree(d_cand);
         return ADSB_ERR_NOMEM;
     }
-    std::vector<uint64_t> cands, aps;
-    int rc = ADSB_OK;
     auto body = [&]() -> int {
         HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
         ScanParams p{};
@@ -1479,27 +1482,41 @@ int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, u
         HIP_TRY(c, hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const bool overflow = ctr.overflow != 0 || count > dev_cap;
+        bool inconsistent = false;
         if (!overflow) {
-            cands.resize(count);
-            if (count) HIP_TRY(c, hipMemcpy(cands.data(), d_cand, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            std::sort(cands.begin(), cands.end());
-            const std::vector<uint32_t> tab = build_gf_tables();
-            const uint32_t *x56 = tab.data() + kTabX56 * 256;
-            std::vector<uint64_t> seg(c->seg_cap);
-            for (int g = 0; g < kApWaveSegs; g++) {
-                const uint32_t k = ctr.seg_ap[g];
-                if (!k) continue;
-                HIP_TRY(c, hipMemcpy(seg.data(), sl.d_ap + (size_t)g * c->seg_cap, (size_t)k * sizeof(uint64_t),
-                                     hipMemcpyDeviceToHost));
-                for (uint32_t i = 0; i < k; i++) {
-                    const uint64_t e = seg[i];
-                    const uint32_t code = entry_code(e);
-                    uint32_t v = entry_value(e);
-                    if (code >= 5 && code < 10) v = x56[v & 255u] ^ x56[256 + ((v >> 8) & 255u)] ^ x56[512 + (v >> 16)];
-                    aps.push_back(pack_entry(v, entry_tp(e), entry_j(e), entry_chunk(e)));
-                }
+            std::vector<uint64_t> all(count);
+            if (count) HIP_TRY(c, hipMemcpy(all.data(), d_cand, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            for (uint64_t e : all) {
+                const uint32_t stage = (uint32_t)(e >> 28) & 3u;
+                const bool gate = ((e >> 30) & 1u) != 0;
+                const uint64_t pos = (e >> 32) << 32 | (e & 0x0FFFFFFFu);
+                if (stage >= 1 && pre) pre->push_back(pos);
+                if (stage >= 2 && snr) snr->push_back(pos);
+                if (gate && cands) cands->push_back(pos);
+                // the production gates (gate_eval) and the reference's own sequence (preamble_stage) must agree
+                inconsistent = inconsistent || (gate != (stage == 3));
             }
-            std::sort(aps.begin(), aps.end());
+            for (auto *v : {pre, snr, cands})
+                if (v) std::sort(v->begin(), v->end());
+            if (aps) {
+                const std::vector<uint32_t> tab = build_gf_tables();
+                const uint32_t *x56 = tab.data() + kTabX56 * 256;
+                std::vector<uint64_t> seg(c->seg_cap);
+                for (int g = 0; g < kApWaveSegs; g++) {
+                    const uint32_t k = ctr.seg_ap[g];
+                    if (!k) continue;
+                    HIP_TRY(c, hipMemcpy(seg.data(), sl.d_ap + (size_t)g * c->seg_cap, (size_t)k * sizeof(uint64_t),
+                                         hipMemcpyDeviceToHost));
+                    for (uint32_t i = 0; i < k; i++) {
+                        const uint64_t e = seg[i];
+                        const uint32_t code = entry_code(e);
+                        uint32_t v = entry_value(e);
+                        if (code >= 5 && code < 10) v = x56[v & 255u] ^ x56[256 + ((v >> 8) & 255u)] ^ x56[512 + (v >> 16)];
+                        aps->push_back(pack_entry(v, entry_tp(e), entry_j(e), entry_chunk(e)));
+                    }
+                }
+                std::sort(aps->begin(), aps->end());
+            }
         }
         // put the slot back: the records kernel zeroes this pass's counters on its way out
         p.cand_out = nullptr;
@@ -1513,17 +1530,54 @@ int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, u
             c->last_error = "selftest: the pass overflowed the fast scan's lists";
             return ADSB_ERR_HIP;
         }
+        if (inconsistent) {
+            c->last_error = "selftest: the scan's gates and the reference's sequence of tests disagree on a position";
+            return ADSB_ERR_HIP;
+        }
         return ADSB_OK;
     };
-    rc = body();
+    const int rc = body();
     (void)hipFree(d_cand);
     (void)hipFree(d_count);
-    if (rc) return rc;
-    if (n_cand) *n_cand = cands.size();
-    if (n_ap) *n_ap = aps.size();
-    if (cands.size() > cand_cap || aps.size() > ap_cap) return ADSB_ERR_CAPACITY;
-    if (!cands.empty()) std::memcpy(cand, cands.data(), cands.size() * sizeof(uint64_t));
-    if (!aps.empty()) std::memcpy(ap, aps.data(), aps.size() * sizeof(uint64_t));
+    return rc;
+}
+
+int hand_out(const std::vector<uint64_t> &a, uint64_t *out_a, size_t cap_a, size_t *n_a, const std::vector<uint64_t> &b,
+             uint64_t *out_b, size_t cap_b, size_t *n_b)
+{
+    if (n_a) *n_a = a.size();
+    if (n_b) *n_b = b.size();
+    if (a.size() > cap_a || b.size() > cap_b) return ADSB_ERR_CAPACITY;
+    if (!a.empty()) std::memcpy(out_a, a.data(), a.size() * sizeof(uint64_t));
+    if (!b.empty()) std::memcpy(out_b, b.data(), b.size() * sizeof(uint64_t));
+    return ADSB_OK;
+}
+
+}  // namespace
+
+int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, uint64_t *cand, size_t cand_cap,
+                              size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap)
+{
+    if ((!cand && cand_cap) || (!ap && ap_cap)) return ADSB_ERR_INVALID;
+    std::vector<uint64_t> cands, aps;
+    if (int rc = selftest_pass(c, d_iq, n_samples, nullptr, nullptr, &cands, &aps)) return rc;
+    return hand_out(cands, cand, cand_cap, n_cand, aps, ap, ap_cap, n_ap);
+}
+
+int adsb_selftest_gate_stages(adsb_ctx *c, const void *d_iq, size_t n_samples, uint64_t *preamble, size_t preamble_cap,
+                              size_t *n_preamble, uint64_t *snr, size_t snr_cap, size_t *n_snr)
+{
+    if ((!preamble && preamble_cap) || (!snr && snr_cap)) return ADSB_ERR_INVALID;
+    std::vector<uint64_t> pre, sn;
+    if (int rc = selftest_pass(c, d_iq, n_samples, &pre, &sn, nullptr, nullptr)) return rc;
+    return hand_out(pre, preamble, preamble_cap, n_preamble, sn, snr, snr_cap, n_snr);
+}
+
+int adsb_selftest_crc_table(uint32_t *out256)
+{
+    if (!out256) return ADSB_ERR_INVALID;
+    static const Crc24 crc;  // the table the host replay scores with (mode_s_host.hpp)
+    std::memcpy(out256, crc.t, sizeof(crc.t));
     return ADSB_OK;
 }
 

@@ -437,6 +437,7 @@ __device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint
 
 // One 64-lane pass of the gates: `ent` is this lane's pattern match (valid lanes only count),
 // passing positions are appended to the wave's candidate region.
+template <bool SELFTEST>
 __device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s, uint32_t ent, bool valid,
                                           uint16_t *wcand, uint32_t &ncand_w, int jbase, uint32_t chunk)
 {
@@ -445,9 +446,17 @@ __device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s,
     if (mask) {
         if (pass) wcand[mask_rank(mask, ncand_w)] = (uint16_t)(ent & 0x1FFFu);
         ncand_w += (uint32_t)__popcll(mask);
-        if (p.cand_out && pass) {  // self-test only: the candidate list itself (adsb_selftest_stage_lists)
+    }
+    if (SELFTEST && p.cand_out && valid) {
+        // self-test instantiation only (adsb_selftest_stage_lists / _gate_stages): every pattern match
+        // that is a preamble by the reference's own sequence of tests goes out as
+        // chunk << 32 | production gate verdict << 30 | stage (1..3, preamble_stage) << 28 | j
+        const int stage = preamble_stage(s.mag + (ent & 0x1FFFu));
+        if (stage | (int)pass) {
             const uint32_t at = atomicAdd(p.cand_count, 1u);
-            if (at < p.cand_cap) p.cand_out[at] = (uint64_t)chunk << 32 | (uint32_t)(jbase - kPad + (int)(ent & 0x1FFFu));
+            if (at < p.cand_cap)
+                p.cand_out[at] = (uint64_t)chunk << 32 | (uint64_t)(pass ? 1u : 0u) << 30 | (uint64_t)stage << 28 |
+                                 (uint32_t)(jbase - kPad + (int)(ent & 0x1FFFu));
         }
     }
 }
@@ -511,7 +520,7 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
 // after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
-template <bool FROM_MAG>
+template <bool FROM_MAG, bool SELFTEST = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
@@ -785,7 +794,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
             // one lane per pattern match (gate_pass)
             {
                 const uint32_t idx = base + (uint32_t)lane;
-                gate_pass(p, s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, ncand_w, jbase, chunk);
+                gate_pass<SELFTEST>(p, s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, ncand_w, jbase, chunk);
             }
             base += 64;
             if (base >= npat_w) {
@@ -906,7 +915,9 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
     const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
     // With events, the launch itself carries them (hipExtLaunchKernelGGL): the dispatch
     // packet's own begin/end timestamps, no barrier packets in the stream around it.
-    if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
+    if (p.cand_out)  // the self-test's instantiation: also writes the gate-stage position list
+        hipLaunchKernelGGL((k_scan_fast<false, true>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
         hipLaunchKernelGGL(k_scan_fast<true>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     else if (p.ev_start && p.ev_stop)
         hipExtLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,

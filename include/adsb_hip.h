@@ -270,6 +270,19 @@ int adsb_selftest_mag_digest(adsb_ctx *ctx, uint32_t first_bits, uint32_t count,
 int adsb_selftest_stage_lists(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples, uint64_t *cand,
                               size_t cand_cap, size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap);
 
+/* Device self-test, the two stages in front of cand[]: every position at which check_preamble returns
+ * Some (src/demod_2400.rs:215-321) -> preamble[], and those that also pass the 3.5 dB test (:129) ->
+ * snr[]; both as buffer << 32 | j, ascending (cand[] above is the subset of snr[] that also passes the
+ * quiet samples, :135-146).  The kernel writes them from the reference's own sequence of tests applied
+ * to its bit-parallel pattern matches, next to the verdict of its production gates; the call fails with
+ * ADSB_ERR_HIP if the two ever disagree.  Same conventions as adsb_selftest_stage_lists. */
+int adsb_selftest_gate_stages(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples, uint64_t *preamble,
+                              size_t preamble_cap, size_t *n_preamble, uint64_t *snr, size_t snr_cap, size_t *n_snr);
+
+/* The 256-entry CRC-24 table the host replay scores with (src/crc.rs:3-260 CRC_TABLE): for the test that
+ * pins it against the reference's constants.  Host only, no context. */
+int adsb_selftest_crc_table(uint32_t *out256);
+
 int adsb_get_stats(const adsb_ctx *ctx, adsb_stats *out);
 /* Diagnostic: how many collected passes handed the host their trial records out of
  * (buffer, j, try_phase) order, so that the host replay had to sort them first.  Passes of more

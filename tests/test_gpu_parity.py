@@ -740,10 +740,10 @@ def test_dense_stream_with_one_overfull_buffer_bucket_falls_back_and_stays_exact
 
 # ----------------------------------------------------------------------------- stages
 def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod, golden, fixture_iq):
-    """Not only frames: the device's magnitudes, the list of positions its gates let through and its
-    address/parity trials (position, try_phase, CRC residual) against tests/golden/stage_goldens.json
-    on the reference captures, and list against list with the oracle on a synthetic stream whose
-    buffers are ragged and carry bursts."""
+    """Not only frames: the device's magnitudes, the positions at which check_preamble matches, those that
+    pass the 3.5 dB test, those its gates let through (all five digests of tests/golden/stage_goldens.json)
+    and its address/parity trials (position, try_phase, CRC residual) on the reference captures, and
+    list against list with the oracle on a synthetic stream whose buffers are ragged and carry bursts."""
     import hashlib
     import json
     import zlib
@@ -761,6 +761,11 @@ def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod,
             cand, ap = c.selftest_stage_lists(dev.data_ptr(), len(iq))
             assert (len(cand), sha(cand)) == (want["n_cand"], want["cand_sha256"])
             assert (len(ap), sha(ap)) == (want["n_ap"], want["ap_sha256"])
+            # and the two stages in front of the candidates: check_preamble, then the 3.5 dB test
+            pre, snr = c.selftest_gate_stages(dev.data_ptr(), len(iq))
+            assert (len(pre), sha(pre)) == (want["n_preamble"], want["preamble_sha256"])
+            assert (len(snr), sha(snr)) == (want["n_snr"], want["snr_sha256"])
+            assert set(cand.tolist()) <= set(snr.tolist()) <= set(pre.tolist())
         n = 5 * 131072 + 7001
         iq = synth.make_iq(n, n_bursts=60, seed=4242, n_icao=7, df11_every=5)
         st = oracle_mod.stage_lists(iq)
@@ -768,6 +773,8 @@ def test_stage_lists_match_the_stage_goldens_and_the_oracle(hip_lib, oracle_mod,
         cand, ap = c.selftest_stage_lists(dev.data_ptr(), n)
         assert cand.tolist() == st["cand"]
         assert ap.tolist() == st["ap"]
+        pre, snr = c.selftest_gate_stages(dev.data_ptr(), n)
+        assert pre.tolist() == st["preamble"] and snr.tolist() == st["snr"]
         # the context is as it was: a normal call still gives the oracle's frames
         c.icao_flush()
         assert_same(c.demod_iq(iq), oracle_mod.Oracle().demod_iq(iq)[0])
@@ -1106,10 +1113,113 @@ def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
     import subprocess
     import sys
     from tests.conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "80", "--seed", "7", "--dense", "5", "--mixed", "5"],
-                       capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "300", "--seed", "7", "--dense", "20", "--mixed", "40"],
+                       capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "80 cases identical" in r.stdout and "dense_pipeline=5" in r.stdout   # (+ 5 dense pipelines: device-side order / score)
+    # (+ 20 dense pipelines: device-side order / score; + 40 mixed ones: small and large passes in flight
+    # together over shared addresses -- the kind of case that found round 2's cross-stream ordering hole)
+    assert "300 cases identical" in r.stdout and "dense_pipeline=20" in r.stdout and "mixed_pipeline=40" in r.stdout
+
+
+def test_four_host_threads_each_with_its_own_context(hip_lib, oracle_mod):
+    """Contexts are independent streams (a context itself is not thread-safe): four host threads, each
+    with its own context on the one GPU, run blocking and pipelined passes over different captures at
+    the same time; every result against the oracle."""
+    import threading
+    import torch
+    from dump1090_rs_amd import Context
+    key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
+    okey = lambda w: (w["chunk"], w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"])
+    jobs = []
+    for tid in range(4):
+        n = (12 + 6 * tid) * 131072 - 1000 * tid
+        iq = synth.make_iq(n, n_bursts=150 + 40 * tid, seed=900 + tid, n_icao=20, df11_every=4)
+        jobs.append((n, torch.from_numpy(iq).cuda(), [okey(w) for w in oracle_mod.Oracle().demod_iq(iq)[0]]))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(tid):
+        try:
+            n, dev, want = jobs[tid]
+            with Context(0, 12 + 6 * tid) as ctx:
+                for it in range(12):
+                    ctx.icao_flush()
+                    if it % 2:
+                        got = [key(m) for m in ctx.demod_iq_device(dev.data_ptr(), n)]
+                    else:  # pipelined: the same capture twice, a flush in between
+                        ctx.submit_iq_device(dev.data_ptr(), n)
+                        ctx.icao_flush()
+                        ctx.submit_iq_device(dev.data_ptr(), n)
+                        got = [key(m) for m in ctx.collect()]
+                        if [key(m) for m in ctx.collect()] != want:
+                            errors.append((tid, it, "second"))
+                    if got != want:
+                        errors.append((tid, it, "first"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+
+
+def test_sixteen_contexts_in_flight_at_once(hip_lib, oracle_mod, golden, fixture_iq):
+    """Sixteen one-buffer contexts in one process (one per receiver, say), all with passes in flight at
+    the same time, created and destroyed twice over (their internal streams come back from the
+    process-wide pool): every context is its own stream -- six passes over its capture equal one oracle
+    stream of six passes (the first gives the reference's frames, the later ones score against what the
+    context's own filter has learned), whatever the fifteen others are doing."""
+    import torch
+    from dump1090_rs_amd import Context
+    fxs = golden["fixtures"]
+    devs = [torch.from_numpy(fixture_iq[fx["file"]]).cuda() for fx in fxs]
+    torch.cuda.synchronize()
+    want = []
+    for fx in fxs:
+        orc = oracle_mod.Oracle()
+        orc.icao_flush()
+        want.append([orc.demod_iq(fixture_iq[fx["file"]])[0] for _ in range(6)])
+        assert [w["buffer"].hex() for w in want[-1][0]] == fx["frames"]
+    for round_ in range(2):
+        ctxs = [Context(0, 1) for _ in range(16)]
+        try:
+            for c in ctxs:
+                c.icao_flush()
+            for rep in range(3):
+                for k, c in enumerate(ctxs):
+                    c.submit_iq_device(devs[k % 3].data_ptr(), 131072)
+                    c.submit_iq_device(devs[k % 3].data_ptr(), 131072)
+                for k, c in enumerate(ctxs):
+                    assert_same(c.collect(), want[k % 3][2 * rep])
+                    assert_same(c.collect(), want[k % 3][2 * rep + 1])
+        finally:
+            for c in ctxs:
+                c.close()
+
+
+def test_one_gib_capture_of_2048_buffers(hip_lib, oracle_mod):
+    """A capture four times the bench's (2048 buffers = 1 GiB of IQ, one blocking call) against the
+    multi-threaded oracle, then twice more: from the second call on the context knows the stream is
+    dense, so those passes are ordered (more than 1024 buckets) and scored on the device."""
+    import torch
+    from dump1090_rs_amd import Context
+    chunks = 2048
+    n = chunks * 131072 - 12345
+    dev = synth.make_iq_torch(n, n_bursts=40 * chunks // 8, seed=4711, n_icao=300, df11_every=6, device="cuda")
+    torch.cuda.synchronize()
+    host = dev.cpu().numpy()
+    want, _ = oracle_mod.Oracle().demod_iq(host, cap=1 << 22, threads=min(64, len(__import__("os").sched_getaffinity(0))))
+    del host
+    assert len(want) > 9000
+    with Context(0, chunks) as c:
+        for rep in range(3):
+            c.icao_flush()
+            assert_same(c.demod_iq_device(dev.data_ptr(), n, cap=1 << 22), want)
+            assert c.stats()["retries"] == 0
+        assert c._L.adsb_host_replays(c._h) == 1      # the first call only: the repeats were the device's
 
 
 def test_inputs_longer_than_the_context_was_sized_for(hip_lib, oracle_mod):

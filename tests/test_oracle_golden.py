@@ -43,11 +43,30 @@ def test_read_test_data_component_order(oracle_mod, fixture_iq, golden):
     assert np.array_equal(a, fixture_iq[f])
 
 
-def test_crc_table_pins(golden, oracle_mod):
+def test_crc_table_pins(golden, oracle_mod, hip_lib):
+    """All 256 entries of the reference's CRC_TABLE (src/crc.rs:3-260, tests/golden/reference_frames.json
+    "crc_table"): the oracle's table, the table regenerated from the generator 0xFFF409, and the table the
+    product's host replay scores with (adsb_selftest_crc_table) are that table.  (The device's GF(2) form of
+    it, adsb_tables.h, is tied to the same polynomial by the GPU stage test: every address/parity trial's
+    residual against this oracle.)"""
     L = oracle_mod.lib()
     assert L.orc_crc_table_entry(0) == 0
     for k, v in golden["crc_table_pins"].items():
         assert L.orc_crc_table_entry(int(k)) == int(v, 16)
+    table = [int(v, 16) for v in golden["crc_table"]]
+    assert len(table) == 256 and all(int(v, 16) == table[int(k)] for k, v in golden["crc_table_pins"].items())
+    assert [L.orc_crc_table_entry(i) for i in range(256)] == table
+
+    def entry(i):
+        c = i << 16
+        for _ in range(8):
+            c = ((c << 1) ^ 0xFFF409) if c & 0x800000 else (c << 1)
+        return c & 0xFFFFFF
+    assert [entry(i) for i in range(256)] == table
+    out = (C.c_uint32 * 256)()
+    assert hip_lib.adsb_selftest_crc_table(out) == 0 and list(out) == table
+    from dump1090_rs_amd import synth
+    assert all(synth.crc24(bytes([i])) == table[i] for i in range(256))   # (what the synthetic frames are built with)
 
 
 def test_crc_residual_of_golden_frames_is_clean(golden, oracle_mod):
