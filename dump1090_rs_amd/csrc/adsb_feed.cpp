@@ -4,14 +4,22 @@
 // reference, main.rs:46) so that downstream tools (adsb_deku's radar, anything that speaks
 // the dump1090 raw format) can consume it.
 //
-//   adsb_feed [--device N] [--port P] [--quiet] [--mem-order] [--buffers K] <capture.iq | ->
+//   adsb_feed [--device N] [--port P] [--quiet] [--mem-order] [--buffers K] [--latency-ms T] <capture.iq | ->
 //
 // Input is the reference's capture format (src/utils.rs:8-20, save_test_data): little-endian
 // i16 pairs, im first; --mem-order takes {re, im} pairs instead.  The stream is cut into
 // 131072-sample buffers exactly as consecutive SDR reads would be (no carry-over between
-// buffers, src/lib.rs:36-44); K of them (default 64) travel to the GPU per pass through the
-// pinned double-buffered ring (adsb_ring_*), so reading, the copy and the scan overlap.
-// The ICAO filter is never flushed, as in the reference's loop.  No GPU -> exits non-zero.
+// buffers, src/lib.rs:36-44); up to K of them (default 64) travel to the GPU per pass through the
+// pinned ring (adsb_ring_*), so reading, the copy and the scan overlap.  A slot does not wait to
+// fill up: when no input has arrived for T ms (default 100) the whole buffers read so far are
+// submitted as a shorter pass -- a live 2.4 MSPS pipe delivers a buffer every 55 ms and would
+// otherwise sit 3.5 s in a 64-buffer slot -- and the begun buffer moves on to the next slot, so the
+// cuts stay where consecutive reads of 131072 samples put them.  Raw-TCP clients are written
+// without blocking: one whose socket buffer is full (it stopped reading) is dropped, as the
+// reference drops a client whose write fails (main.rs:184-200), and never holds up the others or
+// the demodulation.  A pass with more frames than the output array gets them all
+// (adsb_fetch_messages).  The ICAO filter is never flushed, as in the reference's loop.
+// No GPU -> exits non-zero.
 #include <arpa/inet.h>
 #include <cerrno>
 #include <chrono>
@@ -21,6 +29,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <netinet/in.h>
+#include <poll.h>
 #include <string>
 #include <sys/socket.h>
 #include <unistd.h>
@@ -33,6 +42,7 @@ namespace {
 struct Clients {
     int listener = -1;
     std::vector<int> socks;
+    unsigned long long dropped = 0;
 
     bool listen_on(int port)
     {
@@ -54,18 +64,26 @@ struct Clients {
         for (;;) {
             const int s = ::accept(listener, nullptr, nullptr);
             if (s < 0) break;
+            // never block on a client: a generous send buffer for bursts, then EAGAIN means it is not reading
+            ::fcntl(s, F_SETFL, ::fcntl(s, F_GETFL, 0) | O_NONBLOCK);
+            int sndbuf = 1 << 20;  // ~30 000 frames of backlog (the kernel may grant less)
+            ::setsockopt(s, SOL_SOCKET, SO_SNDBUF, &sndbuf, sizeof(sndbuf));
             socks.push_back(s);
         }
     }
-    void send_all(const std::string &lines)  // main.rs:184-199: drop a client when its write fails
+    // main.rs:184-199: drop a client when its write fails -- which includes a full socket buffer
+    // (EAGAIN: a partly written line could not be completed later without queueing per client)
+    void send_all(const std::string &lines)
     {
         for (size_t i = 0; i < socks.size();) {
             size_t off = 0;
             bool dead = false;
             while (off < lines.size()) {
-                const ssize_t w = ::send(socks[i], lines.data() + off, lines.size() - off, MSG_NOSIGNAL);
+                const ssize_t w = ::send(socks[i], lines.data() + off, lines.size() - off, MSG_NOSIGNAL | MSG_DONTWAIT);
                 if (w <= 0) {
+                    if (w < 0 && errno == EINTR) continue;
                     dead = true;
+                    dropped++;
                     break;
                 }
                 off += (size_t)w;
@@ -92,23 +110,38 @@ int die(adsb_ctx *ctx, const char *what, int st)
     return 1;
 }
 
-// read up to `want` bytes (short only at end of input)
-size_t read_full(FILE *f, void *dst, size_t want)
+// Wait up to idle_ms for input (idle_ms < 0: for ever) and read once into dst[have, want).
+// Returns the new fill; *eof at end of input, *idle when nothing arrived in time.
+size_t read_once(int fd, char *dst, size_t have, size_t want, int idle_ms, bool *eof, bool *idle)
 {
-    size_t got = 0;
-    while (got < want) {
-        const size_t r = std::fread((char *)dst + got, 1, want - got, f);
-        if (r == 0) break;
-        got += r;
+    *idle = false;
+    for (;;) {
+        pollfd p{fd, POLLIN, 0};
+        const int pr = ::poll(&p, 1, idle_ms);
+        if (pr == 0) {
+            *idle = true;
+            return have;
+        }
+        if (pr < 0) {
+            if (errno == EINTR) continue;
+            *eof = true;
+            return have;
+        }
+        const ssize_t r = ::read(fd, dst + have, want - have);
+        if (r < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+        if (r <= 0) {
+            *eof = true;
+            return have;
+        }
+        return have + (size_t)r;
     }
-    return got;
 }
 
 }  // namespace
 
 int main(int argc, char **argv)
 {
-    int device = 0, port = 0, buffers = 64;
+    int device = 0, port = 0, buffers = 64, latency_ms = 100, out_cap = 0;
     bool quiet = false, mem_order = false;
     const char *path = nullptr;
     for (int i = 1; i < argc; i++) {
@@ -116,18 +149,20 @@ int main(int argc, char **argv)
         if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--port" && i + 1 < argc) port = std::atoi(argv[++i]);
         else if (a == "--buffers" && i + 1 < argc) buffers = std::atoi(argv[++i]);
+        else if (a == "--latency-ms" && i + 1 < argc) latency_ms = std::atoi(argv[++i]);
+        else if (a == "--out-cap" && i + 1 < argc) out_cap = std::atoi(argv[++i]);  // frames the output array starts with (it grows)
         else if (a == "--quiet") quiet = true;
         else if (a == "--mem-order") mem_order = true;
         else if (a == "--help" || a == "-h") path = nullptr, i = argc;
         else path = argv[i];
     }
     if (!path || buffers < 1) {
-        std::fprintf(stderr, "usage: adsb_feed [--device N] [--port P] [--quiet] [--mem-order] [--buffers K] <capture.iq | ->\n");
+        std::fprintf(stderr, "usage: adsb_feed [--device N] [--port P] [--quiet] [--mem-order] [--buffers K] [--latency-ms T] <capture.iq | ->\n");
         return 2;
     }
     std::signal(SIGPIPE, SIG_IGN);
-    FILE *in = std::strcmp(path, "-") == 0 ? stdin : std::fopen(path, "rb");
-    if (!in) {
+    const int in = std::strcmp(path, "-") == 0 ? 0 : ::open(path, O_RDONLY);
+    if (in < 0) {
         std::fprintf(stderr, "adsb_feed: cannot open %s: %s\n", path, std::strerror(errno));
         return 1;
     }
@@ -145,17 +180,16 @@ int main(int argc, char **argv)
 
     // a 112 us frame every 120 us would be ~450 per 55 ms buffer; neighbouring preamble
     // positions can each emit one, so leave an order of magnitude of room
-    std::vector<adsb_msg> out((size_t)buffers * 4096);
+    std::vector<adsb_msg> out(out_cap > 0 ? (size_t)out_cap : (size_t)buffers * 4096);
     unsigned long long total_samples = 0, total_frames = 0;
     auto drain_one = [&]() -> int {
         size_t n = 0;
-        const int rc = adsb_collect(ctx, out.data(), out.size(), &n);
-        if (rc == ADSB_ERR_CAPACITY) {  // the first out.size() were written
-            std::fprintf(stderr, "adsb_feed: %zu frames in one pass, %zu dropped\n", n, n - out.size());
-            n = out.size();
-        } else if (rc != ADSB_OK) {
-            return rc;
+        int rc = adsb_collect(ctx, out.data(), out.size(), &n);
+        if (rc == ADSB_ERR_CAPACITY) {  // more frames than the array holds: the context kept them all
+            out.resize(n);
+            rc = adsb_fetch_messages(ctx, out.data(), out.size(), &n);
         }
+        if (rc != ADSB_OK) return rc;
         std::string lines;
         char line[40];
         for (size_t i = 0; i < n; i++) {
@@ -173,19 +207,43 @@ int main(int argc, char **argv)
     };
 
     const auto t_start = std::chrono::steady_clock::now();
+    const size_t buf_bytes = (size_t)ADSB_MODES_MAG_BUF_SAMPLES * 4;
+    std::vector<char> begun(buf_bytes);  // the buffer a short pass left unfinished: the next slot starts with it
+    size_t begun_bytes = 0;
+    unsigned long long short_passes = 0;
     bool eof = false;
     while (!eof) {
         int16_t *buf = nullptr;
         size_t cap = 0;
         st = adsb_ring_acquire(ctx, &buf, &cap);
-        if (st == ADSB_ERR_BUSY) {  // both slots in flight: finish the oldest first
+        if (st == ADSB_ERR_BUSY) {  // every slot in flight: finish the oldest first
             if ((st = drain_one()) != ADSB_OK) return die(ctx, "adsb_collect", st);
             continue;
         }
         if (st != ADSB_OK) return die(ctx, "adsb_ring_acquire", st);
-        const size_t bytes = read_full(in, buf, cap * 4);
+        char *dst = (char *)buf;
+        size_t fill = begun_bytes;
+        if (fill) std::memcpy(dst, begun.data(), fill);
+        begun_bytes = 0;
+        // until the slot is full, the input ends, or -- with at least one whole buffer in hand --
+        // nothing has arrived for latency_ms; meanwhile finished passes are handed on
+        while (!eof && fill < cap * 4) {
+            const bool have_whole = fill >= buf_bytes;
+            bool idle = false;
+            fill = read_once(in, dst, fill, cap * 4, have_whole || adsb_pending(ctx) > 0 ? latency_ms : -1, &eof, &idle);
+            if (!idle) continue;
+            if (adsb_pending(ctx) > 0)  // idle input: do not sit on results
+                if ((st = drain_one()) != ADSB_OK) return die(ctx, "adsb_collect", st);
+            if (have_whole) break;      // idle with whole buffers in hand: a short pass
+        }
+        size_t bytes = fill;
+        if (!eof && fill < cap * 4) {  // short pass: whole buffers only, the begun one waits for its rest
+            bytes = fill / buf_bytes * buf_bytes;
+            begun_bytes = fill - bytes;
+            std::memcpy(begun.data(), dst + bytes, begun_bytes);
+            short_passes++;
+        }
         const size_t n = bytes / 4;
-        eof = bytes < cap * 4;
         if (!mem_order)  // file pairs are [im][re]: swap into the in-memory {re, im} (utils.rs:29-31)
             for (size_t k = 0; k < n; k++) {
                 const int16_t im = buf[2 * k];
@@ -200,9 +258,9 @@ int main(int argc, char **argv)
     while (adsb_pending(ctx) > 0)
         if ((st = drain_one()) != ADSB_OK) return die(ctx, "adsb_collect", st);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    std::fprintf(stderr, "adsb_feed: %llu samples, %llu frames in %.3f s (%.1f Msamples/s)\n", total_samples,
-                 total_frames, secs, secs > 0 ? total_samples / secs / 1e6 : 0.0);
-    if (in != stdin) std::fclose(in);
+    std::fprintf(stderr, "adsb_feed: %llu samples, %llu frames in %.3f s (%.1f Msamples/s); %llu short passes, %llu clients dropped\n",
+                 total_samples, total_frames, secs, secs > 0 ? total_samples / secs / 1e6 : 0.0, short_passes, clients.dropped);
+    if (in != 0) ::close(in);
     adsb_destroy(ctx);
     return 0;
 }

@@ -986,6 +986,121 @@ def test_feed_tool_prints_and_serves_reference_raw_lines(hip_lib, oracle_mod, go
             feed.kill()
 
 
+def _start_feed(args):
+    import socket
+    import subprocess
+    import time
+    from tests.conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    feed = subprocess.Popen([str(ROOT / "dump1090_rs_amd" / "adsb_feed"), "--port", str(port), *args, "-"],
+                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+    def connect():
+        for _ in range(200):  # the listener is up before the first read of stdin
+            try:
+                return socket.create_connection(("127.0.0.1", port), timeout=1)
+            except OSError:
+                time.sleep(0.05)
+        raise AssertionError("adsb_feed is not listening")
+    return feed, connect
+
+
+def test_feed_tool_trickling_input_is_not_held_back_for_a_full_slot(hip_lib, oracle_mod):
+    """A live pipe delivers a buffer every 55 ms; with 64-buffer slots the first frames would wait 3.5 s.
+    adsb_feed submits the whole buffers it holds once the input has been idle for --latency-ms, and the
+    buffer it has begun moves on to the next slot: one and a half buffers written, a pause -- the first
+    buffer's frames are out before the rest is written -- then the rest; all of it equal to the oracle's
+    stream cut at the same 131072-sample boundaries."""
+    import os
+    import select
+    import time
+    n = 4 * 131072 + 5000
+    iq = synth.make_iq(n, n_bursts=120, seed=321, n_icao=9, df11_every=4)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    lines = [f"*{w['buffer'].hex()};" for w in want]
+    first = [f"*{w['buffer'].hex()};" for w in want if w["chunk"] == 0]
+    assert len(first) >= 10 and len(lines) > len(first)
+    raw = np.ascontiguousarray(iq[:, ::-1]).tobytes()       # the capture format: im first
+    feed, _ = _start_feed(["--buffers", "64", "--latency-ms", "150"])
+    try:
+        cut = 6 * 131072                                      # one and a half buffers (4 bytes a sample)
+        feed.stdin.write(raw[:cut])
+        feed.stdin.flush()
+        got = b""
+        deadline = time.time() + 20
+        while got.count(b"\n") < len(first) and time.time() < deadline:
+            if select.select([feed.stdout], [], [], 0.2)[0]:
+                got += os.read(feed.stdout.fileno(), 65536)
+        assert got.decode().splitlines() == first, "the first buffer's frames did not come out while the input paused"
+        feed.stdin.write(raw[cut:])
+        feed.stdin.close()
+        got += feed.stdout.read()
+        err = feed.stderr.read().decode()
+        assert feed.wait(timeout=120) == 0, err
+        assert got.decode().splitlines() == lines
+        assert f"{n} samples, {len(lines)} frames in " in err and " 0 short passes" not in err
+    finally:
+        if feed.poll() is None:
+            feed.kill()
+
+
+def test_feed_tool_drops_a_client_that_stops_reading_and_keeps_every_frame(hip_lib, oracle_mod):
+    """One raw-TCP client never reads: once its socket buffer is full it is dropped (the reference drops
+    a client whose write fails, main.rs:184-200) and neither the demodulation nor the other client waits
+    for it.  Every pass yields more frames than the output array starts with (--out-cap 8):
+    adsb_fetch_messages hands out the whole list, nothing is dropped from the reading client's stream."""
+    import socket
+    import threading
+    n = 40 * 131072
+    iq = synth.make_iq(n, n_bursts=16000, seed=77, n_icao=50)
+    packed = synth.noise_numpy(131072, seed=78)                # one buffer of back-to-back short frames
+    synth.add_bursts(packed, [synth.Burst(5 * (150 + 160 * q) + q % 5, 15000, q % 16, synth.df11_frame(0x480000 + q % 900))
+                              for q in range(800)])
+    iq[7 * 131072:8 * 131072] = packed
+    want, _ = oracle_mod.Oracle().demod_iq(iq, cap=1 << 20)
+    lines = [f"*{w['buffer'].hex()};" for w in want]
+    text = "".join(l + "\n" for l in lines)
+    rep = 6
+    assert rep * len(text) > 3 << 20                            # more than the socket buffers of a client that never reads hold
+    raw = np.ascontiguousarray(iq[:, ::-1]).tobytes()
+    feed, connect = _start_feed(["--buffers", "1", "--quiet", "--out-cap", "8"])
+    try:
+        stalled = connect()
+        stalled.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4096)   # and it never calls recv
+        reader = connect()
+        got = []
+
+        def pump():
+            reader.settimeout(60)
+            while True:
+                part = reader.recv(1 << 16)
+                if not part:
+                    break
+                got.append(part)
+        th = threading.Thread(target=pump)
+        th.start()
+        # the stalled client keeps its connection open while ~4 MB more than any socket buffer go by
+        for _ in range(rep):
+            feed.stdin.write(raw)
+        feed.stdin.close()
+        err = feed.stderr.read().decode()
+        assert feed.wait(timeout=300) == 0, err
+        th.join(timeout=60)
+        orc = oracle_mod.Oracle()
+        all_lines = []
+        for _ in range(rep):                                    # the same capture six times over, one filter
+            all_lines += [f"*{w['buffer'].hex()};" for w in orc.demod_iq(iq, cap=1 << 20)[0]]
+        assert b"".join(got).decode().splitlines() == all_lines
+        assert " 1 clients dropped" in err and f"{rep * n} samples, {len(all_lines)} frames in " in err
+        stalled.close()
+        reader.close()
+    finally:
+        if feed.poll() is None:
+            feed.kill()
+
+
 def test_carry_over_mode_recovers_frames_across_buffer_edges(hip_lib, oracle_mod):
     """Opt-in extension, checked against the oracle's restatement of the same
     extension: lead-ins hold the preceding 326 samples, within a call, across calls (blocking,
