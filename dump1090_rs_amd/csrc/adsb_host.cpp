@@ -1885,6 +1885,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.14 gfx950 scan=v7-late-prio tail=v3-buckets"; }
+const char *adsb_version(void) { return "adsb_hip 0.15 gfx950 scan=v8-gate-reads tail=v3-buckets"; }
 
 }  // extern "C"

@@ -58,6 +58,9 @@ using namespace fastgeo;
 #ifndef ADSB_PRIO_LATE
 #define ADSB_PRIO_LATE 1   // wave priority during P3..P5 (0 = leave it alone)
 #endif
+#ifndef ADSB_PRIO_LATE_DENSE
+#define ADSB_PRIO_LATE_DENSE 0  // ... also on dense streams (measured round 3: see DESIGN.md)
+#endif
 #ifndef ADSB_GATE_ASM
 #define ADSB_GATE_ASM 1    // P4: the 19 magnitudes of a match as opaque zero-extended LDS reads (0 = C++ u16 loads)
 #endif
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
 #endif
 
-    const bool late_prio = ADSB_PRIO_LATE != 0 && p.order_cnt == nullptr;
+    const bool late_prio = ADSB_PRIO_LATE != 0 && (ADSB_PRIO_LATE_DENSE != 0 || p.order_cnt == nullptr);
     uint32_t iter = 0;
     for (uint32_t t = t_first; t < t_end; t += t_stride, iter++) {
     const TileRef cur = tile_ref<FROM_MAG>(p, t);

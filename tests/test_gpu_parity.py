@@ -909,6 +909,36 @@ def test_sharded_capture_two_phases_equal_single_stream(hip_lib, oracle_mod):
             c.close()
 
 
+def test_shard_pipeline_overlaps_the_phases_of_consecutive_captures(hip_lib, oracle_mod):
+    """sharding.ShardPipeline: finish + replay of capture i on a worker thread (context i % 2) while the
+    main thread scans capture i + 1 on the other context.  Five different captures through it, each
+    result (a flushed filter per capture) equal to the oracle's, in submission order."""
+    import torch
+    from dump1090_rs_amd import Context, sharding
+    caps = []
+    for k in range(5):
+        n = (3 + k) * 131072 - 1234 * k
+        iq = synth.make_iq(n, n_bursts=40 + 10 * k, seed=600 + k, n_icao=6, df11_every=4)
+        caps.append((n, torch.from_numpy(iq).cuda(), oracle_mod.Oracle().demod_iq(iq)[0]))
+    torch.cuda.synchronize()
+    ctxs = [Context(0, 8), Context(0, 8)]
+    try:
+        pipe = sharding.ShardPipeline(ctxs)
+        got = [pipe.submit(dev.data_ptr(), n, 0) for n, dev, _ in caps]
+        assert got[0] is None and got[1] is None
+        got = got[2:] + pipe.drain()
+        pipe.close()
+        assert len(got) == 5
+        for g, (_, _, want) in zip(got, caps):
+            assert_same(g, want)
+        # the contexts are ordinary ones afterwards
+        ctxs[0].icao_flush()
+        assert_same(ctxs[0].demod_iq_device(caps[0][1].data_ptr(), caps[0][0]), caps[0][2])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_shard_finish_with_a_huge_address_union_overflows_into_the_exact_fallback(hip_lib, oracle_mod):
     """Three quarters of the 24-bit address space handed to adsb_shard_finish: most of the
     shard's address/parity trials now match the superset bitmap, far more than the hit list
