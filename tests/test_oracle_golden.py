@@ -6,7 +6,9 @@ import hashlib
 import numpy as np
 import pytest
 
-from tests.conftest import GOLDEN
+from pathlib import Path
+
+from tests.conftest import GOLDEN, ROOT
 
 
 def test_fixture_files_are_the_reference_captures(golden):
@@ -286,3 +288,50 @@ def test_stage_goldens_are_what_the_oracle_computes(golden, fixture_iq):
         assert now == frozen[fx["file"]], fx["file"]
         assert (now["n_preamble"], now["n_snr"], now["n_cand"], now["n_trials"], now["n_ap"],
                 now["mag_max"][0]) == survey_b[fx["file"]]
+
+
+def test_oracle_under_address_and_ub_sanitizers(golden):
+    """The checker itself under -fsanitize=address,undefined (oracle/Makefile: liboracle_asan.so; the GPU
+    pool offers no device sanitizer, the CPU build does): the three reference captures, a ragged synthetic
+    stream with bursts at buffer edges, single- and multi-threaded, carry-over mode and the all-trials dump
+    -- same answers as the plain build, no report."""
+    import shutil
+    import subprocess
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not Path(asan).exists() or shutil.which("make") is None:
+        pytest.skip("no libasan / make in this environment")
+    code = r'''
+import sys, json, ctypes as C
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import binding
+from dump1090_rs_amd import synth
+import subprocess
+subprocess.run(["make", "-s", "-C", str(binding.HERE), "liboracle_asan.so"], check=True)
+L = binding.load(binding.HERE / "liboracle_asan.so")
+plain = binding.lib()
+golden = json.load(open(%r))
+for fx in golden["fixtures"]:
+    raw = np.fromfile(%r + "/" + fx["file"], dtype="<i2").reshape(-1, 2)
+    iq = np.ascontiguousarray(raw[:, ::-1])
+    got, _ = binding.Oracle(L).demod_iq(iq)
+    assert [m["buffer"].hex() for m in got] == fx["frames"]
+n = 5 * 131072 + 4321
+iq = synth.make_iq(n, n_bursts=80, seed=11, n_icao=5, df11_every=3)
+synth.add_bursts(iq, [synth.Burst(5 * (131072 * k - 60) + k, 20000, k, synth.df17_frame(0x4840D6, k)) for k in range(1, 5)])
+a, _ = binding.Oracle(L).demod_iq(iq)
+assert a == binding.Oracle(plain).demod_iq(iq)[0]
+assert a == binding.Oracle(L).demod_iq(iq, threads=4)[0]
+assert binding.Oracle(L).demod_iq(iq[:400])[0] == binding.Oracle(plain).demod_iq(iq[:400])[0]
+assert binding.Oracle(L).demod_iq(iq[:0])[0] == []
+mb = binding.OrcMagBuf()
+L.orc_to_mag(np.ascontiguousarray(iq[:131072]).ctypes.data, 131072, C.byref(mb))
+buf = (C.c_uint8 * (32 * 5 * 131072 // 8))()
+assert L.orc_all_trials(C.byref(mb), 0, buf, 5 * 131072 // 8) > 0
+print("sanitized oracle ok", len(a))
+''' % (str(ROOT), str(GOLDEN / "reference_frames.json"), str(GOLDEN))
+    env = dict(__import__("os").environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
