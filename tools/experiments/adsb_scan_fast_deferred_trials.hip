@@ -58,6 +58,9 @@ using namespace fastgeo;
 #ifndef ADSB_PRIO_LATE
 #define ADSB_PRIO_LATE 1   // wave priority during P3..P5 (0 = leave it alone)
 #endif
+#ifndef ADSB_PRIO_LATE_DENSE
+#define ADSB_PRIO_LATE_DENSE 0  // ... also on dense streams (measured round 3: see DESIGN.md)
+#endif
 #ifndef ADSB_GATE_ASM
 #define ADSB_GATE_ASM 1    // P4: the 19 magnitudes of a match as opaque zero-extended LDS reads (0 = C++ u16 loads)
 #endif
@@ -84,12 +87,7 @@ static_assert(kAllocSlots <= 8192, "slots fit 13 bits");
 constexpr int kWaves = kThreads / 64;
 constexpr int kPatPerWave = 256;              // a wave's pattern matches (one round)
 constexpr int kRoundBits = 4;                 // plane bits per round when they do not fit: 64 x 4 <= 256
-// A wave's candidates waiting for the trial stage: a ring of slot | plane buffer << 13.  With deferred
-// trials (adsb_scan_geometry.h: kDefer) a tile leaves fewer than 64 trials behind and the next
-// tile's gates add to them.
-constexpr int kCandPerWave = kDefer ? 256 : 128;
-constexpr int kRingTrials = 5 * kCandPerWave;  // the ring in units of (candidate, try_phase)
-static_assert((kCandPerWave & (kCandPerWave - 1)) == 0 && kRingTrials + 64 < 3277, "ring index arithmetic (split5)");
+constexpr int kCandPerWave = 128;             // a wave's candidates waiting for the trial stage
 static_assert(64 * kRoundBits <= kPatPerWave, "wave-private regions");
 constexpr int kHitCap = 32;                   // staged hits per tile (more go straight to HBM)
 
@@ -158,7 +156,7 @@ __device__ __forceinline__ uint32_t lowmask(int n)  // n low bits set, n clamped
 
 struct alignas(16) FastLds {
     uint16_t mag[kAllocSlots];         // P1..P4
-    uint32_t plane[kPlanes * kRowDw];
+    uint32_t plane[kPlanes * kRowDw];  // row = plane buffer 0, then (deferred trials) plane buffer 1
     uint32_t tab[3 * 256];             // F'0 F'1 F'2 (adsb_tables.h)
     uint32_t r16[16];                  // x^24..x^27 reduction
     uint32_t field[300];               // field addressing (adsb_tables.h: build_field_table)
@@ -166,7 +164,7 @@ struct alignas(16) FastLds {
     uint16_t cand[kWaves * kCandPerWave];  // per wave: slot | plane buffer << 13 (cand_entry() expands it for the trial stage)
     uint64_t hit[kHitCap];
     uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
-    uint32_t tile_j[2], tile_chunk[2];  // per plane buffer: jbase - kPad and chunk of the tile whose planes it holds
+    uint32_t tile_j[2], tile_chunk[2];  // per plane buffer: jbase - kPad and buffer number of the tile whose planes it holds
 };
 
 // P4, one pattern match: high / base_signal / base_noise of the branch that matched first
@@ -240,14 +238,15 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32: a ^ b ^ c in one op
 }
 
-// candidate entry: slot | plane bit (slot/12, + 32 kPlaneDw in the second plane buffer) << 13 | slot%12 << 24
+// candidate entry: slot | plane bit (slot/12, + 32 kPlaneDw in the second plane buffer) << 13 | slot%12 << 24 | buffer << 28
 __device__ __forceinline__ uint32_t cand_entry(uint32_t w)
 {
     const uint32_t slot = w & 0x1FFFu;
     const uint32_t qs = (slot * 10923u) >> 17;  // slot / 12 (slot < 16384)
     const uint32_t rs = slot - 12u * qs;
-    const uint32_t qb = kDefer ? qs + __umul24(w >> 13, 32u * kPlaneDw) : qs;
-    return slot | (qb << 13) | (rs << 24) | (kDefer ? (w >> 13) << 28 : 0u);
+    if (!kDefer) return slot | (qs << 13) | (rs << 24);
+    const uint32_t b = w >> 13;
+    return slot | ((qs + __umul24(b, 32u * kPlaneDw)) << 13) | (rs << 24) | (b << 28);
 }
 
 // P5, one trial.  Message bit n = 5k + r of trial phase tp sits at 5x-oversampled position
@@ -446,18 +445,26 @@ __device__ __forceinline__ void compact_matches(uint32_t m, uint32_t code0, uint
 
 // One 64-lane pass of the gates: `ent` is this lane's pattern match (valid lanes only count),
 // passing positions are appended to the wave's candidate region.
+template <bool SELFTEST>
 __device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s, uint32_t ent, bool valid,
                                           uint16_t *wcand, uint32_t &ncand_w, int jbase, uint32_t chunk, uint32_t tag)
 {
     const bool pass = (gate_eval(s.mag, ent) & (uint32_t)valid) != 0;
     const unsigned long long mask = __ballot(pass);
     if (mask) {
-        // (ncand_w: where the next candidate goes -- a plain count, or the ring's write index)
-        if (pass) wcand[mask_rank(mask, ncand_w) & (uint32_t)(kCandPerWave - 1)] = (uint16_t)((ent & 0x1FFFu) | tag);
+        if (pass) wcand[mask_rank(mask, ncand_w)] = (uint16_t)((ent & 0x1FFFu) | tag);
         ncand_w += (uint32_t)__popcll(mask);
-        if (p.cand_out && pass) {  // self-test only: the candidate list itself (adsb_selftest_stage_lists)
+    }
+    if (SELFTEST && p.cand_out && valid) {
+        // self-test instantiation only (adsb_selftest_stage_lists / _gate_stages): every pattern match
+        // that is a preamble by the reference's own sequence of tests goes out as
+        // chunk << 32 | production gate verdict << 30 | stage (1..3, preamble_stage) << 28 | j
+        const int stage = preamble_stage(s.mag + (ent & 0x1FFFu));
+        if (stage | (int)pass) {
             const uint32_t at = atomicAdd(p.cand_count, 1u);
-            if (at < p.cand_cap) p.cand_out[at] = (uint64_t)chunk << 32 | (uint32_t)(jbase - kPad + (int)(ent & 0x1FFFu));
+            if (at < p.cand_cap)
+                p.cand_out[at] = (uint64_t)chunk << 32 | (uint64_t)(pass ? 1u : 0u) << 30 | (uint64_t)stage << 28 |
+                                 (uint32_t)(jbase - kPad + (int)(ent & 0x1FFFu));
         }
     }
 }
@@ -467,14 +474,12 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint
                                            int jbase, uint32_t chunk, uint64_t *seg, uint32_t seg_cap,
                                            uint32_t &ap_count, int lane, uint32_t par)
 {
-    // (jbase / chunk: of the tile this lane's candidate belongs to -- with deferred trials a pass can
-    // hold the previous tile's leftovers beside this tile's)
     Trial tr;
     trial_eval(s, ce, tpi, tr);
     const bool is_ap = live && tr.is_ap, is_hit = live && tr.is_hit, learn = live && tr.learn;
     // entry = value24 | code << 24 | j << 28 | chunk << 45   (adsb_device.h)
     uint32_t j = (uint32_t)(jbase - kPad) + tr.cslot;
-    if (kDefer) {  // the candidate's own tile: by the plane buffer its entry names (bit 28 of ce)
+    if (kDefer) {  // the candidate's own tile (a pass can hold the previous tile's leftovers): by its plane buffer
         const uint32_t b = ce >> 28;
         j = s.tile_j[b] + tr.cslot;
         chunk = s.tile_chunk[b];
@@ -492,13 +497,6 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint
     if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
         if (learn) bitmap_set(p.bitmap, trial_addr(tr));
     }
-}
-
-// t5 = 5 c + tpi for t5 < 3277 (24-bit multiply, not the slow 32-bit one)
-__device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
-{
-    c = __umul24(t5, 13108u) >> 16;
-    tpi = t5 - __umul24(5u, c);
 }
 
 // profiling aids, compiled in with -DADSB_KERNEL_ACCT only (they cost registers):
@@ -528,7 +526,7 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
 // after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
-template <bool FROM_MAG>
+template <bool FROM_MAG, bool SELFTEST = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
@@ -547,7 +545,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     }
     if (tid < kPlanes)  // read slack behind each buffer of a row
         for (int b = 0; b < kPlaneBufs; b++) s.plane[tid * kRowDw + b * kPlaneDw + kPlaneDw - 1] = 0;
-    for (int i = tid; i < kWaves * kCandPerWave; i += kThreads) s.cand[i] = 0;  // (idle lanes of a trial pass read stale entries)
+    for (int i = tid; i < kWaves * kCandPerWave; i += kThreads) s.cand[i] = 0;  // (idle lanes of a trial pass read what is there)
     if (tid < 2) s.nhit[tid] = 0;
 
     const uint32_t seg_cap = p.seg_cap;
@@ -585,42 +583,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_last = acct ? clock64() : 0;
 #endif
 
-    const bool late_prio = ADSB_PRIO_LATE != 0 && p.order_cnt == nullptr;
-    const int wave = tid >> 6;
-    uint16_t *const wpat = s.pat + wave * kPatPerWave;
-    uint16_t *const wcand = s.cand + wave * kCandPerWave;
-    // The wave's ring of candidates (all wave-uniform): `pend` trials wait, the first of them at ring
-    // position t_head (in units of (candidate, try_phase)); the gates write candidates at c_tail.
-    uint32_t pend = 0, t_head = 0, c_tail = 0;
-    uint32_t cur_pbuf = kPlaneBufs - 1;  // plane buffer of the tile processed last
-    // The staged hits of a tile (s.hit, counted in s.nhit[par_]) to the hit list.  Whole workgroup.
-    auto flush_hits = [&](uint32_t par_) {
-        const uint32_t nhit = min(s.nhit[par_], (uint32_t)kHitCap);
-        if (nhit == 0) return;  // the usual case: a handful of hits per chunk
-        if (p.order_cnt) {
-            // dense stream: every hit into its own buffer's bucket (a pass of trials may hold the previous
-            // tile's leftovers, and that tile may belong to another buffer)
-            if (tid == 0) atomicAdd(&p.ctr->n_hits, nhit);
-            for (uint32_t i = tid; i < nhit; i += kThreads) {
-                const uint64_t e = s.hit[i];
-                const uint32_t c = (uint32_t)entry_chunk(e);
-                const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
-                if (k < kOrderBucket) p.order_tmp[(size_t)c * kOrderBucket + k] = e;
-                else atomicOr(&p.ctr->overflow, 1u);
-            }
-        } else {
-            if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
-            lds_barrier();
-            if (s.hit_base + nhit > p.hits_cap) {
-                if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
-            } else {
-                for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
-            }
-        }
-    };
+    const bool late_prio = ADSB_PRIO_LATE != 0 && (ADSB_PRIO_LATE_DENSE != 0 || p.order_cnt == nullptr);
+    // Deferred trials: the candidates a wave still holds (whole ones, fewer than twelve) sit at the front of
+    // its region between tiles; lane l of a trial pass is always (candidate base + l / 5, try_phase 4 + l % 5).
+    uint32_t ncand_w = 0;                 // candidates waiting in the wave's region (wave-uniform)
+    uint32_t cur_pbuf = kPlaneBufs - 1;   // plane buffer of the tile processed last
+    const uint32_t lane_c = __umul24((uint32_t)lane, 13108u) >> 16, lane_tp = (uint32_t)lane - 5u * lane_c;
     uint32_t iter = 0;
-    // (with deferred trials one more turn of the loop after the last tile: nothing but the trials it
-    // left over -- one short pass per wave and launch -- and their hits)
+    // (with deferred trials one more turn of the loop after the last tile: nothing but the trials it left
+    // over -- one short pass per wave and launch -- and their hits)
     bool drain = false;
     for (uint32_t t = t_first;; t += t_stride, iter++) {
     if (t >= t_end) {
@@ -656,7 +627,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
         continue;
     }
 
-    // This tile is processed: it gets the other plane buffer (the trials the previous tile left over
+    // This tile is processed: it gets the other plane buffer (the candidates the previous tile left over
     // still read theirs, and find their tile's position base by it).
     cur_pbuf = kDefer ? cur_pbuf ^ 1u : 0u;
     pbuf = cur_pbuf;
@@ -764,9 +735,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     // is no workgroup barrier and no shared counter between the stages, the waves of a
     // workgroup drift apart, and their latency-bound stages overlap the VALU-dense ones of
     // the others.  Nothing here can overflow: a wave with more matches than its region
-    // holds takes them in rounds of a few plane bits, and the trial stage runs whenever the
-    // ring of candidates could not take another pass of the gates.
+    // holds takes them in rounds of a few plane bits, and candidates are flushed through
+    // the trial stage whenever their region fills.
     {
+    const int wave = tid >> 6;
+    uint16_t *const wpat = s.pat + wave * kPatPerWave;
+    uint16_t *const wcand = s.cand + wave * kCandPerWave;
+
     // ---------------------------------------------------------------- P3 preamble patterns
     // item = (res, w): the 32 positions with slot = 12*(32w + bit) + res.
     // (with 512 threads an item is half a dword, so that all eight waves own positions)
@@ -814,19 +789,14 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
     // all matches in one round when they fit the wave's region (the normal case: ~90 of
     // 256), else rounds of kRoundBits plane bits: at most 64 lanes x kRoundBits matches each
     const int nrounds = total_all <= (uint32_t)kPatPerWave ? 1 : 32 / kRoundBits;
+    if (!kDefer) ncand_w = 0;
+    uint32_t n_old = ncand_w;  // the previous tile's leftovers (fewer than twelve), at the front of the region
+    const uint32_t tag = pbuf << 13;
     if (ADSB_STOP_AT(p, 3)) goto tile_end;  // profiling: patterns only
 
     // One loop, one copy of each stage: take the next round of matches when the previous one
-    // is used up, run one 64-lane pass of the gates while the ring has room for what it may add,
-    // else one pass of the trials.  Trials run in FULL passes: what a tile leaves over (fewer than
-    // 64, a fifth of a pass's worth of candidates on average) waits in the ring and runs with the
-    // next tile's -- 1.6 passes per tile instead of 2.1 (a tile's ~20 candidates are 100 trials).  The
-    // leftovers are the oldest entries of the ring, so the next tile's first pass takes them all;
-    // a tile with too few candidates of its own to fill that pass runs it short, because the tile
-    // after it overwrites the plane buffer they read.
-    const uint32_t old_trials = pend;  // the previous tile's leftovers (< 64)
-    uint32_t taken = 0;                // trials run during this tile
-    const uint32_t tag = pbuf << 13;
+    // is used up, run one 64-lane pass of the gates, and run the trials whenever the
+    // candidate region could not take another pass's worth (or nothing else is left).
     int round = 0;
     uint32_t npat_w = 0, base = 0;
     bool in_round = false;
@@ -853,45 +823,62 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_s
                 in_round = true;
                 base = 0;
             }
-            // room in the ring for the 64 candidates a pass of the gates can add (a pending trial
-            // may be the last of its candidate: + 4)
-            if (pend + 5u * 64u + 4u <= (uint32_t)kRingTrials) {
-                // -------------------------------------------------------- P4 value gates
-                // one lane per pattern match (gate_pass)
+
+            // ------------------------------------------------------------ P4 value gates
+            // one lane per pattern match (gate_pass)
+            {
                 const uint32_t idx = base + (uint32_t)lane;
-                const uint32_t before = c_tail;
-                gate_pass(p, s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, c_tail, jbase, chunk, tag);
-                pend += 5u * (c_tail - before);
-                cand_count += c_tail - before;
-                base += 64;
-                if (base >= npat_w) {
-                    in_round = false;
-                    round++;
-                }
-                continue;
+                const uint32_t before = ncand_w;
+                gate_pass<SELFTEST>(p, s, wpat[min(idx, npat_w - 1u)], idx < npat_w, wcand, ncand_w, jbase, chunk, tag);
+                cand_count += ncand_w - before;
             }
-        } else if (ADSB_STOP_AT(p, 4)) {  // profiling: gates only
-            pend = 0;
-            t_head = 5u * (c_tail & (uint32_t)(kCandPerWave - 1));
-            break;
-        } else if (pend < 64u && (pend == 0 || (kDefer && !drain && taken >= old_trials))) {
-            break;  // the gates are through, less than a pass is left and none of it is the previous tile's
+            base += 64;
+            if (base >= npat_w) {
+                in_round = false;
+                round++;
+            }
+            // room for another pass of the gates and more of them to come: not yet
+            if (round < nrounds && ncand_w + 64 <= (uint32_t)kCandPerWave) continue;
         }
+        if (ncand_w == 0) {
+            if (round >= nrounds) break;
+            continue;
+        }
+        wave_lds_fence();
+        if (ADSB_STOP_AT(p, 4)) {  // profiling: gates only
+            ncand_w = 0;
+            if (round >= nrounds) break;
+            continue;
+        }
+
         // ---------------------------------------------------------------- P5 trials
-        // lane = (candidate, try_phase) (trial_pass)
-        wave_lds_fence();  // the candidates the gates wrote
+        // lane = (candidate, try_phase) (trial_pass).  Whole passes only: twelve candidates x five trial
+        // phases = 60 lanes, so that what is left over is whole candidates; fewer than twelve stay in the
+        // region for the next tile (1.7 passes per tile instead of 2.1: a tile's ~20 candidates are 100
+        // trials).  The previous tile's leftovers are the first entries, so this tile's first pass takes
+        // them all; a tile that cannot fill that pass runs it short, because the tile after it overwrites
+        // the plane buffer they read.  (Without deferral: the last pass of a tile is the short one.)
         {
-            const uint32_t take = min(pend, 64u);
-            uint32_t T = t_head + (uint32_t)lane;
-            T = min(T, T - (uint32_t)kRingTrials);  // mod kRingTrials (unsigned wrap-around)
-            uint32_t c, tpi;
-            split5(T, c, tpi);
-            trial_pass(p, s, cand_entry(wcand[c]), tpi, (uint32_t)lane < take, jbase, chunk, seg, seg_cap, ap_count, lane, par);
-            t_head += take;
-            if (t_head >= (uint32_t)kRingTrials) t_head -= (uint32_t)kRingTrials;
-            pend -= take;
-            taken += take;
+            const bool last = round >= nrounds;   // the gates are through with this tile
+            uint32_t done = 0;
+            while (ncand_w - done >= 12u || (ncand_w > done && (!kDefer || drain || done < n_old || !last))) {
+                const uint32_t take = min(12u, ncand_w - done);
+                trial_pass(p, s, cand_entry(wcand[min(done + lane_c, (uint32_t)kCandPerWave - 1u)]), lane_tp, lane_c < take, jbase, chunk, seg, seg_cap,
+                           ap_count, lane, par);
+                done += take;
+            }
+            const uint32_t left = ncand_w - done;  // (< 12, and none of them the previous tile's)
+            if (left && done) {
+                // move them to the front: a dozen 16-bit entries, read by all lanes before any writes
+                const uint16_t v = wcand[min(done + (uint32_t)lane, (uint32_t)kCandPerWave - 1u)];
+                wave_lds_fence();
+                if ((uint32_t)lane < left) wcand[lane] = v;
+            }
+            ncand_w = left;
+            n_old = 0;
+            wave_lds_fence();  // wcand is reused by the next passes of the gates
         }
+        if (round >= nrounds) break;
     }
     }
 tile_end:
@@ -907,7 +894,29 @@ tile_end:
 
     // ---------------------------------------------------------------- tile epilogue
     // (the AP fill counts are registers; they are written back when the workgroup retires)
-    flush_hits(par);
+    const uint32_t nhit = min(s.nhit[par], (uint32_t)kHitCap);
+    if (nhit) {  // rare: a handful per chunk
+        if (p.order_cnt) {
+            // dense stream: every hit into its own buffer's bucket (a pass of trials may hold the previous
+            // tile's leftovers, and that tile may belong to another buffer)
+            if (tid == 0) atomicAdd(&p.ctr->n_hits, nhit);
+            for (uint32_t i = tid; i < nhit; i += kThreads) {
+                const uint64_t e = s.hit[i];
+                const uint32_t c = (uint32_t)entry_chunk(e);
+                const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
+                if (k < kOrderBucket) p.order_tmp[(size_t)c * kOrderBucket + k] = e;
+                else atomicOr(&p.ctr->overflow, 1u);
+            }
+        } else {
+            if (tid == 0) s.hit_base = atomicAdd(&p.ctr->n_hits, nhit);
+            lds_barrier();
+            if (s.hit_base + nhit > p.hits_cap) {
+                if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
+            } else {
+                for (uint32_t i = tid; i < nhit; i += kThreads) p.hits[s.hit_base + i] = s.hit[i];
+            }
+        }
+    }
     ACCT(6);
     STAMP(6);
     }  // tile loop
@@ -962,7 +971,9 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
     const uint32_t blocks = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
     // With events, the launch itself carries them (hipExtLaunchKernelGGL): the dispatch
     // packet's own begin/end timestamps, no barrier packets in the stream around it.
-    if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
+    if (p.cand_out)  // the self-test's instantiation: also writes the gate-stage position list
+        hipLaunchKernelGGL((k_scan_fast<false, true>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
         hipLaunchKernelGGL(k_scan_fast<true>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     else if (p.ev_start && p.ev_stop)
         hipExtLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,

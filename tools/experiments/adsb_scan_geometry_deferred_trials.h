@@ -20,10 +20,11 @@ constexpr int kPlaneBytes = (kPlaneBits + 7) / 8;      // 84
 static_assert(kPlaneBytes % 4 == 0, "planes are whole dwords");
 constexpr int kPlaneDw = kPlaneBytes / 4 + 1;          // 22: one dword of read slack (always zero)
 
-// P5 runs full 64-lane passes only; the trials a tile leaves over wait for the next tile's and run
-// beside them, on the planes of their own tile: the planes are double-buffered, and a row holds
-// buffer 0, then buffer 1 (adsb_scan_fast.hip).  -DADSB_DEFER_TRIALS=0 builds the round-2 form
-// (one buffer, every tile finishes its own trials) for A/B measurements.
+// P5 runs whole passes only (twelve candidates x five trial phases = 60 of a wave's 64 lanes); the
+// candidates a tile leaves over wait for the next tile's and run with them, on the planes of their
+// own tile: the planes are double-buffered, and a row holds buffer 0, then buffer 1
+// (adsb_scan_fast.hip).  -DADSB_DEFER_TRIALS=0 builds the form in which every tile finishes its own
+// trials (one buffer), for A/B measurements.
 #ifndef ADSB_DEFER_TRIALS
 #define ADSB_DEFER_TRIALS 1
 #endif
