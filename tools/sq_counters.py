@@ -126,9 +126,11 @@ def main():
         }
     except (KeyError, ZeroDivisionError) as e:
         out["valu_roofline_error"] = repr(e)
-    out["raw_rows_first_launches"] = raw
     dst = ROOT / "gpurun_out" / tag / "sq_counters.json"
-    dst.write_text(json.dumps(out, indent=1))
+    # (the raw rows one per line: the file stays readable and diffable)
+    head = json.dumps(out, indent=1)
+    rows = ",\n".join("  " + json.dumps(r, separators=(",", ":")) for r in raw)
+    dst.write_text(head[:-2] + ',\n "raw_rows_first_launches": [\n' + rows + "\n ]\n}\n")
     print(json.dumps({k: out[k] for k in ("per_launch_avg", "valu_roofline", "bench_lines") if k in out}, indent=1))
 
 
