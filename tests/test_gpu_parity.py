@@ -1439,3 +1439,32 @@ def test_abi_misuse_is_refused_not_crashed(hip_lib):
     assert bytes(big[0].msg) == bytes(out[0].msg) and bytes(big[1].msg) == bytes(out[1].msg)
     L.adsb_destroy(h)
     L.adsb_destroy(None)
+
+
+def test_bench_line_keeps_the_driver_contract(hip_lib, oracle_mod):
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver reads:
+    the metric / value / unit block, `roofline` (bound, achieved, peak, unit, frac, traffic) for the
+    dominant kernel, `cpu_baseline` (value, unit, cores, kind, sample) and the parity flag -- checked on a
+    small workload (32 buffers, no ramp, no extra legs)."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--chunks", "32",
+                        "--ramp-ms", "0", "--no-also"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "IQ Msamples/s demodulated" and d["unit"] == "Msamples/s" and d["higher_is_better"] is True
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["data"], d["vs_baseline"]) == (1, 4, 2, "weak", "synthetic", None)
+    assert d["value"] > 0 and abs(d["value"] - 32 * 131072 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
+    assert "workload" in d["config"] and "model" not in d["config"] and isinstance(d["dtype"], str)
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_scan_fast"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 0 and "traffic" in rf
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_avg_ms"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
+    assert rf["algorithmic_bytes_per_launch"] == 4 * 32 * 131072 and rf["sustained"]["frac_over_steps"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["sample"]
+    assert d["parity_checked"] is True and d["parity_frames"] > 0 and d["per_rank_ms_per_step"] and d["world_size_seen"] == 1
