@@ -56,6 +56,10 @@ def parse(argv=None):
                          "shard: one capture of N x --chunks buffers cut into contiguous ranges (config 4)")
     ap.add_argument("--chunks", type=int, default=512, help="131072-sample buffers per step (and per GPU)")
     ap.add_argument("--buffers", type=int, default=3, help="distinct IQ buffers rotated over")
+    ap.add_argument("--capture-chunks", type=int, default=4096,
+                    help="--workload shard: buffers in the ONE capture that is cut into N contiguous ranges "
+                         "(BASELINE config 4: 8 x the 256 MiB buffer = 2 GiB = 4096; the total is fixed, so the "
+                         "line says scaling: strong)")
     ap.add_argument("--ramp-ms", type=float, default=120.0,
                     help="untimed passes of the same workload before the W warm-up steps, for this long: the "
                          "GPU raises its clocks over ~50 ms of sustained load (a pass is 0.1 ms), and a stream "
@@ -665,17 +669,21 @@ def run_shard(env: Env, args):
     torch = env.torch
     from dump1090_rs_amd import Context, sharding, synth, _lib
 
-    n = args.chunks * CHUNK
-    n_bursts = max(1, 64 * args.chunks // 512)
+    total_chunks = max(env.world, args.capture_chunks)
+    ranges = [sharding.chunk_range(total_chunks, env.world, r) for r in range(env.world)]
+    first, last = ranges[env.rank]
+    n = (last - first) * CHUNK
 
     def shard_iq(r, device):
-        return synth.make_iq_torch(n, n_bursts=n_bursts, seed=synth.SEED_DEFAULT + 31 * r, device=device)
+        k = ranges[r][1] - ranges[r][0]
+        return synth.make_iq_torch(k * CHUNK, n_bursts=max(1, 64 * k // 512), seed=synth.SEED_DEFAULT + 31 * r, device=device)
 
     mine = shard_iq(env.rank, env.dev)
     torch.cuda.synchronize()
     # (each context on its own stream: the worker thread's finish must not wait for the other context's scan)
-    ctxs = [Context(device=env.local_rank, max_chunks=args.chunks) for _ in range(2)]
-    base = env.rank * args.chunks
+    max_chunks = max(b - a for a, b in ranges)
+    ctxs = [Context(device=env.local_rank, max_chunks=max_chunks) for _ in range(2)]
+    base = first
 
     def blocking_step():
         ctxs[0].icao_flush()
@@ -720,28 +728,29 @@ def run_shard(env: Env, args):
     same, n_frames = None, None
     if env.rank == 0:
         whole = torch.cat([mine] + [shard_iq(r, env.dev) for r in range(1, env.world)]) if env.world > 1 else mine
-        with Context(device=env.local_rank, max_chunks=args.chunks) as solo:
+        with Context(device=env.local_rank, max_chunks=min(512, total_chunks)) as solo:
             solo.icao_flush()
-            want = solo.demod_iq_device(whole.data_ptr(), n * env.world, cap=1 << 20)
+            want = solo.demod_iq_device(whole.data_ptr(), total_chunks * CHUNK, cap=1 << 20)
         key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
         same = [key(m) for m in merged] == [key(m) for m in want] and results == args.steps
         n_frames = len(want)
         del whole
     elapsed, frames = env.reduce(elapsed, frames)
     result = {
-        "metric": "IQ Msamples/s demodulated", "value": round(n * env.world * args.steps / elapsed / 1e6, 1),
+        "metric": "IQ Msamples/s demodulated", "value": round(total_chunks * CHUNK * args.steps / elapsed / 1e6, 1),
         "unit": "Msamples/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "ms_per_step_two_blocking_phases": round(env.reduce(blocking_ms / 1e3, 0)[0] * 1e3, 4),
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
         "backend": env.backend if env.world > 1 else None, "world_size_seen": env.world,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        # the capture is the same whatever N is: total work fixed, per-GPU work = 1 / N of it
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "frames_per_s": round(frames / elapsed, 1),
-        "config": {"workload": f"one capture of {env.world} x {args.chunks} buffers = {env.world * n * 4 // (1 << 20)} MiB "
-                               f"cut into {env.world} contiguous ranges of {args.chunks} buffers, one per GPU, resident in "
-                               "HBM (BASELINE config 4); a step = icao_flush + shard scan on every rank + host-side "
+        "config": {"workload": f"one capture of {total_chunks} buffers = {total_chunks * CHUNK * 4 // (1 << 20)} MiB "
+                               f"cut into {env.world} contiguous ranges ({', '.join(str(b - a) for a, b in ranges)} buffers), "
+                               "one per GPU, resident in HBM (BASELINE config 4); a step = icao_flush + shard scan on every rank + host-side "
                                "exchange of learned addresses + match + records gathered and replayed once on rank 0",
-                   "per_gpu_samples_per_step": n,
+                   "per_gpu_samples_per_step": [(b - a) * CHUNK for a, b in ranges],
                    "sharding": "contiguous buffer ranges, the IQ never moves; learned addresses and trial records "
                                "exchanged as host tensors over gloo groups (no RCCL collective on the data path; "
                                "torch.distributed's default group only carries the barrier and the timing reduction)",

@@ -1605,6 +1605,7 @@ namespace {
 // in the fallback's host buffer (c->fb.h_rec) with chunk = 0; *n_out = how many.
 int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, uint32_t *clean, size_t *n_out)
 {
+    HIP_TRY(c, hipSetDevice(c->device));
     Slot &sl = c->slot[0];
     if (int rc = ensure_fallback(c)) return rc;
     const uint64_t off = ch * kChunkSamples;
@@ -1656,6 +1657,8 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
     if ((uintptr_t)device_iq % 16) return ADSB_ERR_INVALID;
+    // (the caller may be a worker thread whose current device is not this context's: sharding.ShardPipeline)
+    HIP_TRY(c, hipSetDevice(c->device));
     Slot &sl = c->slot[0];
     ScanParams p{};
     p.src = device_iq;
@@ -1740,6 +1743,7 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
     if (!c || (!extra_addrs && n_extra) || (!records_out && cap)) return ADSB_ERR_INVALID;
     if (!c->shard_active) return ADSB_ERR_INVALID;
     if (n_records) *n_records = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
     Slot &sl = c->slot[0];
     ScanParams p = c->shard_params;
     p.keep_counters = 0;

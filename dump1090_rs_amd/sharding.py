@@ -279,14 +279,22 @@ def plan_affinity(local_rank: int, local_world: int, gpus: Sequence[Tuple[str, i
     allowed = sorted(set(allowed))
     order = list(visible) if visible else list(range(len(gpus)))
 
+    def device_of(r: int) -> int:
+        """the visible device rank r runs on: more ranks than GPUs (an oversubscribed gloo run) wrap
+        around, as bench.py's Env does (local_rank % device_count)"""
+        return r % len(order) if order else -1
+
     def node_of(r: int) -> int:
-        if r < len(order) and 0 <= order[r] < len(gpus):
-            return gpus[order[r]][1]
+        d = device_of(r)
+        if d >= 0 and 0 <= order[d] < len(gpus):
+            return gpus[order[d]][1]
         return -1
 
     node = node_of(local_rank)
     cpus = [c for c in node_cpus.get(node, ()) if c in set(allowed)] if node >= 0 else []
     if cpus:
+        # every rank whose (effective) GPU hangs off this node shares the node's cores -- ranks that
+        # share a GPU included
         sharers = [r for r in range(local_world) if node_of(r) == node]
         k, m, source = sharers.index(local_rank), len(sharers), "numa node of the rank's GPU"
     else:
@@ -295,8 +303,9 @@ def plan_affinity(local_rank: int, local_world: int, gpus: Sequence[Tuple[str, i
     mine = cpus[k * per:(k + 1) * per] if k < m - 1 else cpus[k * per:]
     if not mine:
         mine = cpus
+    d = device_of(local_rank)
     return {"numa_node": node, "cpus": mine, "ranks_on_node": m, "source": source,
-            "gpu": gpus[order[local_rank]][0] if local_rank < len(order) and 0 <= order[local_rank] < len(gpus) else None}
+            "gpu": gpus[order[d]][0] if d >= 0 and 0 <= order[d] < len(gpus) else None}
 
 
 def pin_to_gpu_numa_node(local_rank: int, local_world: int, sysfs: str = "/sys") -> dict:

@@ -72,46 +72,43 @@ def lib() -> C.CDLL:
 
 
 def _bind(L: C.CDLL) -> C.CDLL:
-    if True:
-        if True:
-            pass
-        vp, sz = C.c_void_p, C.c_size_t
-        L.orc_icao_flush.argtypes = [vp]
-        L.orc_icao_hash.argtypes = [C.c_uint32]
-        L.orc_icao_hash.restype = C.c_uint32
-        L.orc_icao_filter_add.argtypes = [vp, C.c_uint32]
-        L.orc_icao_filter_test.argtypes = [vp, C.c_uint32]
-        L.orc_icao_filter_test.restype = C.c_int
-        L.orc_crc_table_entry.argtypes = [C.c_uint]
-        L.orc_crc_table_entry.restype = C.c_uint32
-        L.orc_modes_checksum.argtypes = [vp, sz]
-        L.orc_modes_checksum.restype = C.c_uint32
-        L.orc_getbits.argtypes = [vp, sz, sz]
-        L.orc_getbits.restype = sz
-        L.orc_score_modes_message.argtypes = [vp, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int32)]
-        L.orc_score_modes_message.restype = C.c_int
-        L.orc_to_mag.argtypes = [vp, sz, vp]
-        L.orc_to_mag.restype = C.c_int
-        L.orc_mag_sample.argtypes = [C.c_int16, C.c_int16]
-        L.orc_mag_sample.restype = C.c_uint16
-        L.orc_check_preamble.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        L.orc_check_preamble.restype = C.c_int
-        L.orc_slice_phase.argtypes = [vp, sz, C.c_int, vp]
-        L.orc_slice_phase.restype = None
-        L.orc_demodulate2400.argtypes = [vp, vp, C.c_uint64, vp, sz, vp]
-        L.orc_demodulate2400.restype = sz
-        L.orc_demod_iq.argtypes = [vp, vp, sz, vp, sz, vp]
-        L.orc_demod_iq.restype = sz
-        L.orc_demod_iq_carry.argtypes = [vp, vp, sz, vp, sz, vp, vp]
-        L.orc_demod_iq_carry.restype = sz
-        L.orc_demod_iq_mt.argtypes = [vp, vp, sz, vp, sz, vp, C.c_int]
-        L.orc_demod_iq_mt.restype = sz
-        L.orc_read_test_data.argtypes = [C.c_char_p, vp, sz]
-        L.orc_read_test_data.restype = C.c_long
-        L.orc_mag_x_digest.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
-        L.orc_mag_x_digest.restype = C.c_uint64
-        L.orc_all_trials.argtypes = [vp, C.c_uint64, vp, sz]
-        L.orc_all_trials.restype = sz
+    vp, sz = C.c_void_p, C.c_size_t
+    L.orc_icao_flush.argtypes = [vp]
+    L.orc_icao_hash.argtypes = [C.c_uint32]
+    L.orc_icao_hash.restype = C.c_uint32
+    L.orc_icao_filter_add.argtypes = [vp, C.c_uint32]
+    L.orc_icao_filter_test.argtypes = [vp, C.c_uint32]
+    L.orc_icao_filter_test.restype = C.c_int
+    L.orc_crc_table_entry.argtypes = [C.c_uint]
+    L.orc_crc_table_entry.restype = C.c_uint32
+    L.orc_modes_checksum.argtypes = [vp, sz]
+    L.orc_modes_checksum.restype = C.c_uint32
+    L.orc_getbits.argtypes = [vp, sz, sz]
+    L.orc_getbits.restype = sz
+    L.orc_score_modes_message.argtypes = [vp, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int32)]
+    L.orc_score_modes_message.restype = C.c_int
+    L.orc_to_mag.argtypes = [vp, sz, vp]
+    L.orc_to_mag.restype = C.c_int
+    L.orc_mag_sample.argtypes = [C.c_int16, C.c_int16]
+    L.orc_mag_sample.restype = C.c_uint16
+    L.orc_check_preamble.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.orc_check_preamble.restype = C.c_int
+    L.orc_slice_phase.argtypes = [vp, sz, C.c_int, vp]
+    L.orc_slice_phase.restype = None
+    L.orc_demodulate2400.argtypes = [vp, vp, C.c_uint64, vp, sz, vp]
+    L.orc_demodulate2400.restype = sz
+    L.orc_demod_iq.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.orc_demod_iq.restype = sz
+    L.orc_demod_iq_carry.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+    L.orc_demod_iq_carry.restype = sz
+    L.orc_demod_iq_mt.argtypes = [vp, vp, sz, vp, sz, vp, C.c_int]
+    L.orc_demod_iq_mt.restype = sz
+    L.orc_read_test_data.argtypes = [C.c_char_p, vp, sz]
+    L.orc_read_test_data.restype = C.c_long
+    L.orc_mag_x_digest.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.orc_mag_x_digest.restype = C.c_uint64
+    L.orc_all_trials.argtypes = [vp, C.c_uint64, vp, sz]
+    L.orc_all_trials.restype = sz
     return L
 
 

@@ -314,6 +314,13 @@ def test_rank_affinity_plan_follows_the_gpus_numa_nodes(tmp_path):
     assert p["numa_node"] == 0 and p["cpus"] == list(range(0, 16)) and p["gpu"] == "0000:20:00.0"
     assert sharding.visible_devices({"HIP_VISIBLE_DEVICES": "3,1"}) == [3, 1]
     assert sharding.visible_devices({"ROCR_VISIBLE_DEVICES": "GPU-abc"}) is None and sharding.visible_devices({}) is None
+    # more ranks than GPUs (eight gloo ranks on a one-GPU box): rank r runs on device r % 1, and the eight
+    # share that GPU's node cores in disjoint parts instead of overlapping rank 0's
+    one = gpus[:1]
+    plans = [sharding.plan_affinity(r, 8, one, node_cpus, range(256)) for r in range(8)]
+    assert all(p["numa_node"] == 0 and p["ranks_on_node"] == 8 and p["gpu"] == "0000:10:00.0" for p in plans)
+    assert all(p["source"].startswith("numa node") and len(p["cpus"]) == 16 for p in plans)
+    assert sum(len(p["cpus"]) for p in plans) == len(set().union(*[set(p["cpus"]) for p in plans])) == 128
     # no sysfs at all: even split of what the process may run on
     p = sharding.plan_affinity(2, 4, [], {}, range(8))
     assert p["cpus"] == [4, 5] and p["numa_node"] == -1
