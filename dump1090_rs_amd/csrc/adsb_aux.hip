@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void k_records(ScanParams p, TrialRecord *rec)
         __syncthreads();
         if (threadIdx.x < 2 * cnt) {
             // a pass that k_score takes over keeps its records in HBM: the host only wants them when
-            // it cannot use the device's result, and fetches them then (adsb_host.cpp: finish_pass)
+            // it cannot use the device's result, and fetches them then (adsb_collect.cpp: finish_pass)
             if (do_score)
                 ((u32x4_t *)(p.score.rec + b0))[threadIdx.x] = ((const u32x4_t *)stage)[threadIdx.x];
             else

@@ -1,0 +1,378 @@
+// adsb_collect.cpp -- waiting for a pass, its checksums, the ordered host replay (src/demod_2400.rs:149-207 with
+// src/mode_s/mod.rs:34-139 scoring against src/icao_filter.rs), and the overflow fallback.
+#include "adsb_ctx.h"
+
+using namespace adsb::host;
+
+namespace {
+
+// Ordered replay (src/demod_2400.rs:149-207 with mode_s scoring): records sorted by
+// (chunk, j, try_phase); per (chunk, j) the best trial by strictly-greater score
+// starting from -2 wins and is emitted when its score is >= 0.
+inline uint64_t replay_key(const TrialRecord &r)
+{
+    return (uint64_t)r.chunk << 32 | (uint64_t)(r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24);
+}
+
+// The pass's messages as the device scored them, when they can be taken as they are: scored in the
+// current epoch, whole (checksum), and with the filter nowhere near full -- the one situation whose
+// reference behaviour (icao_filter_add gives up on a full table, src/icao_filter.rs:46-62) the parallel
+// formulation does not reproduce.  Applies the pass's additions to the host's filter, in order.
+bool take_device_result(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, std::vector<adsb_msg> &out)
+{
+    if (!sl.device_scored || sl.score_epoch != c->score_epoch) return false;
+    const ScoreSummary *ss = sl.h_ssum;
+    if (__atomic_load_n(&ss->seq, __ATOMIC_ACQUIRE) != sl.seq || !ss->scored) return false;
+    const size_t nm = ss->n_msgs, na = ss->n_adds;
+    if (nm > c->score.cap || na > c->score.cap) return false;
+    size_t held = 0;
+    for (uint32_t a : c->filter.table()) held += a != 0;
+    if (held + na + 64 >= IcaoFilter::kSize) return false;
+    const uint64_t want = (uint64_t)ss->msg_sum_hi << 32 | ss->msg_sum_lo;
+    bool whole = false;
+    for (int attempt = 0; attempt < 200 && !whole; attempt++) {
+        uint64_t got = 0;
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(sl.h_msgs);
+        for (size_t i = 0; i < 5 * nm; i++) got += __atomic_load_n(&w[i], __ATOMIC_RELAXED);
+        whole = got == want;
+    }
+    if (!whole) return false;
+    const size_t at = out.size();
+    out.insert(out.end(), sl.h_msgs, sl.h_msgs + nm);
+    if (chunk_offset)
+        for (size_t i = at; i < out.size(); i++) out[i].chunk += chunk_offset;
+    for (size_t i = 0; i < na; i++) c->filter.add(sl.h_adds[i]);
+    return true;
+}
+
+}  // namespace
+
+namespace adsb {
+namespace host {
+
+void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out, uint64_t *host_sorts)
+{
+    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
+    // else is put in order here -- the records stay where they are (they may sit in mapped host
+    // memory), only 16-byte (key, index) pairs are sorted.
+    struct Ref {
+        uint64_t key;
+        uint32_t idx;
+    };
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i++) sorted = replay_key(rec[i - 1]) <= replay_key(rec[i]);
+    std::vector<Ref> order;
+    if (!sorted) {
+        if (host_sorts) ++*host_sorts;
+        order.resize(n);
+        uint64_t all_or = 0;
+        for (size_t i = 0; i < n; i++) {
+            order[i] = {replay_key(rec[i]), (uint32_t)i};
+            all_or |= order[i].key;
+        }
+        // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
+        // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
+        std::vector<Ref> tmp(n);
+        Ref *src = order.data(), *dst = tmp.data();
+        for (int shift = 0; shift < 64; shift += 11) {
+            if (((all_or >> shift) & 0x7FFu) == 0) continue;
+            uint32_t count[2048] = {0};
+            for (size_t i = 0; i < n; i++) count[(src[i].key >> shift) & 0x7FFu]++;
+            uint32_t at = 0;
+            for (uint32_t &c : count) {
+                const uint32_t k = c;
+                c = at;
+                at += k;
+            }
+            for (size_t i = 0; i < n; i++) dst[count[(src[i].key >> shift) & 0x7FFu]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != order.data()) order.swap(tmp);
+    }
+    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i].idx]; };
+    size_t i = 0;
+    while (i < n) {
+        const uint64_t pos = replay_key(at(i)) >> 8;  // (chunk, j)
+        const TrialRecord *best = nullptr;
+        Score best_score{false, (int)ADSB_MODES_SHORT_MSG_BYTES, -2};
+        for (; i < n; i++) {
+            const TrialRecord &r = at(i);
+            if ((replay_key(r) >> 8) != pos) break;
+            // records built on the device bring the CRC residual along (pad bit 0) and the filter
+            // hash of the value their DF asks about (pad bit 1, hash in bits 4..15)
+            const Score s = (r.pad & 1) ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg,
+                                                              (r.pad & 2) ? (int)(r.pad >> 4) : -1)
+                                        : score_modes_message(filter, crc, r.msg);
+            if (!s.some || s.value <= best_score.value) continue;
+            best = &r;
+            best_score = s;
+        }
+        if (!best || best_score.value < 0) continue;
+        adsb_msg m{};
+        std::memcpy(m.msg, best->msg, 14);
+        m.len = (uint8_t)best_score.len;
+        m.score = best_score.value;
+        m.try_phase = (uint8_t)(best->j_tp >> 24);
+        // demod_2400.rs:191-198: signal_len = 14*12/5 = 33 (the same three divisions, in this order)
+        const double signal_power = (double)(best->power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
+        m.signal_level = signal_power / 33.0;
+        m.j = (uint32_t)(pos & 0xFFFFFFu);
+        m.chunk = chunk_offset + (pos >> 24);
+        out.push_back(m);
+    }
+}
+
+// The records and the summary travel to host memory as separate posted writes; the summary's
+// sequence word says the pass is done, this says every one of its records has landed whole: the
+// 64-bit sum of all their u64 words, as the records kernel added them up.  (Records that are still
+// in flight when the completion event has fired would be a platform fault: give them a moment,
+// then fail loudly rather than replay something torn.)
+int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size_t n)
+{
+    const uint64_t want = (uint64_t)sum->rec_sum_hi << 32 | sum->rec_sum_lo;
+    for (int attempt = 0; attempt < 200; attempt++) {
+        uint64_t got = 0;
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(rec);
+        for (size_t i = 0; i < 4 * n; i++) got += __atomic_load_n(&w[i], __ATOMIC_RELAXED);
+        if (got == want) return ADSB_OK;
+        for (volatile int spin = 0; spin < 2000; spin++) {}
+    }
+    if (c) c->last_error = "trial records in host memory do not add up to the checksum of the pass that wrote them";
+    return ADSB_ERR_HIP;
+}
+
+// Wait for the pass in `sl` and replay it.  Returns 1 when a device list overflowed
+// (caller re-runs in smaller pieces), 0 on success, < 0 on error.
+int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out)
+{
+#ifdef ADSB_TUNING
+    const auto tw0 = std::chrono::steady_clock::now();
+#endif
+    HIP_TRY(c, hipEventSynchronize(sl.done));
+#ifdef ADSB_TUNING
+    c->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+#endif
+    if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
+        c->last_error = "pass completed without publishing its summary";
+        return ADSB_ERR_HIP;
+    }
+    if (sl.h_sum->overflow) return 1;
+    const size_t n = sl.h_sum->n_hits;
+    // (k_records' own test: a pass that k_score took over has left its records in device memory)
+    const bool rec_on_device = sl.device_scored && n <= c->score.cap;
+    if (!rec_on_device)
+        if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    if (sl.profiled) {
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
+        st.ms_scan += ms;
+        // The device time this launch adds: the part of it after the latest scan end seen so far (the
+        // "frontier": normally the previous pass's; scans on the two scan streams can also finish out of
+        // order, and one that ended before the frontier adds nothing -- the union of the launches'
+        // intervals is what is being summed).  The frontier's events are intact for kScanEvRing - kSlots
+        // passes back: the ring is that much longer than what can be in flight.
+        float excl = ms;
+        bool advance = true;
+        if (c->last_stop && sl.scan_seq - c->last_scan_seq <= (uint64_t)(kScanEvRing - kSlots)) {
+            float since = 0;
+            if (hipEventElapsedTime(&since, c->last_stop, sl.ev[1]) == hipSuccess) {
+                if (since <= 0) {
+                    excl = 0;
+                    advance = false;
+                } else if (since < excl) {
+                    excl = since;
+                }
+            }
+        }
+        st.ms_scan_exclusive += excl;
+        if (advance) {
+            c->last_stop = sl.ev[1];
+            c->last_scan_seq = sl.scan_seq;
+        }
+        if (sl.profiled > 1) {  // per-kernel split of the tail (events cost a few us each)
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
+            st.ms_match += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]));
+            st.ms_records += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[4]));
+            st.ms_total_device += ms;
+        }
+    }
+    st.n_candidates += sl.h_sum->n_cand_total;
+    st.n_ap_entries += sl.h_sum->n_ap_total;
+    st.n_records += n;
+    // Density is records per buffer (8 and more: device-side order + score; under 2: the host does
+    // it), so that a context of 64 buffers decides like one of 512.  Passes too small to be ordered on
+    // the device anyway (and the fallback's one-buffer passes) say nothing about the stream: a small
+    // pass between large dense ones must not flip the mode, each flip drains the pipeline.
+    if (sl.hits_cap == c->hits_cap && sl.n_chunks > kInlineTailChunks) {
+        if (n >= 8u * (size_t)sl.n_chunks) c->dense_mode = true;
+        else if (n < 2u * (size_t)sl.n_chunks) c->dense_mode = false;
+    }
+    if (take_device_result(c, sl, chunk_offset, out)) return 0;
+    if (rec_on_device && n) {
+        HIP_TRY(c, hipMemcpy(sl.h_rec, sl.score.rec, n * sizeof(TrialRecord), hipMemcpyDeviceToHost));
+        if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    }
+    c->host_replays++;
+    c->score_epoch++;        // passes in flight were scored on the device without what this replay adds
+    c->exact_valid = false;
+    static const bool skip_replay = tuning_env("ADSB_SKIP_REPLAY") != nullptr;  // measurement aid (tuning build only)
+#ifdef ADSB_TUNING
+    const auto tr0 = std::chrono::steady_clock::now();
+#endif
+    if (!skip_replay) replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out, &c->host_sorts);
+#ifdef ADSB_TUNING
+    c->t_replay += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+#endif
+    return 0;
+}
+
+// Finish the oldest submission: replay it, or -- when a device list overflowed (far
+// denser input than the lists were sized for) -- drain the stream and go chunk by
+// chunk, where the worst case always fits.  Bitmap bits set by the aborted pass or by
+// later passes are a harmless superset in time.
+int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
+{
+    Slot &sl = c->slot[c->collected % kSlots];
+    adsb_stats st{};
+    st.n_samples = sl.n_samples;
+    st.n_chunks = sl.n_chunks;
+    if (sl.flush_before) c->filter.flush();  // icao_flush() took effect before this pass
+    int rc = finish_pass(c, sl, 0, st, out);
+    if (rc > 0 && sl.from_mag) {  // a caller-supplied buffer denser than the fast scan's lists: again, the slow way
+        st.retries++;
+        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
+        HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->score_stream));
+        const bool keep_flush = c->flush_pending;
+        c->flush_pending = false;
+        Slot tmp;
+        rc = fallback_slot(c, sl, tmp);
+        if (rc == 0) rc = reseed_bitmap_from_filter(c);
+        if (rc == 0) rc = enqueue_pass(c, tmp, sl.src, true, sl.n_samples, 1, false, false, false, true);
+        if (rc == 0) rc = finish_pass(c, tmp, 0, st, out);
+        c->flush_pending = keep_flush;
+    } else if (rc > 0) {
+        st.retries++;
+        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
+        HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->score_stream));
+        const bool keep_flush = c->flush_pending;
+        c->flush_pending = false;
+        Slot tmp;  // same counters, summary and events; one chunk at a time into the worst-case lists
+        rc = fallback_slot(c, sl, tmp);
+        if (rc == 0) rc = reseed_bitmap_from_filter(c);
+        for (uint64_t ch = 0; ch < sl.n_chunks && rc == 0; ch++) {
+            const uint64_t off = ch * kChunkSamples;
+            const uint64_t n = std::min<uint64_t>(kChunkSamples, sl.n_samples - off);
+            // (carry-over mode: buffers after the first find their lead-in in src itself; the
+            // carry for the next call was already taken when the pass was first enqueued)
+            // the reference-shaped kernel: its lists hold the worst case of a chunk
+            rc = enqueue_pass(c, tmp, (const uint32_t *)sl.src + off, false, n, 1, false, ch > 0, false, true);
+            if (rc == 0) rc = finish_pass(c, tmp, ch, st, out);
+        }
+        c->flush_pending = keep_flush;
+    }
+    sl.busy = false;
+    c->collected++;
+    if (rc > 0) {
+        c->last_error = "device lists overflowed on a single chunk";
+        return ADSB_ERR_HIP;
+    }
+    if (rc < 0) return rc;
+    c->stats = st;
+    return ADSB_OK;
+}
+
+// Finish every pass in flight now; the caller still gets them from adsb_collect, in order.
+int park_pending(adsb_ctx *c)
+{
+    while (c->collected < c->submitted) {
+        Slot &sl = c->slot[c->collected % kSlots];
+        sl.parked_msgs.clear();
+        sl.park_rc = collect_oldest(c, sl.parked_msgs);
+        sl.parked_stats = c->stats;
+        sl.parked = true;
+    }
+    return ADSB_OK;
+}
+
+// adsb_collect: the oldest pass the caller has not had yet
+int collect_next(adsb_ctx *c, std::vector<adsb_msg> &out)
+{
+    if (c->delivered < c->collected) {
+        Slot &sl = c->slot[c->delivered % kSlots];
+        out.swap(sl.parked_msgs);
+        sl.parked_msgs.clear();
+        c->stats = sl.parked_stats;
+        sl.parked = false;
+        c->delivered++;
+        return sl.park_rc;
+    }
+    const int rc = collect_oldest(c, out);
+    c->delivered++;
+    return rc;
+}
+
+int deliver(adsb_ctx *c, std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap,
+            size_t *n_out)
+{
+    c->stats.n_messages = msgs.size();
+    const size_t n = std::min(cap, msgs.size());
+    if (n && out) std::memcpy(out, msgs.data(), n * sizeof(adsb_msg));
+    if (n_out) *n_out = msgs.size();
+    c->has_undelivered = msgs.size() > cap;
+    if (!c->has_undelivered) {
+        c->undelivered.clear();
+        return ADSB_OK;
+    }
+    c->undelivered.swap(msgs);  // the pass is consumed: keep what it produced (adsb_fetch_messages)
+    return ADSB_ERR_CAPACITY;
+}
+
+}  // namespace host
+}  // namespace adsb
+
+extern "C" {
+
+int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
+{
+    if (!c || (!out && cap)) return ADSB_ERR_INVALID;
+    if (c->submitted == c->delivered) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<adsb_msg> msgs;
+    int rc = collect_next(c, msgs);
+    if (rc) return rc;
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->delivered) : 0; }
+
+int adsb_fetch_messages(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
+{
+    if (!c || (!out && cap) || !c->has_undelivered) return ADSB_ERR_INVALID;
+    const size_t n = std::min(cap, c->undelivered.size());
+    if (n) std::memcpy(out, c->undelivered.data(), n * sizeof(adsb_msg));
+    if (n_out) *n_out = c->undelivered.size();
+    return c->undelivered.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
+                        size_t cap, size_t *n_out)
+{
+    if (!filter_table || (!records && n) || (!out && cap)) return ADSB_ERR_INVALID;
+    static const Crc24 crc;
+    IcaoFilter filter;
+    filter.load(filter_table);
+    std::vector<adsb_msg> msgs;
+    replay(filter, crc, reinterpret_cast<TrialRecord *>(records), n, 0, msgs);
+    filter.store(filter_table);
+    const size_t k = std::min(cap, msgs.size());
+    if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
+    if (n_out) *n_out = msgs.size();
+    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+}  // extern "C"

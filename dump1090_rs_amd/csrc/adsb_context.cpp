@@ -1,0 +1,452 @@
+// adsb_context.cpp -- context lifetime, the stream pool, settings and diagnostics (include/adsb_hip.h).
+//
+// The functions of the library mirror the reference's library API for the path (src/utils.rs:43 to_mag,
+// src/demod_2400.rs:115 demodulate2400, src/icao_filter.rs:11 icao_flush); what each one replaces is
+// listed in the header.
+#include "adsb_ctx.h"
+
+using namespace adsb::host;
+
+extern "C" {
+
+// The internal streams of destroyed contexts, kept for the next context on the same device.  The
+// runtime gives every new stream of a priority a new hardware queue until it has four of that priority
+// and never gives one back, so a process that creates, destroys and re-creates contexts ends up with its
+// streams spread over a different set of queues each time -- measured: a dense stream in the second
+// context alternates 88 / 270 us per pass (0.175 ms mean) where the first one holds 0.13.  Re-using the
+// same streams keeps every context of a process on the queues the first one got.
+struct StreamSet {
+    int device = -1;
+    hipStream_t own = nullptr, scan[2] = {nullptr, nullptr}, tail = nullptr, score = nullptr, copy = nullptr;
+};
+std::mutex g_stream_pool_mu;
+std::vector<StreamSet> g_stream_pool;
+
+bool take_stream_set(int device, StreamSet &out)
+{
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+        if (g_stream_pool[i].device == device) {
+            out = g_stream_pool[i];
+            g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+
+int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
+{
+    if (!out) return ADSB_ERR_INVALID;
+    *out = nullptr;
+    if (device < 0) return ADSB_ERR_NO_DEVICE;  // no CPU backend by design
+    if (max_chunks == 0) max_chunks = 1;
+    if (max_chunks > kMaxChunks) return ADSB_ERR_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return ADSB_ERR_NO_DEVICE;
+
+    adsb_ctx *c = new (std::nothrow) adsb_ctx;
+    if (!c) return ADSB_ERR_NOMEM;
+    c->device = device;
+    c->max_chunks = max_chunks;
+    if (const char *ds = tuning_env("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
+    if (const char *st = tuning_env("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
+    // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
+    // of n buffers runs min(17 n, resident grid) workgroups of four waves, so a small context only gets
+    // the segments it can ever use), each sized for ~5x the rate pure noise produces (2.3 % of
+    // samples become address/parity entries).  Denser input falls back to buffer-by-buffer
+    // passes through the reference-shaped kernel, whose list (dap) and the hit list hold one
+    // buffer's worst case: every position sliced, five trials each.
+    (void)hipSetDevice(device);  // scan_resident_blocks() asks the current device
+    const uint64_t used_segs = 4 * std::min<uint64_t>((uint64_t)scan_resident_blocks(), max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
+    c->seg_cap = (uint32_t)std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + used_segs - 1) / used_segs);
+    c->ap_cap = (uint32_t)(used_segs * c->seg_cap);
+    // hit list: ~5x what a busy airspace produces (a frame leaves 3-4 trial records; 1000 frames/s
+    // are ~55 per buffer); more than that is the fallback's business too
+    c->hits_cap = (uint32_t)(4096 + max_chunks * 1024);
+
+    int rc = ADSB_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(device));
+        StreamSet pooled;
+        const bool reuse = !tuning_env("ADSB_STREAM_PRIO") && !tuning_env("ADSB_SCORE_PRIO") && take_stream_set(device, pooled);
+        if (reuse) {
+            c->own_stream = pooled.own;
+            c->scan_stream[0] = pooled.scan[0];
+            c->scan_stream[1] = pooled.scan[1];
+            c->tail_stream = pooled.tail;
+            c->score_stream = pooled.score;
+            c->copy_stream_spare = pooled.copy;
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        }
+        c->stream = c->own_stream;
+        HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
+        if (!reuse) {
+            // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+            // default, per priority) and two streams on one queue run strictly one after the other.
+            // Both scan streams take the highest priority: that pool holds nothing else of this
+            // process (the null stream, torch's and the caller's streams are of normal priority), so
+            // the two get a queue each and consecutive scans can overlap.  They must have the SAME
+            // priority: with different ones, whenever two scans are pending at once (after any hiccup
+            // of the host) the higher one's starts first, its successor on that stream is then free
+            // earlier too, and the stream settles into finishing passes in the order 2, 1, 4, 3, ...
+            // for thousands of passes, 8-10 % slower (passes are collected in order), until another
+            // hiccup flips it back; measured over 22 000 passes: (mid, high) spends a third of the
+            // time in that mode, (high, high) and (mid, mid) none.
+            int least = 0, greatest = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            int pt = least, p0 = greatest, p1 = greatest;
+            if (const char *e = tuning_env("ADSB_STREAM_PRIO")) {  // measurement aid: "tail,scan0,scan1" as 0 (least) .. 2
+                int a = 0, b = 1, d = 2;
+                if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
+                    const int lv[3] = {least, (least + greatest) / 2, greatest};
+                    pt = lv[a % 3], p0 = lv[b % 3], p1 = lv[d % 3];
+                }
+            }
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, pt));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, p0));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, p1));
+            if (tuning_env("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
+        }
+        for (auto &e : c->input_ready)
+            HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+        for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapAllocWords * sizeof(uint32_t)));
+        for (Slot &sl : c->slot) {
+            HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
+            sl.hits_cap = c->hits_cap;
+            HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_cnt, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(sl.d_order_cnt, 0, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_base, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_tmp, (size_t)c->hits_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipEventCreateWithFlags(&sl.scanned, hipEventDisableTiming | hipEventDisableSystemFence));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_carry, kCarrySamples * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t)));
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->d_carry_next, kCarrySamples * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t)));
+        {
+            // device-side scoring state (shared by the passes: they go through it one after the other
+            // on the tail stream); passes of more hits than `cap` are scored on the host
+            ScoreDev &cd = c->score;   // cap / hash_mask / exact: the context's; the rest per slot
+            cd.cap = std::min<uint32_t>(c->hits_cap, 131072u);
+            uint32_t hsize = 1;
+            while (hsize < 2 * cd.cap) hsize <<= 1;
+            cd.hash_mask = hsize - 1;
+            for (auto &bm : c->exact_bm) {
+                HIP_TRY(c, hipMalloc((void **)&bm, kBitmapAllocWords * sizeof(uint32_t)));
+                HIP_TRY(c, hipMemset(bm, 0, kBitmapAllocWords * sizeof(uint32_t)));
+            }
+            cd.exact = c->exact_bm[0];
+            cd.si = reinterpret_cast<uint32_t *>(cd.exact);  // (non-null: "scoring is available")
+            if (!c->score_stream) {
+                int least = 0, greatest = 0;
+                HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                int ps = least;  // with the tail stream's priority: its own hardware queue in that pool
+                if (const char *e = tuning_env("ADSB_SCORE_PRIO")) ps = std::atoi(e) == 2 ? greatest : (std::atoi(e) == 1 ? (least + greatest) / 2 : least);
+                HIP_TRY(c, hipStreamCreateWithPriority(&c->score_stream, hipStreamNonBlocking, ps));
+            }
+            for (Slot &sl : c->slot) {
+                ScoreDev &sd = sl.score;
+                sd = cd;
+                HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.rec, (size_t)sd.cap * sizeof(TrialRecord)));
+                HIP_TRY(c, hipMalloc((void **)&sd.flag, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.pos, (size_t)sd.cap * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMalloc((void **)&sd.slot, (size_t)sd.cap * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.hash, (size_t)hsize * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMemset(sd.hash, 0xFF, (size_t)hsize * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMalloc((void **)&sd.blk, 2 * kScoreBlocks * sizeof(uint32_t)));
+                HIP_TRY(c, hipMalloc((void **)&sd.state, sizeof(ScoreState)));
+                HIP_TRY(c, hipMemset(sd.state, 0, sizeof(ScoreState)));
+                HIP_TRY(c, hipEventCreateWithFlags(&sl.recorded, hipEventDisableTiming | hipEventDisableSystemFence));
+            }
+            const ScoreDev &sd = cd;
+            for (Slot &sl : c->slot) {
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_msgs, (size_t)sd.cap * sizeof(adsb_msg), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_adds, (size_t)sd.cap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_ssum, sizeof(ScoreSummary), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_msgs_dev, sl.h_msgs, 0));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_adds_dev, sl.h_adds, 0));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_ssum_dev, sl.h_ssum, 0));
+                std::memset(sl.h_ssum, 0, sizeof(ScoreSummary));
+            }
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->d_tables, kTabWords * sizeof(uint32_t)));
+        {
+            std::vector<uint32_t> tab = build_gf_tables();
+            const std::vector<uint32_t> r16 = build_r16(), ft = build_field_table(fast_plane_bytes()),
+                                        bits = build_bit_residuals();
+            tab.insert(tab.end(), r16.begin(), r16.end());
+            tab.insert(tab.end(), ft.begin(), ft.end());
+            tab.insert(tab.end(), bits.begin(), bits.end());
+            HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
+                                 hipMemcpyHostToDevice));
+        }
+        for (Slot &sl : c->slot) {
+            // (mapped + coherent: the records kernel's write-through stores are visible to the host
+            // when its completion event fires, whatever the runtime's default for pinned memory)
+            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(c, hipHostMalloc((void **)&sl.h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
+                                     hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_sum_dev, sl.h_sum, 0));
+            HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_rec_dev, sl.h_rec, 0));
+            // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
+            for (int k = 2; k < 5; k++) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev[k], hipEventDisableSystemFence));
+            const bool fenced = tuning_env("ADSB_DONE_FENCE") != nullptr;  // measurement aid only
+            HIP_TRY(c, hipEventCreateWithFlags(&sl.done, fenced ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
+        }
+        for (auto &pair : c->scan_ev)
+            for (auto &e : pair) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+        if (tuning_env("ADSB_TIMELINE")) {
+            // 1: stamps of 8 blocks x 8 tiles; 2 (with ADSB_DEBUG_STOP=100): per-wave phase totals
+            HIP_TRY(c, hipMalloc((void **)&c->d_timeline, kTimelineWords * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemset(c->d_timeline, 0, kTimelineWords * sizeof(unsigned long long)));
+        }
+        // both bitmaps clean and both counter blocks zero to start with; from then on each
+        // pass cleans up for the next (the first pass needs no flush of its own)
+        for (int k = 0; k < kBitmaps; k++)
+            if (int e = launch_reset(c->slot[k % kSlots].d_ctr, c->d_bitmap[k], c->stream))
+                return fail(c, (hipError_t)e, "launch_reset");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->flush_pending = false;
+        return (int)ADSB_OK;
+    };
+    rc = body();
+    if (rc != ADSB_OK) {
+        std::fprintf(stderr, "adsb_create: %s\n", c->last_error.c_str());
+        adsb_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ADSB_OK;
+}
+
+void adsb_destroy(adsb_ctx *c)
+{
+    if (!c) return;
+#ifdef ADSB_TUNING
+    if (tuning_env("ADSB_HOST_TIMES"))
+        std::fprintf(stderr, "host times over %llu passes: enqueue %.1f us, wait %.1f us, replay %.1f us per pass\n",
+                     (unsigned long long)c->collected, 1e6 * c->t_enqueue / (c->collected ? c->collected : 1),
+                     1e6 * c->t_wait / (c->collected ? c->collected : 1), 1e6 * c->t_replay / (c->collected ? c->collected : 1));
+#endif
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (auto &pair : c->scan_ev)
+        for (auto &e : pair)
+            if (e) (void)hipEventDestroy(e);
+    for (Slot &sl : c->slot) {
+        for (int k = 2; k < 5; k++)
+            if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.scanned) (void)hipEventDestroy(sl.scanned);
+        if (sl.d_ctr) (void)hipFree(sl.d_ctr);
+        if (sl.d_hits) (void)hipFree(sl.d_hits);
+        if (sl.d_ap) (void)hipFree(sl.d_ap);
+        if (sl.d_order_cnt) (void)hipFree(sl.d_order_cnt);
+        if (sl.d_order_base) (void)hipFree(sl.d_order_base);
+        if (sl.d_order_tmp) (void)hipFree(sl.d_order_tmp);
+        if (sl.h_msgs) (void)hipHostFree(sl.h_msgs);
+        if (sl.h_adds) (void)hipHostFree(sl.h_adds);
+        if (sl.h_ssum) (void)hipHostFree(sl.h_ssum);
+        if (sl.d_carry) (void)hipFree(sl.d_carry);
+        if (sl.h_sum) (void)hipHostFree(sl.h_sum);
+        if (sl.h_rec) (void)hipHostFree(sl.h_rec);
+    }
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_mag) (void)hipFree(c->d_mag);
+    for (auto &b : c->d_bitmap)
+        if (b) (void)hipFree(b);
+    for (hipStream_t q : c->scan_stream)
+        if (q) (void)hipStreamSynchronize(q);
+    for (hipEvent_t e : c->input_ready)
+        if (e) (void)hipEventDestroy(e);
+    if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
+    for (Slot &sl : c->slot) {
+        for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot, (void *)sl.score.pos,
+                        (void *)sl.score.hash, (void *)sl.score.blk, (void *)sl.score.state})
+            if (q && q != (void *)c->score.exact) (void)hipFree(q);
+        if (sl.recorded) (void)hipEventDestroy(sl.recorded);
+    }
+    for (uint32_t *bm : c->exact_bm)
+        if (bm) (void)hipFree(bm);
+    if (c->score_stream) (void)hipStreamSynchronize(c->score_stream);
+    if (c->fb.d_hits) (void)hipFree(c->fb.d_hits);
+    if (c->fb.d_dap) (void)hipFree(c->fb.d_dap);
+    if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    for (auto &r : c->ring) {
+        if (r.copied) (void)hipEventDestroy(r.copied);
+        if (r.h_iq) (void)hipHostFree(r.h_iq);
+        if (r.d_iq) (void)hipFree(r.d_iq);
+    }
+    if (c->d_addrs) (void)hipFree(c->d_addrs);
+    if (c->d_carry_next) (void)hipFree(c->d_carry_next);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->d_timeline && c->debug_stop == 100) {
+        // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves
+        std::vector<unsigned long long> tl(kTimelineWords);
+        if (hipMemcpy(tl.data(), c->d_timeline, kTimelineWords * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[8] = {0};
+            int nw = 0;
+            for (size_t w = 0; w < kTimelineWords / 8; w++) {
+                double tot = 0;
+                for (int k = 0; k < 8; k++) tot += (double)tl[w * 8 + k];
+                if (tot == 0) continue;
+                nw++;
+                for (int k = 0; k < 8; k++) sum[k] += (double)tl[w * 8 + k];
+            }
+            double all = 0;
+            for (double v : sum) all += v;
+            static const char *name[8] = {"P1", "wait B1", "P2", "wait B2", "P3-5", "wait B3", "epilogue", "wait B4"};
+            std::fprintf(stderr, "phase accounting over %d waves (clock64 ticks per wave, share):\n", nw);
+            for (int k = 0; k < 8; k++)
+                std::fprintf(stderr, "  %-9s %10.0f  %5.1f %%\n", name[k], sum[k] / (nw ? nw : 1), 100.0 * sum[k] / (all ? all : 1));
+        }
+        (void)hipFree(c->d_timeline);
+    } else if (c->d_timeline) {
+        // profiling aid: dump the stamps of the last scan on the way out
+        unsigned long long tl[512];
+        if (hipMemcpy(tl, c->d_timeline, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int b = 0; b < 8; b++)
+                for (int it = 0; it < 8; it++) {
+                    const unsigned long long *r = tl + (b * 8 + it) * 8;
+                    if (!r[0]) continue;
+                    std::fprintf(stderr, "timeline block %d tile %d: start %8lld |", b * 128, it,
+                                 (long long)(r[0] - tl[0]));
+                    for (int k = 1; k < 7; k++) std::fprintf(stderr, " %6lld", (long long)(r[k] - r[k - 1]));
+                    std::fprintf(stderr, "  total %lld\n", (long long)(r[6] - r[0]));
+                }
+        (void)hipFree(c->d_timeline);
+    }
+    {
+        // the streams go back to the pool (a context whose creation failed half-way has no full set:
+        // its streams are simply destroyed)
+        StreamSet set;
+        set.device = c->device;
+        set.own = c->own_stream;
+        set.scan[0] = c->scan_stream[0];
+        set.scan[1] = c->scan_stream[1];
+        set.tail = c->tail_stream;
+        set.score = c->score_stream;
+        set.copy = c->copy_stream ? c->copy_stream : c->copy_stream_spare;
+        if (set.own && set.scan[0] && set.scan[1] && set.tail && set.score) {
+            std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+            g_stream_pool.push_back(set);
+        } else {
+            for (hipStream_t q : {set.own, set.scan[0], set.scan[1], set.tail, set.score, set.copy})
+                if (q) (void)hipStreamDestroy(q);
+        }
+    }
+    delete c;
+}
+
+int adsb_set_stream(adsb_ctx *c, void *hip_stream)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ADSB_OK;
+}
+
+int adsb_set_profiling(adsb_ctx *c, int enabled)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    return ADSB_OK;
+}
+
+int adsb_set_carry_over(adsb_ctx *c, int enabled)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->carry_over = enabled != 0;
+    // the stream starts here: nothing precedes the next call
+    for (Slot &sl : c->slot) HIP_TRY(c, hipMemsetAsync(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ADSB_OK;
+}
+
+int adsb_icao_flush(adsb_ctx *c)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // Takes effect for everything submitted after this call: the next pass's reset kernel
+    // clears the device bitmap (stream-ordered), and the host filter is flushed when that
+    // pass is collected, after the passes before it have been replayed.
+    c->flush_pending = true;
+    return ADSB_OK;
+}
+
+int adsb_read_test_data(const char *path, int16_t *iq, size_t max_samples, size_t *n_out)
+{
+    if (!path || !iq) return ADSB_ERR_INVALID;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return ADSB_ERR_INVALID;
+    size_t k = 0;
+    unsigned char b[4];
+    while (k < max_samples && std::fread(b, 1, 4, fp) == 4) {
+        // file: [im lo][im hi][re lo][re hi]  (src/utils.rs:29-31) -> memory {re, im}
+        iq[2 * k] = (int16_t)(b[2] | (b[3] << 8));
+        iq[2 * k + 1] = (int16_t)(b[0] | (b[1] << 8));
+        k++;
+    }
+    std::fclose(fp);
+    if (n_out) *n_out = k;
+    return ADSB_OK;
+}
+
+int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
+{
+    if (!m || !out || (m->len != ADSB_MODES_SHORT_MSG_BYTES && m->len != ADSB_MODES_LONG_MSG_BYTES))
+        return ADSB_ERR_INVALID;
+    const size_t need = 2u * m->len + 3u;  // '*', hex, ';', '\n'
+    if (out_size < need + 1) return ADSB_ERR_CAPACITY;
+    static const char digits[] = "0123456789abcdef";  // hex::encode is lowercase
+    char *w = out;
+    *w++ = '*';
+    for (int i = 0; i < m->len; i++) {
+        *w++ = digits[m->msg[i] >> 4];
+        *w++ = digits[m->msg[i] & 15];
+    }
+    *w++ = ';';
+    *w++ = '\n';
+    *w = 0;
+    return (int)need;
+}
+
+uint64_t adsb_host_sorts(const adsb_ctx *c) { return c ? c->host_sorts : 0; }
+uint64_t adsb_host_replays(const adsb_ctx *c) { return c ? c->host_replays : 0; }
+
+int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
+{
+    if (!c || !out) return ADSB_ERR_INVALID;
+    *out = c->stats;
+    return ADSB_OK;
+}
+
+const char *adsb_strerror(int status)
+{
+    switch (status) {
+    case ADSB_OK: return "ok";
+    case ADSB_ERR_INVALID: return "invalid argument";
+    case ADSB_ERR_NO_DEVICE: return "no usable HIP device (libadsb_hip has no CPU fallback)";
+    case ADSB_ERR_HIP: return "HIP runtime error";
+    case ADSB_ERR_TOO_LONG: return "more than 131072 samples for a single MagnitudeBuffer";
+    case ADSB_ERR_CAPACITY: return "output array too small";
+    case ADSB_ERR_NOMEM: return "out of memory";
+    case ADSB_ERR_BUSY: return "submissions are pending (collect them first) or too many are in flight";
+    default: return "unknown status";
+    }
+}
+
+const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+const char *adsb_version(void) { return "adsb_hip 0.15 gfx950 scan=v8-gate-reads tail=v3-buckets"; }
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// adsb_ctx.h -- what the host-side units of libadsb_hip.so share: the context, a pass slot, and the
+// internal entry points between them.  Not part of the ABI (include/adsb_hip.h is).
+//
+//   adsb_context.cpp   create / destroy, the stream pool, settings, diagnostics
+//   adsb_pass.cpp      one device pass: what is enqueued on which stream, and every cross-stream edge
+//                      (DESIGN.md section 5b lists them), submit, the blocking entry points
+//   adsb_collect.cpp   waiting for a pass, checksums, the ordered host replay, the overflow fallback
+//   adsb_ring.cpp      the pinned streaming ring
+//   adsb_shard.cpp     the two-phase shard calls
+//   adsb_selftest.cpp  stage lists and digests for the tests
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/adsb_hip.h"
+#include "adsb_device.h"
+#include "adsb_scan_geometry.h"
+#include "adsb_tables.h"
+#include "mode_s_host.hpp"
+
+using namespace adsb;
+
+// One submission in flight: what was asked, and the pinned host side of its results.
+struct Slot {
+    bool busy = false;
+    bool flush_before = false;  // an icao_flush precedes this pass (host filter flushed at collect)
+    bool from_mag = false;
+    const void *src = nullptr;
+    uint64_t n_samples = 0;
+    uint32_t n_chunks = 0;
+    // pinned, mapped host memory the records kernel writes straight into (no copy commands
+    // on the stream): *_dev are the device-side addresses of the same allocations
+    Summary *h_sum = nullptr, *h_sum_dev = nullptr;
+    TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;  // hits_cap entries
+    uint32_t hits_cap = 0;  // entries in d_hits / h_rec (the fallback's lists are larger than the slot's own)
+    // device side of the slot: its own counters, AP list and hit list, so that the match /
+    // records tail of this pass (tail stream) can run while the next pass's scan (scan
+    // stream) fills the other slot's
+    Counters *d_ctr = nullptr;
+    uint64_t *d_ap = nullptr, *d_hits = nullptr;
+    // device-side ordering of the hit list: per-buffer counts and their prefix (max_chunks + 1
+    // each), and the second list the counting sort scatters into
+    uint32_t *d_order_cnt = nullptr, *d_order_base = nullptr;
+    uint64_t *d_order_tmp = nullptr;
+    // device-side scoring: the messages, the filter additions and their summary, in mapped host memory
+    adsb_msg *h_msgs = nullptr, *h_msgs_dev = nullptr;
+    uint32_t *h_adds = nullptr, *h_adds_dev = nullptr;
+    ScoreSummary *h_ssum = nullptr, *h_ssum_dev = nullptr;
+    // a pass the library finished ahead of the caller's adsb_collect (park_pending): its result waits here
+    bool parked = false;
+    int park_rc = 0;
+    std::vector<adsb_msg> parked_msgs;
+    adsb_stats parked_stats{};
+    ScoreDev score{};             // this slot's scoring buffers (the exact bitmap in it is the context's)
+    hipEvent_t recorded = nullptr;  // this pass's records kernel has finished (k_score may start; the superset
+                                    // bitmap it matched against may be cleared)
+    hipStream_t tail_q = nullptr;   // the stream its match / order / records ran on
+    bool device_scored = false;   // this pass went through k_score / k_emit
+    uint64_t score_epoch = 0;     // ... against the filter history of this epoch
+    uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
+                                   // (kept until the slot is reused: the overflow fallback re-reads it)
+    hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
+    uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
+    uint64_t scan_seq = 0;  // running number of the pass (ms_scan_exclusive: was the previous scan the previous pass?)
+    hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int profiled = 0;  // profiling level the pass was enqueued with
+};
+
+constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 4: the device never waits for the host between passes (3 do for sparse streams; a dense one has a longer tail)
+constexpr int kBitmaps = kSlots + 1;
+constexpr int kScanEvRing = kSlots + 3;  // scan start / stop event pairs in rotation (finish_pass: ms_scan_exclusive)
+
+constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup
+
+struct adsb_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int profiling = 1;  // 0: no events, 1: around the scan kernel, 2: around every kernel
+    bool flush_pending = true;  // consumed by the next pass: it switches to the clean spare bitmap
+    uint32_t stagger_ticks = 0;
+    int debug_stop = 0;  // ADSB_DEBUG_STOP: profiling aid, breaks results when non-zero
+    unsigned long long *d_timeline = nullptr;  // ADSB_TIMELINE=1: 8 blocks x 8 tiles x 8 stamps
+    size_t max_chunks = 0;
+
+    void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
+    size_t stage_bytes = 0;
+    uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
+    // Address bitmaps in rotation (one more than passes in flight): icao_flush moves on to the
+    // next (clean) one, the retired one is cleared by that pass's records kernel and comes back
+    // into use kSlots flushes later -- a pass that far ahead cannot even be submitted before the
+    // pass that cleared it has been collected, so neither a reset launch nor a cross-stream wait
+    // is ever needed.
+    uint32_t *d_bitmap[kBitmaps] = {};
+    int cur_bitmap = 0;
+    hipStream_t score_stream = nullptr;  // k_score / k_emit of the device-scored passes, in pass order
+    hipStream_t tail_stream = nullptr;  // match + records of pass i run here, beside scan i+1
+    // The scans run on two internal streams, alternating between consecutive pipelined passes:
+    // those do not depend on each other (own lists and counters per slot; bits another scan
+    // adds to the bitmap meanwhile only widen the superset), so the next scan's workgroups
+    // fill the CUs as the previous scan's persistent grid drains instead of waiting ~13 us
+    // behind an in-order queue's end-of-kernel barrier.  `stream` (the caller's) only orders
+    // the input: each scan waits for the point `stream` had reached at submit.
+    hipStream_t scan_stream[2] = {nullptr, nullptr};
+    hipEvent_t prev_scanned = nullptr;      // the latest submission's scan-end event and the stream it is on
+    hipStream_t prev_scan_stream = nullptr;
+    bool prev_inline = false;               // ... and whether its match ran there rather than on the tail stream
+    hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
+    uint32_t *d_tables = nullptr;
+    uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;
+    // Lists that hold the worst case of one buffer (every position sliced, five trials each), for
+    // the buffer-by-buffer fallback through the reference-shaped kernel.  58 MB, most of it pinned
+    // host memory: allocated the first time a pass overflows the normal lists -- a receiver's
+    // stream never gets there, and a process with hundreds of small contexts stays small.
+    struct Fallback {
+        uint64_t *d_hits = nullptr, *d_dap = nullptr;
+        TrialRecord *h_rec = nullptr, *h_rec_dev = nullptr;
+    } fb;
+
+    Slot slot[kSlots];
+    // start / stop events of the scans, in a ring one longer than the passes in flight: when pass N
+    // is collected the stop event of pass N-1 is still its own (ms_scan_exclusive)
+    hipEvent_t scan_ev[kScanEvRing][2] = {};
+    hipEvent_t last_stop = nullptr;  // stop event of the pass collected last, and its number
+    uint64_t last_scan_seq = 0;
+    uint64_t scan_counter = 0;
+    uint64_t submitted = 0, collected = 0;  // passes enqueued / finished (replayed) by the library
+    uint64_t delivered = 0;                 // passes handed to the caller (<= collected: park_pending)
+    // Dense input (thousands of trial records per pass) is ordered and scored on the device; sparse
+    // input is not worth the extra launches on the tail stream, the host does it in microseconds.
+    // Decided from the last pass finished (a stream's density changes slowly).
+    bool dense_mode = false;
+    uint32_t next_seq = 1;
+
+    // streaming ring (adsb_ring_*): per slot a pinned host buffer the caller fills and a
+    // device staging buffer; the H2D copy of one slot runs on its own stream while the
+    // other slot's pass computes
+    struct RingSlot {
+        int16_t *h_iq = nullptr;
+        void *d_iq = nullptr;
+        hipEvent_t copied = nullptr;
+    } ring[kSlots];
+    size_t ring_samples = 0;
+    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream_spare = nullptr;  // a pooled copy stream this context has not needed (yet)
+
+    bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
+    uint32_t *d_carry_next = nullptr;  // the end of the latest submission's input: the next one's lead-in
+
+    // sharded capture (adsb_shard_scan / adsb_shard_finish): the pass parked between its two phases
+    bool shard_active = false;
+    bool shard_by_chunk = false;  // the shard overflowed the fast scan's lists: both phases go chunk by chunk
+    ScanParams shard_params{};
+    uint32_t *d_addrs = nullptr;
+    size_t addrs_cap = 0;
+
+    IcaoFilter filter;
+    Crc24 crc;
+    adsb_stats stats{};
+    std::string last_error;
+    // the messages of a call whose `out` was too small (ADSB_ERR_CAPACITY): the pass is consumed
+    // and the filter has moved on, so they are kept for adsb_fetch_messages
+    uint64_t host_sorts = 0;  // passes whose records the host had to put in order itself
+    uint64_t host_replays = 0;  // passes the host scored itself (small passes, fallbacks, full filter ...)
+    // Device-side scoring (adsb_device.h: ScoreDev).  The exact bitmap follows the filter pass by pass
+    // on the tail stream; the host's own filter follows at collect time from the additions each pass
+    // reports.  Whenever the host scores a pass itself the two part ways: `score_epoch` moves on, which
+    // disowns the device results of passes already in flight, and device scoring resumes once the
+    // context is idle and the bitmap has been rebuilt from the host's table.
+    ScoreDev score{};
+    uint32_t *exact_bm[2] = {nullptr, nullptr};  // the exact bitmap in use and the clean one an icao_flush switches to
+    int cur_exact = 0;
+    bool exact_valid = false;
+    uint64_t score_epoch = 0;
+#ifdef ADSB_TUNING
+    double t_wait = 0, t_replay = 0, t_enqueue = 0;  // host seconds (ADSB_HOST_TIMES prints them at destroy)
+#endif
+    std::vector<adsb_msg> undelivered;
+    bool has_undelivered = false;
+};
+
+namespace adsb {
+namespace host {
+
+constexpr uint32_t kWorstPerChunk = 5u * kChunkSamples;  // every j sliced, 5 trials each
+constexpr uint32_t kInlineTailChunks = 16;               // passes this small keep their tail on the scan stream
+
+inline int fail(adsb_ctx *c, hipError_t e, const char *what)
+{
+    if (c) {
+        c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return ADSB_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, call)                                                \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return ::adsb::host::fail((ctx), e_, #call); \
+    } while (0)
+
+// adsb_pass.cpp
+int ensure_fallback(adsb_ctx *c);
+int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp);
+int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples, uint32_t n_chunks,
+                 bool inline_tail = false, bool lead_from_src = false, bool advance_carry = true,
+                 bool force_simple = false, hipEvent_t input_done = nullptr);
+int resync_exact(adsb_ctx *c);
+int reseed_bitmap_from_filter(adsb_ctx *c);
+int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false,
+           hipEvent_t input_done = nullptr);
+int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out);
+int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<adsb_msg> &out);
+int ensure_stage(adsb_ctx *c, size_t bytes);
+
+// adsb_collect.cpp
+void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out, uint64_t *host_sorts = nullptr);
+int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size_t n);
+int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out);
+int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out);
+int park_pending(adsb_ctx *c);
+int collect_next(adsb_ctx *c, std::vector<adsb_msg> &out);
+int deliver(adsb_ctx *c, std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap, size_t *n_out);
+
+}  // namespace host
+}  // namespace adsb

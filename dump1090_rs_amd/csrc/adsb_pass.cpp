@@ -1,0 +1,443 @@
+// adsb_pass.cpp -- one device pass: what is enqueued on which stream (every cross-stream event edge is here;
+// DESIGN.md section 5b is the table to review it against), submit, and the blocking entry points
+// (reference: src/utils.rs:43 to_mag, src/demod_2400.rs:115 demodulate2400, dump1090_rs/src/main.rs:166-167).
+#include "adsb_ctx.h"
+
+using namespace adsb::host;
+
+namespace adsb {
+namespace host {
+
+int ensure_fallback(adsb_ctx *c)
+{
+    auto &fb = c->fb;
+    if (fb.h_rec_dev) return ADSB_OK;
+    if (!fb.d_hits) HIP_TRY(c, hipMalloc((void **)&fb.d_hits, (size_t)kWorstPerChunk * sizeof(uint64_t)));
+    if (!fb.d_dap) HIP_TRY(c, hipMalloc((void **)&fb.d_dap, (size_t)kWorstPerChunk * sizeof(uint64_t)));
+    if (!fb.h_rec)
+        HIP_TRY(c, hipHostMalloc((void **)&fb.h_rec, (size_t)kWorstPerChunk * sizeof(TrialRecord), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, hipHostGetDevicePointer((void **)&fb.h_rec_dev, fb.h_rec, 0));
+    return ADSB_OK;
+}
+
+// `sl` with the worst-case lists in place of its own: what a one-buffer fallback pass runs on
+// (same counters, AP list, summary, events and carry as the pass it redoes).
+int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp)
+{
+    if (int rc = ensure_fallback(c)) return rc;
+    tmp = sl;
+    tmp.d_hits = c->fb.d_hits;
+    tmp.h_rec = c->fb.h_rec;
+    tmp.h_rec_dev = c->fb.h_rec_dev;
+    tmp.hits_cap = kWorstPerChunk;
+    return ADSB_OK;
+}
+
+// Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
+// reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
+int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
+                 uint32_t n_chunks, bool inline_tail, bool lead_from_src,
+                 bool advance_carry, bool force_simple, hipEvent_t input_done)
+{
+    // Passes of many buffers of a dense stream hand their hits over in (buffer, j, try_phase) order and
+    // scored; a small pass is all launch overhead and a sparse one leaves a few hundred records that
+    // the host sorts and scores in no time; the worst-case lists of the fallback are the host's too.
+    const bool order_on_device = !force_simple && n_chunks > kInlineTailChunks && sl.hits_cap == c->hits_cap && c->dense_mode;
+    if (order_on_device && c->score.si && !c->exact_valid) {
+        // the device's copy of the filter can only be rebuilt from the host's once every pass in
+        // flight has been replayed: finish them now (their results wait for adsb_collect)
+        if (int rc = park_pending(c)) return rc;
+        if (int rc = resync_exact(c)) return rc;
+    }
+    ScanParams p{};
+    p.src = d_src;
+    p.n_samples = n_samples;
+    p.n_chunks = n_chunks;
+    p.clean_bitmap = nullptr;
+    if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the next clean one
+        p.clean_bitmap = c->d_bitmap[c->cur_bitmap];
+        c->cur_bitmap = (c->cur_bitmap + 1) % kBitmaps;
+    }
+    p.bitmap = c->d_bitmap[c->cur_bitmap];
+    p.hits = sl.d_hits;
+    p.hits_cap = sl.hits_cap;
+    p.ap = sl.d_ap;
+    p.ap_cap = c->ap_cap;
+    p.seg_cap = c->seg_cap;
+    p.dap = c->fb.d_dap;  // only the reference-shaped kernel writes it (force_simple: fallback_slot() came first)
+    p.dap_cap = c->fb.d_dap ? kWorstPerChunk : 0;
+    p.tables = c->d_tables;
+    p.ctr = sl.d_ctr;
+    p.summary = sl.h_sum_dev;
+    p.stagger_ticks = c->stagger_ticks;
+    p.debug_stop = c->debug_stop;
+    p.timeline = c->d_timeline;
+    p.carry = c->carry_over && !from_mag ? sl.d_carry : nullptr;
+    p.lead_from_src = lead_from_src ? 1u : 0u;
+    p.order_cnt = order_on_device ? sl.d_order_cnt : nullptr;
+    p.order_base = order_on_device ? sl.d_order_base : nullptr;
+    p.order_tmp = order_on_device ? sl.d_order_tmp : nullptr;
+    sl.device_scored = false;
+    if (order_on_device && c->score.si) {
+        if (c->exact_valid) {
+            p.score = sl.score;
+            p.score.exact_retired = nullptr;
+            if (c->flush_pending) {  // icao_flush: this pass starts from the clean bitmap
+                p.score.exact_retired = c->exact_bm[c->cur_exact];
+                c->cur_exact ^= 1;
+            }
+            p.score.exact = c->exact_bm[c->cur_exact];
+            p.score.out_msgs = sl.h_msgs_dev;
+            p.score.out_adds = sl.h_adds_dev;
+            p.score.summary = sl.h_ssum_dev;
+            sl.device_scored = true;
+            sl.score_epoch = c->score_epoch;
+        }
+    }
+
+    sl.src = d_src;
+    sl.from_mag = from_mag;
+    sl.n_samples = n_samples;
+    sl.n_chunks = n_chunks;
+    sl.flush_before = c->flush_pending;
+    sl.profiled = c->profiling;
+    const int prof = sl.profiled;
+    sl.seq = c->next_seq++;
+    if (c->next_seq == 0) c->next_seq = 1;
+    sl.scan_seq = ++c->scan_counter;
+    sl.ev[0] = c->scan_ev[sl.scan_seq % kScanEvRing][0];
+    sl.ev[1] = c->scan_ev[sl.scan_seq % kScanEvRing][1];
+    sl.h_sum->seq = 0;  // the records kernel overwrites it, last, with sl.seq
+    p.seq = sl.seq;
+    if (sl.device_scored) {
+        p.score.seq = sl.seq;
+        sl.h_ssum->seq = 0;
+    }
+    // level 1: the scan launch stamps its own begin/end (no extra packets on the stream);
+    // level 2: classic event records between all kernels
+    static const bool ext_events = !tuning_env("ADSB_NO_EXT_EVENTS");
+    const bool fast = !from_mag && !force_simple;
+    p.ev_start = ext_events && prof == 1 && fast ? sl.ev[0] : nullptr;
+    p.ev_stop = ext_events && prof == 1 && fast ? sl.ev[1] : nullptr;
+
+    c->flush_pending = false;
+    const bool classic = prof > 1 || (prof == 1 && (!fast || !ext_events));
+    // odd slots scan on the second stream, unless something orders consecutive passes (the
+    // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
+    static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
+    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (c->submitted & 1u) != 0;
+    hipStream_t ss = c->scan_stream[second ? 1 : 0];
+    // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
+    hipEvent_t ready = input_done;
+    if (!ready) {
+        ready = c->input_ready[second ? 1 : 0];
+        HIP_TRY(c, hipEventRecord(ready, c->stream));
+    }
+    HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
+    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));
+    if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
+        HIP_TRY(c, hipMemcpyAsync(sl.d_carry, c->d_carry_next, kCarrySamples * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, ss));
+    if (int e = force_simple ? launch_scan_simple(p, from_mag, ss) : launch_scan(p, from_mag, ss))
+        return fail(c, (hipError_t)e, "launch_scan");
+    if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], ss));
+    if (p.carry && advance_carry) {
+        // the next submission starts from the end of this one's input (taken now: the caller
+        // may reuse the buffer as soon as this pass is collected)
+        if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, c->d_carry_next, ss))
+            return fail(c, (hipError_t)e, "launch_update_carry");
+    }
+    // the tail runs on its own stream behind the scan: the next pass's scan does not wait
+    // for it (it works on the other slot's lists and counters)
+    // (a blocking call has nothing to overlap with: its tail stays on the scan stream and
+    // saves the cross-stream hand-off)
+    // A small pass is all launch overhead: its tail stays on its scan stream too (the two scan
+    // streams still let consecutive passes overlap), which saves the cross-stream hand-off.
+    if (n_chunks <= kInlineTailChunks) inline_tail = true;
+    hipStream_t ts = inline_tail ? ss : c->tail_stream;
+    if (p.clean_bitmap && fast) {
+        // this pass's records kernel clears the bitmap the previous passes matched against: not
+        // before the pass still in flight (whichever stream its tail is on) is through with it
+        // (a pass whose tail ran on this same in-order stream is already behind us: only tails that
+        // ran elsewhere -- small passes keep theirs on their scan stream -- need the event; it is the
+        // one behind their records kernel, not `done`, which device-scored passes record later, on
+        // the score stream)
+        for (Slot &other : c->slot)
+            if (&other != &sl && other.busy && other.tail_q != ts) HIP_TRY(c, hipStreamWaitEvent(ts, other.recorded, 0));
+    }
+    // The match must see every bit the scans of this and of all earlier passes set in the bitmap
+    // (addresses their clean DF11 / DF17 frames will add).  Behind its own scan it is in stream order or
+    // waits for `scanned`.  Behind the previous pass's scan it is in order when both matches run on the
+    // tail stream (that pass's match waited for its scan); but a small pass matches on its own scan
+    // stream, beside the other one -- where the previous pass may still be scanning, or, the other way
+    // round, where a small previous pass may not even have started (its input still being copied) when
+    // this one's scan is over.  Then the match waits for the previous scan explicitly.  (Scans before the
+    // previous one are behind this pass's scan or the previous pass's, on the same two streams.)
+    HIP_TRY(c, hipEventRecord(sl.scanned, ss));
+    if (!inline_tail) HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+    if (c->prev_scanned && c->prev_scan_stream != ss && (inline_tail || c->prev_inline))
+        HIP_TRY(c, hipStreamWaitEvent(ts, c->prev_scanned, 0));
+    c->prev_scanned = sl.scanned;
+    c->prev_scan_stream = ss;
+    c->prev_inline = inline_tail;
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
+    static const bool skip_match = tuning_env("ADSB_SKIP_MATCH") != nullptr;  // measurement aid (tuning build only): wrong results
+    if (!skip_match)
+        if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
+    if (int e = launch_order_hits(p, ts)) return fail(c, (hipError_t)e, "launch_order_hits");
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
+    // the records kernel writes the records and the summary into the slot's mapped host
+    // memory with write-through stores; `done` only has to say the kernel has drained
+    if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
+        return fail(c, (hipError_t)e, "launch_records");
+    sl.tail_q = ts;
+    // (always: a later pass whose own tail runs on another stream -- a small one behind an icao_flush --
+    // waits for this event before its records kernel clears the bitmap this pass matched against)
+    HIP_TRY(c, hipEventRecord(sl.recorded, ts));
+    if (sl.device_scored) {
+        // Scoring runs on its own in-order stream behind this pass's records kernel, so that the next
+        // pass's match / order / records (tail stream) overlap it: every kernel beside the persistent
+        // scan is latency, and one chain of eight would be longer than the scan it hides behind.
+        // The score stream's order is the filter's order: k_score(i+1) reads the exact bitmap after
+        // k_emit(i) has committed pass i's additions to it.
+        hipStream_t qs = c->score_stream;
+        HIP_TRY(c, hipStreamWaitEvent(qs, sl.recorded, 0));
+        if (int e = launch_score(p, qs)) return fail(c, (hipError_t)e, "launch_score");
+        ts = qs;
+    }
+    if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
+    HIP_TRY(c, hipEventRecord(sl.done, ts));
+    return ADSB_OK;
+}
+
+// The exact bitmap rebuilt from the host's filter table (only while nothing is in flight).
+int resync_exact(adsb_ctx *c)
+{
+    std::vector<uint32_t> addrs;
+    for (uint32_t a : c->filter.table())
+        if (a != 0 && a <= 0xFFFFFFu) addrs.push_back(a);
+    hipStream_t ts = c->score_stream;
+    for (uint32_t *bm : c->exact_bm) HIP_TRY(c, hipMemsetAsync(bm, 0, kBitmapAllocWords * sizeof(uint32_t), ts));
+    if (!addrs.empty()) {
+        if (addrs.size() > c->addrs_cap) {
+            if (c->d_addrs) (void)hipFree(c->d_addrs);
+            c->d_addrs = nullptr;
+            c->addrs_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_addrs, IcaoFilter::kSize * sizeof(uint32_t)));
+            c->addrs_cap = IcaoFilter::kSize;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ts));
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->exact_bm[c->cur_exact], ts))
+            return fail(c, (hipError_t)e, "launch_set_addresses");
+    }
+    HIP_TRY(c, hipStreamSynchronize(ts));  // (rare: only after the host scored a pass itself)
+    c->exact_valid = true;
+    return ADSB_OK;
+}
+
+// The overflow fallback re-runs a pass against the bitmap in use NOW.  Passes submitted after the
+// overflowed one may have rotated the bitmaps (an icao_flush in between) and the retired one has been
+// cleared, so the addresses the filter held before this pass would be missing from the superset:
+// put them back.  At this point the host filter is exactly the state that preceded the pass (later
+// passes have not been replayed yet), and extra bits only widen the superset for later passes.
+int reseed_bitmap_from_filter(adsb_ctx *c)
+{
+    std::vector<uint32_t> addrs;
+    for (uint32_t a : c->filter.table())
+        if (a != 0 && a <= 0xFFFFFFu) addrs.push_back(a);  // DF18 entries (addr | 1 << 25) match no 24-bit residual
+    if (addrs.empty()) return ADSB_OK;
+    if (addrs.size() > c->addrs_cap) {
+        if (c->d_addrs) (void)hipFree(c->d_addrs);
+        c->d_addrs = nullptr;
+        c->addrs_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_addrs, IcaoFilter::kSize * sizeof(uint32_t)));
+        c->addrs_cap = IcaoFilter::kSize;
+    }
+    HIP_TRY(c, hipMemcpy(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->d_bitmap[c->cur_bitmap], c->scan_stream[0]))
+        return fail(c, (hipError_t)e, "launch_set_addresses");
+    return ADSB_OK;
+}
+
+int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail,
+           hipEvent_t input_done)
+{
+    const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
+    if (n_chunks == 0 || n_chunks > kMaxChunks || n_chunks > c->max_chunks) return ADSB_ERR_INVALID;
+    Slot &sl = c->slot[c->submitted % kSlots];
+    if (sl.busy || sl.parked || c->shard_active) return ADSB_ERR_BUSY;
+#ifdef ADSB_TUNING
+    const auto te0 = std::chrono::steady_clock::now();
+#endif
+    int rc = enqueue_pass(c, sl, d_src, from_mag, n_samples, (uint32_t)n_chunks, inline_tail, false, true, false,
+                          input_done);
+#ifdef ADSB_TUNING
+    c->t_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
+#endif
+    if (rc) return rc;
+    sl.busy = true;
+    c->submitted++;
+    return ADSB_OK;
+}
+
+// synchronous pass: everything pending is finished first, in order
+int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out)
+{
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+    int rc = submit(c, d_src, from_mag, n_samples, true);
+    if (rc) return rc;
+    return collect_next(c, out);
+}
+
+// IQ stream of any length resident on the device.
+int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<adsb_msg> &out)
+{
+    if (n_samples == 0) {
+        c->stats = adsb_stats{};
+        return ADSB_OK;
+    }
+    adsb_stats total{};
+    // a device pass takes at most max_chunks buffers (what the context's lists were sized for;
+    // never more than kMaxChunks: entry packing): longer streams go in pieces, which is what
+    // consecutive calls would be -- buffers are independent but for the filter
+    const uint64_t piece = std::min<uint64_t>(kMaxChunks, c->max_chunks) * (uint64_t)kChunkSamples;
+    for (uint64_t off = 0; off < n_samples; off += piece) {
+        const uint64_t n = std::min<uint64_t>(piece, n_samples - off);
+        std::vector<adsb_msg> part;
+        int rc = run_sync(c, (const uint32_t *)d_iq + off, false, n, part);
+        if (rc) return rc;
+        const uint64_t chunk0 = off / kChunkSamples;
+        for (auto &m : part) {
+            m.chunk += chunk0;
+            out.push_back(m);
+        }
+        total.n_chunks += c->stats.n_chunks;
+        total.n_candidates += c->stats.n_candidates;
+        total.n_ap_entries += c->stats.n_ap_entries;
+        total.n_records += c->stats.n_records;
+        total.ms_scan += c->stats.ms_scan;
+        total.ms_scan_exclusive += c->stats.ms_scan_exclusive;
+        total.ms_match += c->stats.ms_match;
+        total.ms_records += c->stats.ms_records;
+        total.ms_total_device += c->stats.ms_total_device;
+        total.retries += c->stats.retries;
+    }
+    total.n_samples = n_samples;
+    c->stats = total;
+    return ADSB_OK;
+}
+
+int ensure_stage(adsb_ctx *c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return ADSB_OK;
+    if (c->d_stage) HIP_TRY(c, hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return ADSB_OK;
+}
+
+}  // namespace host
+}  // namespace adsb
+
+extern "C" {
+
+int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, size_t *length_out)
+{
+    if (!c || (!iq && n) || !data_out) return ADSB_ERR_INVALID;
+    if (n > kChunkSamples) return ADSB_ERR_TOO_LONG;  // reference: index panic, lib.rs:48
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_stage(c, (size_t)kChunkSamples * 4);
+    if (rc) return rc;
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (int e = launch_to_mag(c->d_stage, (uint32_t)n, c->d_mag, c->stream))
+        return fail(c, (hipError_t)e, "launch_to_mag");
+    HIP_TRY(c, hipMemcpyAsync(data_out, c->d_mag, kMagDataLen * sizeof(uint16_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (length_out) *length_out = n;
+    return ADSB_OK;
+}
+
+int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_msg *out, size_t cap,
+                        size_t *n_out)
+{
+    if (!c || !data || (!out && cap)) return ADSB_ERR_INVALID;
+    if (length > kChunkSamples) return ADSB_ERR_TOO_LONG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+    c->stats = adsb_stats{};
+    c->stats.n_samples = length;
+    c->stats.n_chunks = 1;
+    std::vector<adsb_msg> msgs;
+    if (length) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_mag, data, kMagDataLen * sizeof(uint16_t),
+                                  hipMemcpyHostToDevice, c->stream));
+        int rc = run_sync(c, c->d_mag, true, length, msgs);
+        if (rc) return rc;
+    }
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_demod_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples, adsb_msg *out, size_t cap,
+                         size_t *n_out)
+{
+    if (!c || (!d_iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
+    if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<adsb_msg> msgs;
+    int rc = demod_device(c, d_iq, n_samples, msgs);
+    if (rc) return rc;
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+int adsb_submit_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples)
+{
+    if (!c || !d_iq || n_samples == 0) return ADSB_ERR_INVALID;
+    if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
+    if ((n_samples + kChunkSamples - 1) / kChunkSamples > std::min<uint64_t>(kMaxChunks, c->max_chunks))
+        return ADSB_ERR_INVALID;  // more buffers than the context was created for
+    HIP_TRY(c, hipSetDevice(c->device));
+    return submit(c, d_iq, false, n_samples);
+}
+
+int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *out, size_t cap,
+                  size_t *n_out)
+{
+    if (!c || (!iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // stage through the device in pieces of at most max_chunks chunks
+    std::vector<adsb_msg> msgs;
+    adsb_stats total{};
+    const size_t piece = c->max_chunks * (size_t)kChunkSamples;
+    int rc = ensure_stage(c, std::min(piece, std::max<size_t>(n_samples, 1)) * 4);
+    if (rc) return rc;
+    for (size_t off = 0; off < n_samples; off += piece) {
+        const size_t n = std::min(piece, n_samples - off);
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq + 2 * off, n * 4, hipMemcpyHostToDevice, c->stream));
+        std::vector<adsb_msg> part;
+        rc = demod_device(c, c->d_stage, n, part);
+        if (rc) return rc;
+        const uint64_t chunk0 = off / kChunkSamples;
+        for (auto &m : part) {
+            m.chunk += chunk0;
+            msgs.push_back(m);
+        }
+        total.n_chunks += c->stats.n_chunks;
+        total.n_candidates += c->stats.n_candidates;
+        total.n_ap_entries += c->stats.n_ap_entries;
+        total.n_records += c->stats.n_records;
+        total.ms_scan += c->stats.ms_scan;
+        total.ms_scan_exclusive += c->stats.ms_scan_exclusive;
+        total.ms_match += c->stats.ms_match;
+        total.ms_records += c->stats.ms_records;
+        total.ms_total_device += c->stats.ms_total_device;
+        total.retries += c->stats.retries;
+    }
+    total.n_samples = n_samples;
+    c->stats = total;
+    return deliver(c, msgs, out, cap, n_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// adsb_ring.cpp -- the pinned streaming ring (dump1090_rs/src/main.rs:154-167: one read, one demodulation).
+#include "adsb_ctx.h"
+
+using namespace adsb::host;
+
+extern "C" {
+
+int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
+{
+    if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
+    if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->copy_stream_spare) {
+        c->copy_stream = c->copy_stream_spare;
+        c->copy_stream_spare = nullptr;
+    } else {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    }
+    for (auto &r : c->ring) {
+        HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
+        HIP_TRY(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
+    }
+    c->ring_samples = samples_per_slot;
+    return ADSB_OK;
+}
+
+int adsb_ring_acquire(adsb_ctx *c, int16_t **host_iq, size_t *capacity_samples)
+{
+    if (!c || !host_iq || !c->ring_samples) return ADSB_ERR_INVALID;
+    if (c->slot[c->submitted % kSlots].busy || c->slot[c->submitted % kSlots].parked) return ADSB_ERR_BUSY;  // collect the oldest pass first
+    *host_iq = c->ring[c->submitted % kSlots].h_iq;
+    if (capacity_samples) *capacity_samples = c->ring_samples;
+    return ADSB_OK;
+}
+
+int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
+{
+    if (!c || !c->ring_samples || n_samples == 0 || n_samples > c->ring_samples) return ADSB_ERR_INVALID;
+    if (c->slot[c->submitted % kSlots].busy || c->slot[c->submitted % kSlots].parked) return ADSB_ERR_BUSY;
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto &r = c->ring[c->submitted % kSlots];
+    // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's
+    // transfer overlaps the other slot's kernels
+    HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(r.copied, c->copy_stream));
+    return submit(c, r.d_iq, false, n_samples, false, r.copied);
+}
+
+}  // extern "C"
