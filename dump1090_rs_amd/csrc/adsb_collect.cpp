@@ -149,7 +149,10 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
 #ifdef ADSB_TUNING
     const auto tw0 = std::chrono::steady_clock::now();
 #endif
-    HIP_TRY(c, hipEventSynchronize(sl.done));
+    {
+        HT(c, HT_SYNC);
+        HIP_TRY(c, hipEventSynchronize(sl.done));
+    }
 #ifdef ADSB_TUNING
     c->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
 #endif
@@ -161,8 +164,10 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     const size_t n = sl.h_sum->n_hits;
     // (k_records' own test: a pass that k_score took over has left its records in device memory)
     const bool rec_on_device = sl.device_scored && n <= c->score.cap;
-    if (!rec_on_device)
+    if (!rec_on_device) {
+        HT(c, HT_VERIFY);
         if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    }
     if (sl.profiled) {
         float ms = 0;
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
@@ -222,7 +227,10 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
 #ifdef ADSB_TUNING
     const auto tr0 = std::chrono::steady_clock::now();
 #endif
-    if (!skip_replay) replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out, &c->host_sorts);
+    {
+        HT(c, HT_REPLAY);
+        if (!skip_replay) replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out, &c->host_sorts);
+    }
 #ifdef ADSB_TUNING
     c->t_replay += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
 #endif

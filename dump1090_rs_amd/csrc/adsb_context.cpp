@@ -231,6 +231,19 @@ void adsb_destroy(adsb_ctx *c)
         std::fprintf(stderr, "host times over %llu passes: enqueue %.1f us, wait %.1f us, replay %.1f us per pass\n",
                      (unsigned long long)c->collected, 1e6 * c->t_enqueue / (c->collected ? c->collected : 1),
                      1e6 * c->t_wait / (c->collected ? c->collected : 1), 1e6 * c->t_replay / (c->collected ? c->collected : 1));
+    if (tuning_env("ADSB_HOST_TIMES")) {
+        static const char *name[HT_COUNT] = {"ring: hipMemcpyAsync", "ring: event record (copied)", "input-ready record + wait",
+                                             "scan launch", "scanned record + waits", "match (+ order) launch", "records launch",
+                                             "recorded / done records", "collect: wait for the pass", "collect: record checksum",
+                                             "collect: replay"};
+        double all = 0;
+        for (int k = 0; k < HT_COUNT; k++) all += c->ht_s[k];
+        for (int k = 0; k < HT_COUNT; k++)
+            if (c->ht_n[k])
+                std::fprintf(stderr, "  %-32s %8.2f us per pass  (%llu calls, %.2f us each)  %5.1f %%\n", name[k],
+                             1e6 * c->ht_s[k] / (c->collected ? c->collected : 1), (unsigned long long)c->ht_n[k],
+                             1e6 * c->ht_s[k] / c->ht_n[k], 100.0 * c->ht_s[k] / (all > 0 ? all : 1));
+    }
 #endif
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);

@@ -184,6 +184,8 @@ struct adsb_ctx {
     uint64_t score_epoch = 0;
 #ifdef ADSB_TUNING
     double t_wait = 0, t_replay = 0, t_enqueue = 0;  // host seconds (ADSB_HOST_TIMES prints them at destroy)
+    double ht_s[16] = {};                            // ... and call by call (HT() below)
+    uint64_t ht_n[16] = {};
 #endif
     std::vector<adsb_msg> undelivered;
     bool has_undelivered = false;
@@ -208,6 +210,27 @@ inline int fail(adsb_ctx *c, hipError_t e, const char *what)
         hipError_t e_ = (call);                                           \
         if (e_ != hipSuccess) return ::adsb::host::fail((ctx), e_, #call); \
     } while (0)
+
+// Host seconds per kind of HIP call of a pass (tuning builds only; ADSB_HOST_TIMES=1 prints the table when the
+// context is destroyed: tools/hosttime.py).  `{ HT(c, HT_SCAN_LAUNCH); launch ...; }`
+enum HtKey { HT_RING_MEMCPY, HT_RING_EVENT, HT_IN_READY, HT_SCAN_LAUNCH, HT_EV_SCANNED, HT_MATCH_LAUNCH, HT_RECORDS_LAUNCH,
+             HT_EV_DONE, HT_SYNC, HT_VERIFY, HT_REPLAY, HT_COUNT };
+#ifdef ADSB_TUNING
+struct HostTimer {
+    adsb_ctx *c;
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer(adsb_ctx *c_, int k_) : c(c_), k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer()
+    {
+        c->ht_s[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        c->ht_n[k]++;
+    }
+};
+#define HT(c, k) ::adsb::host::HostTimer ht_timer_##k((c), ::adsb::host::k)
+#else
+#define HT(c, k) do {} while (0)
+#endif
 
 // adsb_pass.cpp
 int ensure_fallback(adsb_ctx *c);

@@ -129,17 +129,23 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     hipStream_t ss = c->scan_stream[second ? 1 : 0];
     // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
     hipEvent_t ready = input_done;
-    if (!ready) {
-        ready = c->input_ready[second ? 1 : 0];
-        HIP_TRY(c, hipEventRecord(ready, c->stream));
+    {
+        HT(c, HT_IN_READY);
+        if (!ready) {
+            ready = c->input_ready[second ? 1 : 0];
+            HIP_TRY(c, hipEventRecord(ready, c->stream));
+        }
+        HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     }
-    HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));
     if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
         HIP_TRY(c, hipMemcpyAsync(sl.d_carry, c->d_carry_next, kCarrySamples * sizeof(uint32_t),
                                   hipMemcpyDeviceToDevice, ss));
-    if (int e = force_simple ? launch_scan_simple(p, from_mag, ss) : launch_scan(p, from_mag, ss))
-        return fail(c, (hipError_t)e, "launch_scan");
+    {
+        HT(c, HT_SCAN_LAUNCH);
+        if (int e = force_simple ? launch_scan_simple(p, from_mag, ss) : launch_scan(p, from_mag, ss))
+            return fail(c, (hipError_t)e, "launch_scan");
+    }
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], ss));
     if (p.carry && advance_carry) {
         // the next submission starts from the end of this one's input (taken now: the caller
@@ -173,27 +179,39 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // round, where a small previous pass may not even have started (its input still being copied) when
     // this one's scan is over.  Then the match waits for the previous scan explicitly.  (Scans before the
     // previous one are behind this pass's scan or the previous pass's, on the same two streams.)
-    HIP_TRY(c, hipEventRecord(sl.scanned, ss));
-    if (!inline_tail) HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
-    if (c->prev_scanned && c->prev_scan_stream != ss && (inline_tail || c->prev_inline))
-        HIP_TRY(c, hipStreamWaitEvent(ts, c->prev_scanned, 0));
+    {
+        HT(c, HT_EV_SCANNED);
+        HIP_TRY(c, hipEventRecord(sl.scanned, ss));
+        if (!inline_tail) HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+        if (c->prev_scanned && c->prev_scan_stream != ss && (inline_tail || c->prev_inline))
+            HIP_TRY(c, hipStreamWaitEvent(ts, c->prev_scanned, 0));
+    }
     c->prev_scanned = sl.scanned;
     c->prev_scan_stream = ss;
     c->prev_inline = inline_tail;
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
     static const bool skip_match = tuning_env("ADSB_SKIP_MATCH") != nullptr;  // measurement aid (tuning build only): wrong results
-    if (!skip_match)
-        if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
-    if (int e = launch_order_hits(p, ts)) return fail(c, (hipError_t)e, "launch_order_hits");
+    {
+        HT(c, HT_MATCH_LAUNCH);
+        if (!skip_match)
+            if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
+        if (int e = launch_order_hits(p, ts)) return fail(c, (hipError_t)e, "launch_order_hits");
+    }
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[3], ts));
     // the records kernel writes the records and the summary into the slot's mapped host
     // memory with write-through stores; `done` only has to say the kernel has drained
-    if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
-        return fail(c, (hipError_t)e, "launch_records");
+    {
+        HT(c, HT_RECORDS_LAUNCH);
+        if (int e = launch_records(p, from_mag, sl.h_rec_dev, ts))
+            return fail(c, (hipError_t)e, "launch_records");
+    }
     sl.tail_q = ts;
     // (always: a later pass whose own tail runs on another stream -- a small one behind an icao_flush --
     // waits for this event before its records kernel clears the bitmap this pass matched against)
-    HIP_TRY(c, hipEventRecord(sl.recorded, ts));
+    {
+        HT(c, HT_EV_DONE);
+        HIP_TRY(c, hipEventRecord(sl.recorded, ts));
+    }
     if (sl.device_scored) {
         // Scoring runs on its own in-order stream behind this pass's records kernel, so that the next
         // pass's match / order / records (tail stream) overlap it: every kernel beside the persistent
@@ -206,7 +224,10 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         ts = qs;
     }
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[4], ts));
-    HIP_TRY(c, hipEventRecord(sl.done, ts));
+    {
+        HT(c, HT_EV_DONE);
+        HIP_TRY(c, hipEventRecord(sl.done, ts));
+    }
     return ADSB_OK;
 }
 

@@ -42,8 +42,14 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     auto &r = c->ring[c->submitted % kSlots];
     // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's
     // transfer overlaps the other slot's kernels
-    HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipEventRecord(r.copied, c->copy_stream));
+    {
+        HT(c, HT_RING_MEMCPY);
+        HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    {
+        HT(c, HT_RING_EVENT);
+        HIP_TRY(c, hipEventRecord(r.copied, c->copy_stream));
+    }
     return submit(c, r.d_iq, false, n_samples, false, r.copied);
 }
 
