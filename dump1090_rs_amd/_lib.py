@@ -126,6 +126,8 @@ def lib() -> C.CDLL:
     L.adsb_selftest_crc_table.restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]
     L.adsb_host_replays.restype = C.c_uint64
+    L.adsb_host_rematches.argtypes = [vp]
+    L.adsb_host_rematches.restype = C.c_uint64
     L.adsb_host_sorts.argtypes = [vp]
     L.adsb_host_sorts.restype = C.c_uint64
     for name in ("adsb_create", "adsb_set_stream", "adsb_set_profiling", "adsb_icao_flush",

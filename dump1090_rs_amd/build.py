@@ -22,7 +22,7 @@ SOURCES = [CSRC / "adsb_scan_fast.hip", CSRC / "adsb_scan_simple.hip", CSRC / "a
            *(CSRC / f for f in ("adsb_context.cpp", "adsb_pass.cpp", "adsb_collect.cpp", "adsb_ring.cpp",
                                 "adsb_shard.cpp", "adsb_selftest.cpp"))]
 HEADERS = [CSRC / "adsb_ctx.h", CSRC / "adsb_device.h", CSRC / "adsb_dev_common.h", CSRC / "adsb_scan_geometry.h",
-           CSRC / "adsb_tables.h", CSRC / "mode_s_host.hpp", PKG.parent / "include" / "adsb_hip.h"]
+           CSRC / "adsb_tables.h", CSRC / "adsb_tail_dev.h", CSRC / "mode_s_host.hpp", PKG.parent / "include" / "adsb_hip.h"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
     "-Wall", "-Wextra", "-x", "hip",

@@ -41,7 +41,9 @@ bool take_device_result(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, std::vecto
     out.insert(out.end(), sl.h_msgs, sl.h_msgs + nm);
     if (chunk_offset)
         for (size_t i = at; i < out.size(); i++) out[i].chunk += chunk_offset;
+    const uint64_t before = c->filter.inserts();
     for (size_t i = 0; i < na; i++) c->filter.add(sl.h_adds[i]);
+    if (c->filter.inserts() != before) c->last_new_insert_seq = sl.scan_seq;
     return true;
 }
 
@@ -151,7 +153,22 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
 #endif
     {
         HT(c, HT_SYNC);
-        HIP_TRY(c, hipEventSynchronize(sl.done));
+        if (sl.fused) {
+            // A one-launch pass has no event behind it: its last workgroup writes the summary into mapped
+            // host memory (after the records, with their checksum), and that is what the host watches for.
+            // Give up spinning after a while (a pass queued behind long ones) and block on its stream.
+            const auto t0 = std::chrono::steady_clock::now();
+            bool seen = false;
+            for (uint32_t spin = 0; !seen; spin++) {
+                seen = __atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) == sl.seq;
+                if (seen) break;
+                __builtin_ia32_pause();
+                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+            if (!seen) HIP_TRY(c, hipStreamSynchronize(sl.tail_q));
+        } else {
+            HIP_TRY(c, hipEventSynchronize(sl.done));
+        }
     }
 #ifdef ADSB_TUNING
     c->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
@@ -161,6 +178,11 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         return ADSB_ERR_HIP;
     }
     if (sl.h_sum->overflow) return 1;
+    // A one-launch pass did not wait for the passes that were in flight on the other scan stream.  If one
+    // of those (all replayed by now: passes are collected in order) taught the filter a NEW address, this
+    // pass's address/parity trials may have been matched before its bit was set: again, through the three
+    // launches (every earlier pass is complete now, so nothing can be missed a second time).
+    if (sl.fused && sl.unsynced_from && c->last_new_insert_seq >= sl.unsynced_from) return 2;
     const size_t n = sl.h_sum->n_hits;
     // (k_records' own test: a pass that k_score took over has left its records in device memory)
     const bool rec_on_device = sl.device_scored && n <= c->score.cap;
@@ -229,7 +251,9 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
 #endif
     {
         HT(c, HT_REPLAY);
+        const uint64_t before = c->filter.inserts();
         if (!skip_replay) replay(c->filter, c->crc, sl.h_rec, n, chunk_offset, out, &c->host_sorts);
+        if (c->filter.inserts() != before) c->last_new_insert_seq = sl.scan_seq;
     }
 #ifdef ADSB_TUNING
     c->t_replay += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
@@ -249,6 +273,24 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     st.n_chunks = sl.n_chunks;
     if (sl.flush_before) c->filter.flush();  // icao_flush() took effect before this pass
     int rc = finish_pass(c, sl, 0, st, out);
+    if (rc == 2) {
+        // a one-launch pass that a pass in flight beside it may have invalidated (finish_pass): once more
+        // through the three launches.  Passes submitted after it may have rotated the bitmaps behind an
+        // icao_flush: as for the overflow fallback, drain the streams and put the filter's addresses (the
+        // state that preceded this pass) back into the bitmap in use.
+        c->rematches++;
+        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
+        HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->score_stream));
+        const bool keep_flush = c->flush_pending;
+        c->flush_pending = false;
+        rc = reseed_bitmap_from_filter(c);
+        if (rc == 0)
+            rc = enqueue_pass(c, sl, sl.src, sl.from_mag, sl.n_samples, sl.n_chunks, true, false, false, false,
+                              input_ready_now(), true);
+        if (rc == 0) rc = finish_pass(c, sl, 0, st, out);
+        c->flush_pending = keep_flush;
+    }
     if (rc > 0 && sl.from_mag) {  // a caller-supplied buffer denser than the fast scan's lists: again, the slow way
         st.retries++;
         for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));

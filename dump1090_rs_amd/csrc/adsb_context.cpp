@@ -110,6 +110,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->lazy_ev, hipEventDisableTiming | hipEventDisableSystemFence));
         for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapAllocWords * sizeof(uint32_t)));
         for (Slot &sl : c->slot) {
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
@@ -276,6 +277,8 @@ void adsb_destroy(adsb_ctx *c)
         if (q) (void)hipStreamSynchronize(q);
     for (hipEvent_t e : c->input_ready)
         if (e) (void)hipEventDestroy(e);
+    if (c->lazy_ev) (void)hipEventDestroy(c->lazy_ev);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
     for (Slot &sl : c->slot) {
         for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot, (void *)sl.score.pos,
@@ -435,6 +438,7 @@ int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
 
 uint64_t adsb_host_sorts(const adsb_ctx *c) { return c ? c->host_sorts : 0; }
 uint64_t adsb_host_replays(const adsb_ctx *c) { return c ? c->host_replays : 0; }
+uint64_t adsb_host_rematches(const adsb_ctx *c) { return c ? c->rematches : 0; }
 
 int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 {
@@ -460,6 +464,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.15 gfx950 scan=v8-gate-reads tail=v3-buckets"; }
+const char *adsb_version(void) { return "adsb_hip 0.16 gfx950 scan=v8-gate-reads tail=v4-one-launch"; }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ struct Slot {
     hipEvent_t recorded = nullptr;  // this pass's records kernel has finished (k_score may start; the superset
                                     // bitmap it matched against may be cleared)
     hipStream_t tail_q = nullptr;   // the stream its match / order / records ran on
+    hipStream_t scan_q = nullptr;   // ... and its scan
     bool device_scored = false;   // this pass went through k_score / k_emit
     uint64_t score_epoch = 0;     // ... against the filter history of this epoch
     uint32_t *d_carry = nullptr;   // carry-over mode: the kCarrySamples samples before this pass's input
@@ -71,6 +72,13 @@ struct Slot {
     hipEvent_t scanned = nullptr;  // scan stream: this pass's scan has finished
     uint32_t seq = 0;   // what the records kernel writes into h_sum->seq (sanity check)
     uint64_t scan_seq = 0;  // running number of the pass (ms_scan_exclusive: was the previous scan the previous pass?)
+    // A pass of a few buffers is ONE launch (k_scan_fast<.., FUSED>: scan, match, records): no event is
+    // recorded behind it -- the host sees its summary land in mapped memory -- and it does not wait for a
+    // one-launch pass still running on the other scan stream.  `unsynced_from`: the oldest pass that was in
+    // flight then (0: none); if any pass from there on turns out to have taught the filter a new address,
+    // this pass's match may have missed it and the pass is redone through the three-launch path.
+    bool fused = false;
+    uint64_t unsynced_from = 0;
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int profiled = 0;  // profiling level the pass was enqueued with
@@ -95,6 +103,8 @@ struct adsb_ctx {
 
     void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
     size_t stage_bytes = 0;
+    void *h_stage = nullptr, *h_stage_dev = nullptr;  // ... pinned and mapped, for calls of a few buffers: the pass reads it in place
+    size_t h_stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
     // Address bitmaps in rotation (one more than passes in flight): icao_flush moves on to the
     // next (clean) one, the retired one is cleared by that pass's records kernel and comes back
@@ -115,6 +125,10 @@ struct adsb_ctx {
     hipEvent_t prev_scanned = nullptr;      // the latest submission's scan-end event and the stream it is on
     hipStream_t prev_scan_stream = nullptr;
     bool prev_inline = false;               // ... and whether its match ran there rather than on the tail stream
+    bool prev_fused = false;                // ... as part of the scan's own launch (no event behind it: prev_scanned is stale)
+    hipEvent_t lazy_ev = nullptr;           // recorded on a stream at the moment somebody has to wait for a one-launch pass on it
+    uint64_t last_new_insert_seq = 0;       // the latest pass whose replay put a NEW address into the filter
+    uint64_t rematches = 0;                 // one-launch passes redone because a pass in flight beside them did
     hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;
@@ -147,6 +161,7 @@ struct adsb_ctx {
     // other slot's pass computes
     struct RingSlot {
         int16_t *h_iq = nullptr;
+        void *h_iq_dev = nullptr;  // the same pinned buffer as the device addresses it (slots of a few buffers are read in place)
         void *d_iq = nullptr;
         hipEvent_t copied = nullptr;
     } ring[kSlots];
@@ -235,16 +250,23 @@ struct HostTimer {
 // adsb_pass.cpp
 int ensure_fallback(adsb_ctx *c);
 int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp);
+// input_done: the event behind which the input is complete; kInputReadyNow: it already is (host-visible
+// pinned memory the caller has filled); null: wherever `stream` stands now.  no_fuse: three launches even
+// for a pass of a few buffers.
+inline hipEvent_t input_ready_now() { return reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(1)); }
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples, uint32_t n_chunks,
                  bool inline_tail = false, bool lead_from_src = false, bool advance_carry = true,
-                 bool force_simple = false, hipEvent_t input_done = nullptr);
+                 bool force_simple = false, hipEvent_t input_done = nullptr, bool no_fuse = false);
+int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other);
 int resync_exact(adsb_ctx *c);
 int reseed_bitmap_from_filter(adsb_ctx *c);
 int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false,
            hipEvent_t input_done = nullptr);
-int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out);
+int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out,
+             hipEvent_t input_done = nullptr);
 int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<adsb_msg> &out);
 int ensure_stage(adsb_ctx *c, size_t bytes);
+int ensure_host_stage(adsb_ctx *c, size_t bytes);
 
 // adsb_collect.cpp
 void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,

@@ -290,10 +290,12 @@ __device__ __forceinline__ void bitmap_clear(uint32_t *bitmap, uint32_t gi, uint
         ((uint4 *)bitmap)[v] = make_uint4((v == 0 || v == kBitmapWords / 4) ? 1u : 0u, 0u, 0u, 0u);
 }
 
-__device__ __forceinline__ void bitmap_set(uint32_t *bitmap, uint32_t addr)
+// returns true when the address bit was clear before
+__device__ __forceinline__ bool bitmap_set(uint32_t *bitmap, uint32_t addr)
 {
-    atomicOr(&bitmap[addr >> 5], 1u << (addr & 31));
+    const uint32_t old = atomicOr(&bitmap[addr >> 5], 1u << (addr & 31));
     atomicOr(&bitmap[kBitmapWords + ((addr & 4095u) >> 5)], 1u << (addr & 31));  // the summary
+    return ((old >> (addr & 31)) & 1u) == 0;
 }
 
 // samples in `chunk` of a call over n_samples (the last chunk may be short)

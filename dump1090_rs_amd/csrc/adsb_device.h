@@ -96,11 +96,13 @@ constexpr int kApWaveSegs = 4 * kApSegments;  // one per wave of a persistent wo
 struct Counters {
     uint32_t n_hits;       // entries in the hit list
     uint32_t overflow;     // bit0: hit list, bit1: an AP segment, bit3: dap list
-    uint32_t reserved0;
+    uint32_t scan_blocks_done;  // one-launch pass: scan workgroups that have finished (the last one runs the tail)
     uint32_t n_dap;        // entries in the dap list
     uint32_t n_cand_simple;  // candidates seen by the simple kernel (diagnostic)
     uint32_t blocks_done;    // records kernel: blocks that have finished (last one publishes)
     uint32_t rec_sum[2];     // records kernel: 64-bit sum of every u64 word of the records it wrote (8-byte aligned)
+    uint32_t learned_new;    // one-launch pass: a trial of this pass set an address bit that was clear before
+    uint32_t reserved1;
     uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
 };
@@ -213,6 +215,9 @@ struct ScanParams {
     uint32_t cand_cap;
     // device-side scoring (k_score / k_emit; score.si null: the host replays the records)
     ScoreDev score;
+    // one-launch pass (k_scan_fast<.., FUSED>: scan + match + records in one kernel, for passes of a few
+    // buffers): where its records go (mapped host memory), else null
+    TrialRecord *fused_rec;
 };
 
 
@@ -234,6 +239,9 @@ int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
 // set); only needed once per context: afterwards every pass cleans up for the next one
 int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream);
 int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
+// the whole pass in one launch (p.fused_rec set): one workgroup per tile, the last one to finish matches
+// what the pass learned late, builds the records and publishes the summary; for passes of a few buffers
+int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream);
 int scan_resident_blocks();  // workgroups of the fast scan's persistent grid (<= kApSegments)
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_match(const ScanParams &p, void *stream);

@@ -33,11 +33,24 @@ int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp)
     return ADSB_OK;
 }
 
+// `waiter` waits until `other`'s pass is through matching (its records kernel has finished): the event
+// behind a three-launch pass, or -- a one-launch pass records none -- an event put on its stream now.
+int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other)
+{
+    if (other.fused) {
+        HIP_TRY(c, hipEventRecord(c->lazy_ev, other.tail_q));
+        HIP_TRY(c, hipStreamWaitEvent(waiter, c->lazy_ev, 0));
+    } else {
+        HIP_TRY(c, hipStreamWaitEvent(waiter, other.recorded, 0));
+    }
+    return ADSB_OK;
+}
+
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
                  uint32_t n_chunks, bool inline_tail, bool lead_from_src,
-                 bool advance_carry, bool force_simple, hipEvent_t input_done)
+                 bool advance_carry, bool force_simple, hipEvent_t input_done, bool no_fuse)
 {
     // Passes of many buffers of a dense stream hand their hits over in (buffer, j, try_phase) order and
     // scored; a small pass is all launch overhead and a sparse one leaves a few hundred records that
@@ -117,6 +130,14 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // level 2: classic event records between all kernels
     static const bool ext_events = !tuning_env("ADSB_NO_EXT_EVENTS");
     const bool fast = !from_mag && !force_simple;
+    // A pass of a few buffers is all launch overhead and event traffic: it goes out as ONE launch whose
+    // last workgroup matches, builds the records and publishes the summary (k_scan_fast<.., FUSED>), with
+    // no event behind it.  (Level-2 profiling wants the three kernels apart.)
+    static const bool never_fuse = tuning_env("ADSB_NO_FUSE") != nullptr;
+    const bool fused = !force_simple && !no_fuse && !never_fuse && prof <= 1 && n_chunks <= kInlineTailChunks;
+    sl.fused = fused;
+    sl.unsynced_from = 0;
+    p.fused_rec = fused ? sl.h_rec_dev : nullptr;
     p.ev_start = ext_events && prof == 1 && fast ? sl.ev[0] : nullptr;
     p.ev_stop = ext_events && prof == 1 && fast ? sl.ev[1] : nullptr;
 
@@ -127,23 +148,57 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
     const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (c->submitted & 1u) != 0;
     hipStream_t ss = c->scan_stream[second ? 1 : 0];
-    // the input is complete at `input_done` (the ring's copy) or where `stream` stands now
-    hipEvent_t ready = input_done;
-    {
+    // the input is complete at `input_done` (the ring's copy), already (input_ready_now: pinned memory the
+    // host has filled), or where `stream` stands now
+    if (input_done != input_ready_now()) {
         HT(c, HT_IN_READY);
+        hipEvent_t ready = input_done;
         if (!ready) {
             ready = c->input_ready[second ? 1 : 0];
             HIP_TRY(c, hipEventRecord(ready, c->stream));
         }
         HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     }
+    if (n_chunks <= kInlineTailChunks) inline_tail = true;
+    // ---- cross-stream edges (DESIGN.md section 5b is the table of them) -------------------------------
+    // (1) A bitmap an icao_flush retired is cleared by this pass (its records kernel, or every workgroup
+    //     of a one-launch pass): not before the passes still in flight, whichever stream their tail is on,
+    //     are through matching against it.  A tail on this same in-order stream is behind us already.
+    // (2) The match must see every address bit the scans of this and of all earlier passes set.  Behind
+    //     its own scan it is in stream order or waits for `scanned`.  Behind the previous pass's scan it is
+    //     in order when both matches run on the tail stream (that pass's match waited for its scan); a pass
+    //     whose match runs on its own scan stream waits for the previous scan explicitly when that ran on
+    //     the other one.  (Scans before the previous one are behind this pass's scan or the previous
+    //     pass's, on the same two streams.)
+    // (3) One-launch passes record no event and do not wait for each other across the two scan streams:
+    //     a three-launch pass that needs one of them behind it records an event on that stream now; a
+    //     one-launch pass notes from which pass on its match is unsynchronised (Slot::unsynced_from) and
+    //     the host redoes it if one of those turns out to have taught the filter a new address.
+    if (fused) {
+        HT(c, HT_EV_SCANNED);
+        if (p.clean_bitmap)
+            for (Slot &other : c->slot)
+                if (&other != &sl && other.busy && other.tail_q != ss)
+                    if (int rc = wait_for_tail_of(c, ss, other)) return rc;
+        bool other_stream_synced = false;
+        if (c->prev_scan_stream && c->prev_scan_stream != ss && !c->prev_fused && c->prev_scanned) {
+            HIP_TRY(c, hipStreamWaitEvent(ss, c->prev_scanned, 0));
+            other_stream_synced = true;   // (in stream order behind it: every earlier pass on that stream)
+        }
+        if (!other_stream_synced)   // (every pass in flight whose scan is not in stream order before this launch)
+            for (Slot &other : c->slot)
+                if (&other != &sl && other.busy && other.scan_q != ss)
+                    sl.unsynced_from = sl.unsynced_from ? std::min(sl.unsynced_from, other.scan_seq) : other.scan_seq;
+    }
+    sl.scan_q = ss;
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));
     if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
         HIP_TRY(c, hipMemcpyAsync(sl.d_carry, c->d_carry_next, kCarrySamples * sizeof(uint32_t),
                                   hipMemcpyDeviceToDevice, ss));
     {
         HT(c, HT_SCAN_LAUNCH);
-        if (int e = force_simple ? launch_scan_simple(p, from_mag, ss) : launch_scan(p, from_mag, ss))
+        if (int e = fused ? launch_pass_fused(p, from_mag, ss)
+                          : (force_simple ? launch_scan_simple(p, from_mag, ss) : launch_scan(p, from_mag, ss)))
             return fail(c, (hipError_t)e, "launch_scan");
     }
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[1], ss));
@@ -153,42 +208,49 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         if (int e = launch_update_carry(sl.d_carry, d_src, n_samples, c->d_carry_next, ss))
             return fail(c, (hipError_t)e, "launch_update_carry");
     }
+    if (fused) {
+        sl.tail_q = ss;
+        c->prev_scanned = nullptr;
+        c->prev_scan_stream = ss;
+        c->prev_inline = true;
+        c->prev_fused = true;
+        return ADSB_OK;
+    }
     // the tail runs on its own stream behind the scan: the next pass's scan does not wait
     // for it (it works on the other slot's lists and counters)
     // (a blocking call has nothing to overlap with: its tail stays on the scan stream and
     // saves the cross-stream hand-off)
     // A small pass is all launch overhead: its tail stays on its scan stream too (the two scan
     // streams still let consecutive passes overlap), which saves the cross-stream hand-off.
-    if (n_chunks <= kInlineTailChunks) inline_tail = true;
     hipStream_t ts = inline_tail ? ss : c->tail_stream;
     if (p.clean_bitmap && fast) {
-        // this pass's records kernel clears the bitmap the previous passes matched against: not
-        // before the pass still in flight (whichever stream its tail is on) is through with it
-        // (a pass whose tail ran on this same in-order stream is already behind us: only tails that
-        // ran elsewhere -- small passes keep theirs on their scan stream -- need the event; it is the
-        // one behind their records kernel, not `done`, which device-scored passes record later, on
-        // the score stream)
+        // edge (1): the event behind the other passes' records kernels, not `done`, which device-scored
+        // passes record later, on the score stream
         for (Slot &other : c->slot)
-            if (&other != &sl && other.busy && other.tail_q != ts) HIP_TRY(c, hipStreamWaitEvent(ts, other.recorded, 0));
+            if (&other != &sl && other.busy && other.tail_q != ts)
+                if (int rc = wait_for_tail_of(c, ts, other)) return rc;
     }
-    // The match must see every bit the scans of this and of all earlier passes set in the bitmap
-    // (addresses their clean DF11 / DF17 frames will add).  Behind its own scan it is in stream order or
-    // waits for `scanned`.  Behind the previous pass's scan it is in order when both matches run on the
-    // tail stream (that pass's match waited for its scan); but a small pass matches on its own scan
-    // stream, beside the other one -- where the previous pass may still be scanning, or, the other way
-    // round, where a small previous pass may not even have started (its input still being copied) when
-    // this one's scan is over.  Then the match waits for the previous scan explicitly.  (Scans before the
-    // previous one are behind this pass's scan or the previous pass's, on the same two streams.)
     {
         HT(c, HT_EV_SCANNED);
         HIP_TRY(c, hipEventRecord(sl.scanned, ss));
         if (!inline_tail) HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
-        if (c->prev_scanned && c->prev_scan_stream != ss && (inline_tail || c->prev_inline))
+        // edge (2)
+        if (c->prev_scanned && !c->prev_fused && c->prev_scan_stream != ss && (inline_tail || c->prev_inline))
             HIP_TRY(c, hipStreamWaitEvent(ts, c->prev_scanned, 0));
+        // edge (3): one-launch passes in flight on a stream this match is not behind
+        for (hipStream_t q : c->scan_stream) {
+            if (q == ts || (q == ss && !inline_tail)) continue;   // (behind its own scan: behind everything on that stream)
+            bool any = false;
+            for (Slot &other : c->slot) any = any || (&other != &sl && other.busy && other.fused && other.tail_q == q);
+            if (!any) continue;
+            HIP_TRY(c, hipEventRecord(c->lazy_ev, q));
+            HIP_TRY(c, hipStreamWaitEvent(ts, c->lazy_ev, 0));
+        }
     }
     c->prev_scanned = sl.scanned;
     c->prev_scan_stream = ss;
     c->prev_inline = inline_tail;
+    c->prev_fused = false;
     if (prof > 1) HIP_TRY(c, hipEventRecord(sl.ev[2], ts));
     static const bool skip_match = tuning_env("ADSB_SKIP_MATCH") != nullptr;  // measurement aid (tuning build only): wrong results
     {
@@ -302,10 +364,11 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bo
 }
 
 // synchronous pass: everything pending is finished first, in order
-int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out)
+int run_sync(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, std::vector<adsb_msg> &out,
+             hipEvent_t input_done)
 {
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
-    int rc = submit(c, d_src, from_mag, n_samples, true);
+    int rc = submit(c, d_src, from_mag, n_samples, true, input_done);
     if (rc) return rc;
     return collect_next(c, out);
 }
@@ -345,6 +408,20 @@ int demod_device(adsb_ctx *c, const void *d_iq, uint64_t n_samples, std::vector<
     }
     total.n_samples = n_samples;
     c->stats = total;
+    return ADSB_OK;
+}
+
+// pinned, mapped staging for host-pointer calls of a few buffers: the pass reads it in place over the
+// link, which saves the copy command and its event
+int ensure_host_stage(adsb_ctx *c, size_t bytes)
+{
+    if (bytes <= c->h_stage_bytes) return ADSB_OK;
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = c->h_stage_dev = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, hipHostGetDevicePointer(&c->h_stage_dev, c->h_stage, 0));
+    c->h_stage_bytes = bytes;
     return ADSB_OK;
 }
 
@@ -432,8 +509,35 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
     std::vector<adsb_msg> msgs;
     adsb_stats total{};
     const size_t piece = c->max_chunks * (size_t)kChunkSamples;
-    int rc = ensure_stage(c, std::min(piece, std::max<size_t>(n_samples, 1)) * 4);
+    // A call of a few buffers (the reference's own call shape, benches/demod_benchmark.rs:10-11: one
+    // 131072-sample buffer) is one launch that reads the samples in place from pinned host memory: one
+    // host copy into it instead of a copy command, its staging inside the runtime and an event.
+    const bool in_place = n_samples <= (size_t)kInlineTailChunks * kChunkSamples && !c->carry_over;
+    int rc = in_place ? ensure_host_stage(c, std::max<size_t>(n_samples, 1) * 4)
+                      : ensure_stage(c, std::min(piece, std::max<size_t>(n_samples, 1)) * 4);
     if (rc) return rc;
+    if (in_place && n_samples) {
+        std::memcpy(c->h_stage, iq, n_samples * 4);
+        for (size_t off = 0; off < n_samples; off += piece) {
+            const size_t n = std::min(piece, n_samples - off);
+            std::vector<adsb_msg> part;
+            rc = run_sync(c, (const uint32_t *)c->h_stage_dev + off, false, n, part, input_ready_now());
+            if (rc) return rc;
+            const uint64_t chunk0 = off / kChunkSamples;
+            for (auto &m : part) {
+                m.chunk += chunk0;
+                msgs.push_back(m);
+            }
+            const adsb_stats &st = c->stats;
+            total.n_chunks += st.n_chunks, total.n_candidates += st.n_candidates, total.n_ap_entries += st.n_ap_entries;
+            total.n_records += st.n_records, total.ms_scan += st.ms_scan, total.ms_scan_exclusive += st.ms_scan_exclusive;
+            total.ms_match += st.ms_match, total.ms_records += st.ms_records, total.ms_total_device += st.ms_total_device;
+            total.retries += st.retries;
+        }
+        total.n_samples = n_samples;
+        c->stats = total;
+        return deliver(c, msgs, out, cap, n_out);
+    }
     for (size_t off = 0; off < n_samples; off += piece) {
         const size_t n = std::min(piece, n_samples - off);
         HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq + 2 * off, n * 4, hipMemcpyHostToDevice, c->stream));

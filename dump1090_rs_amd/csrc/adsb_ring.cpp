@@ -17,7 +17,9 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     }
     for (auto &r : c->ring) {
-        HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocDefault));
+        // (mapped and coherent: slots of a few buffers are read in place by the pass itself)
+        HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer(&r.h_iq_dev, r.h_iq, 0));
         HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
         HIP_TRY(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
     }
@@ -40,6 +42,13 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     if (c->slot[c->submitted % kSlots].busy || c->slot[c->submitted % kSlots].parked) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipSetDevice(c->device));
     auto &r = c->ring[c->submitted % kSlots];
+    // A slot of a few buffers (the reference reads and demodulates 131072 samples at a time,
+    // dump1090_rs/src/main.rs:161-167) is one launch that reads the pinned buffer in place over the link:
+    // no copy command, no event, no staging -- the pass is as long as the transfer either way, and the
+    // host side of it is a single launch.  Larger slots are copied while the slots before them compute.
+    static const bool always_copy = tuning_env("ADSB_RING_COPY") != nullptr;
+    if (!always_copy && (n_samples + kChunkSamples - 1) / kChunkSamples <= kInlineTailChunks && !c->carry_over)
+        return submit(c, r.h_iq_dev, false, n_samples, false, input_ready_now());
     // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's
     // transfer overlaps the other slot's kernels
     {

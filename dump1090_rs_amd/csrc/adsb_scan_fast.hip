@@ -48,6 +48,7 @@
 
 #include "adsb_dev_common.h"
 #include "adsb_scan_geometry.h"
+#include "adsb_tail_dev.h"
 
 namespace adsb {
 
@@ -485,7 +486,9 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint
     }
     if (__ballot(is_hit)) stage_hit(p, s, is_hit, entry, lane, par);  // rare
     if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
-        if (learn) bitmap_set(p.bitmap, trial_addr(tr));
+        // (one-launch pass: an address bit that was clear until now means trials this pass has already
+        // matched may have missed it -- its last workgroup then matches the lists once more)
+        if (learn && bitmap_set(p.bitmap, trial_addr(tr)) && p.fused_rec) atomicOr(&p.ctr->learned_new, 1u);
     }
 }
 
@@ -523,13 +526,48 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
 // t = block, block + grid, ...  The IQ of the next tile is loaded into registers right
 // after the magnitudes of the current one are in LDS, so HBM latency hides behind P2..P5.
-template <bool FROM_MAG, bool SELFTEST = false>
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
+// LDS only the one-launch instantiation has: the x^56 multiplier (adsb_tables.h) for its own match
+template <bool FUSED>
+struct FusedLds {
+    uint32_t x56[3 * 256];
+    uint32_t is_last;
+};
+template <>
+struct FusedLds<false> {
+};
+
+// One address/parity entry against the bitmap (k_match's test: adsb_aux.hip); a match goes to the hit
+// list and the entry is marked (code 15) so that a second look does not report it twice.
+__device__ __forceinline__ void fused_match_entry(const ScanParams &p, const uint32_t *x56, uint64_t *slot, uint64_t e)
+{
+    const uint32_t code = entry_code(e);
+    if (code == 15u) return;
+    uint32_t c = entry_value(e);
+    if (code >= 5u && code < 10u) c = gf_apply(x56, c);
+    // (agent scope: bits other workgroups of this launch have set, not a line this CU's cache holds)
+    const uint32_t w = __hip_atomic_load(&p.bitmap[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((w >> (c & 31)) & 1u) {
+        const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
+        if (idx < p.hits_cap) p.hits[idx] = e;
+        else atomicOr(&p.ctr->overflow, 1u);
+        *slot = e | (15ull << 24);
+    }
+}
+
+template <bool FROM_MAG, bool SELFTEST = false, bool FUSED = false>
+__global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
+    __shared__ FusedLds<FUSED> fs;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
+    if constexpr (FUSED) {
+        for (int i = tid; i < 3 * 256; i += kThreads) fs.x56[i] = p.tables[kTabX56 * 256 + i];
+        // an icao_flush retired a bitmap: every workgroup clears its share (k_records does it for the
+        // passes of three launches)
+        if (p.clean_bitmap) bitmap_clear(p.clean_bitmap, blockIdx.x * kThreads + tid, gridDim.x * kThreads);
+    }
 
     // ---------------------------------------------------------------- P0 once per workgroup
     for (int i = tid; i < 3 * 256; i += kThreads) s.tab[i] = p.tables[kTabF * 256 + i];
@@ -877,6 +915,54 @@ tile_end:
         if (ap_count > seg_cap) atomicOr(&p.ctr->overflow, 2u);
         p.ctr->seg_ap[my_seg] = min(ap_count, seg_cap);
     }
+    if constexpr (FUSED) {
+        // ============================================================ the tail of a one-launch pass
+        // (a) Each wave matches its own address/parity entries against the bitmap as it stands now: it
+        // holds every address of the passes before this one (stream order; the host redoes a pass whose
+        // predecessor on the other scan stream turns out to have learned one: adsb_collect.cpp) and
+        // whatever this pass has learned so far.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's entries have left
+        {
+            const uint32_t n_mine = min(ap_count, seg_cap);
+            for (uint32_t i = (uint32_t)lane; i < n_mine; i += 64u)
+                fused_match_entry(p, fs.x56, &seg[i], __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        // (b) The last workgroup to get here runs the rest alone: release what this one wrote (list
+        // entries, marks, counts, address bits), count it in, acquire what the others wrote.
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) fs.is_last = atomicAdd(&p.ctr->scan_blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (!fs.is_last) return;
+        __threadfence();
+        // (c) An address bit that was clear when the pass began was set on the way: entries matched
+        // before that moment may have missed it (a trial must see what EARLIER positions taught, and a
+        // workgroup that scanned a later tile may have finished first -- extra hits are harmless, the
+        // host replay scores in order).  Once more over every segment, marked entries skipped.
+        if (__hip_atomic_load(&p.ctr->learned_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const uint32_t nseg = gridDim.x * (uint32_t)kWaves;
+            constexpr uint32_t U = 8;  // segments a wave has in flight (each a chain count -> entry -> bitmap word)
+            for (uint32_t g0 = (uint32_t)(tid >> 6) * U; g0 < nseg; g0 += kWaves * U) {
+                uint32_t n[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) n[u] = g0 + u < nseg ? min(p.ctr->seg_ap[g0 + u], seg_cap) : 0u;
+                uint32_t nmax = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) nmax = max(nmax, n[u]);
+                for (uint32_t i = (uint32_t)lane; i < nmax; i += 64u) {
+                    uint64_t e[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) e[u] = i < n[u] ? p.ap[(uint64_t)(g0 + u) * seg_cap + i] : (15ull << 24);
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) fused_match_entry(p, fs.x56, &p.ap[(uint64_t)(g0 + u) * seg_cap + i], e[u]);
+                }
+            }
+            __threadfence();
+        }
+        __syncthreads();
+        // (d) records, checksum, summary into mapped host memory; the counters back to zero
+        records_block<FROM_MAG, false>(p, p.fused_rec, 0u, 1u, nullptr, false);
+    }
 }
 
 inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -907,6 +993,21 @@ int scan_resident_blocks()
         return r;
     }();
     return resident;
+}
+
+int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream)
+{
+    hip_clear();
+    const uint32_t tiles = p.n_chunks * kTilesPerChunk;  // one workgroup per tile: a pass of a few buffers
+    if (tiles == 0 || !p.fused_rec) return (int)hipErrorInvalidValue;
+    if (from_mag)
+        hipLaunchKernelGGL((k_scan_fast<true, false, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else if (p.ev_start && p.ev_stop)
+        hipExtLaunchKernelGGL((k_scan_fast<false, false, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream,
+                              (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
+    else
+        hipLaunchKernelGGL((k_scan_fast<false, false, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
+    return hip_ok(hipGetLastError());
 }
 
 int launch_scan(const ScanParams &p, bool from_mag, void *stream)

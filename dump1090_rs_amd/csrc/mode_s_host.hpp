@@ -48,6 +48,7 @@ class IcaoFilter {
             if (table_[h] == addr) return;
             if (table_[h] == 0) {
                 table_[h] = addr;
+                inserts_++;
                 return;
             }
             h = (h + 1) & (kSize - 1);
@@ -67,11 +68,14 @@ class IcaoFilter {
     }
 
     const std::array<uint32_t, kSize> &table() const { return table_; }
+    // how many values add() has newly put into the table so far (never reset: callers compare)
+    uint64_t inserts() const { return inserts_; }
     void load(const uint32_t *t) { std::memcpy(table_.data(), t, sizeof(uint32_t) * kSize); }
     void store(uint32_t *t) const { std::memcpy(t, table_.data(), sizeof(uint32_t) * kSize); }
 
   private:
     std::array<uint32_t, kSize> table_;
+    uint64_t inserts_ = 0;
 };
 
 // src/crc.rs: Mode-S CRC-24, generator 0xFFF409.

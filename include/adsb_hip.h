@@ -294,6 +294,12 @@ uint64_t adsb_host_sorts(const adsb_ctx *ctx);
  * scored on the device against a device-resident copy of the ICAO filter; small passes, fallbacks,
  * a filter close to its 4096 entries and the passes in flight behind any of those are not. */
 uint64_t adsb_host_replays(const adsb_ctx *ctx);
+/* Diagnostic: how many passes of a few buffers were run a second time.  Such a pass is a single launch
+ * that does not wait for the passes still in flight beside it; when one of those turns out to have added
+ * a NEW address to the filter (src/icao_filter.rs:46-62) -- rare once a receiver has seen the aircraft
+ * around it -- the later pass's address/parity trials may have been matched too early, and it is redone
+ * behind everything else so that the result stays the reference's. */
+uint64_t adsb_host_rematches(const adsb_ctx *ctx);
 const char *adsb_strerror(int status);
 /* Text of the last HIP failure on this context ("" if none). */
 const char *adsb_last_error(const adsb_ctx *ctx);

@@ -95,6 +95,7 @@ unsafe extern "C" {
     pub fn adsb_get_stats(ctx: *const AdsbCtx, out: *mut AdsbStats) -> c_int;
     pub fn adsb_host_sorts(ctx: *const AdsbCtx) -> u64;
     pub fn adsb_host_replays(ctx: *const AdsbCtx) -> u64;
+    pub fn adsb_host_rematches(ctx: *const AdsbCtx) -> u64;
     pub fn adsb_strerror(status: c_int) -> *const c_char;
     pub fn adsb_last_error(ctx: *const AdsbCtx) -> *const c_char;
     pub fn adsb_version() -> *const c_char;

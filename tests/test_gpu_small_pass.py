@@ -1,0 +1,205 @@
+"""The reference's own call shape -- one read, one demodulation of 131072 samples at a time
+(dump1090_rs/src/main.rs:161-167, benches/demod_benchmark.rs:10-11) -- goes through the library as ONE
+launch per pass (k_scan_fast<.., FUSED>: scan, match and records in one kernel, no events, the ring slot
+read in place from pinned host memory).  What that form must get right, against the CPU oracle:
+
+* the pinned ring at one buffer per slot (BASELINE config 3 as written), several passes in flight;
+* an address learned in pass k that a frame in pass k + 1 needs, while k + 1 was launched before k was
+  collected (the host redoes k + 1: adsb_host_rematches);
+* inside one pass: an address/parity frame late in the buffer for an address taught early in it (its
+  workgroup may match before the teaching workgroup has set the bit: the last workgroup looks again),
+  and the reverse (must NOT decode);
+* every entry point at 1 .. 17 buffers (16 is the largest one-launch pass, 17 the smallest of three).
+"""
+import numpy as np
+import pytest
+
+from dump1090_rs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 131072
+
+
+def ap_frame(first_bytes: bytes, icao: int) -> bytes:
+    return first_bytes + (synth.crc24(first_bytes) ^ icao).to_bytes(3, "big")
+
+
+def key(m):
+    return (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
+
+
+def want_key(w, chunk_offset=0):
+    return (w["chunk"] + chunk_offset, w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"])
+
+
+def rematches(c) -> int:
+    return int(c._L.adsb_host_rematches(c._h))
+
+
+def ring_stream(c, iq, per_slot, depth):
+    """`iq` through the ring in slots of `per_slot` samples, `depth` passes in flight; (slot, message) pairs."""
+    n_slots = (len(iq) + per_slot - 1) // per_slot
+    got, collected = [], 0
+    for b in range(n_slots):
+        if c.pending() == depth:
+            got += [(collected, m) for m in c.collect()]
+            collected += 1
+        part = iq[b * per_slot:(b + 1) * per_slot]
+        buf = c.ring_acquire()
+        buf[: len(part)] = part
+        c.ring_submit(len(part))
+    while c.pending():
+        got += [(collected, m) for m in c.collect()]
+        collected += 1
+    assert collected == n_slots
+    return got
+
+
+@pytest.mark.parametrize("depth", [1, 3, 4])
+def test_ring_of_512kb_slots_equals_one_oracle_stream(hip_lib, oracle_mod, depth):
+    """BASELINE config 3 as written: 96 slots of ONE 131072-sample buffer each (the last one ragged),
+    `depth` passes in flight, against one oracle stream over the same bytes.  The stream keeps teaching
+    the filter new addresses (a pool of 40) and holds address/parity frames for them right behind."""
+    from dump1090_rs_amd import Context
+    n = 95 * CHUNK + 70001
+    iq = synth.make_iq(n, n_bursts=500, seed=9400 + depth, n_icao=40, df11_every=5)
+    icao = 0x4B1A2C
+    df4 = ap_frame(bytes([0x20, 0x00, 0x05, 0x30]), icao)
+    df20 = ap_frame(bytes([0xA0, 0x00, 0x05, 0x30, 1, 2, 3, 4, 5, 6, 7]), icao)
+    at = lambda chunk, j: 5 * (chunk * CHUNK + j)
+    synth.add_bursts(iq, [synth.Burst(at(30, 50000), 22000, 1, df4),                       # too early
+                          synth.Burst(at(31, 100000) + 2, 22000, 2, synth.df17_frame(icao, 7)),
+                          synth.Burst(at(32, 300) + 1, 22000, 3, df4),                     # the very next pass
+                          synth.Burst(at(33, 60000) + 3, 22000, 4, df20),
+                          synth.Burst(at(35, 1000), 22000, 5, df4)])
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    with Context(0, 1) as c:
+        c.ring_create(CHUNK)
+        c.icao_flush()
+        got = ring_stream(c, iq, CHUNK, depth)
+        assert [(s,) + key(m)[1:] for s, m in got] == [want_key(w) for w in want]
+        frames = lambda f: sorted(s for s, m in got if m.buffer() == f)
+        assert frames(df4) == [32, 35] and frames(df20) == [33]
+        if depth > 1:   # pass 32 was launched while 31 was in flight: it had to be matched again
+            assert rematches(c) >= 1
+        else:
+            assert rematches(c) == 0
+        # the same stream once more without a flush: everything is known now, nothing is redone
+        before = rematches(c)
+        again = ring_stream(c, iq[: 40 * CHUNK], CHUNK, depth)
+        orc = oracle_mod.Oracle()
+        orc.demod_iq(iq)
+        want2, _ = orc.demod_iq(iq[: 40 * CHUNK])
+        assert [(s,) + key(m)[1:] for s, m in again] == [want_key(w) for w in want2]
+        assert frames(df4) == [32, 35]
+        assert sorted(s for s, m in again if m.buffer() == df4) == [30, 32, 35]    # 30 decodes now
+        assert rematches(c) == before
+
+
+def test_address_taught_early_in_a_buffer_reaches_a_frame_late_in_it_and_not_the_reverse(hip_lib, oracle_mod):
+    """One buffer, one launch, 17 workgroups that finish in any order: a DF17 in the first tile and
+    address/parity frames for its address in the last tiles must decode (score 1000), the mirrored buffer
+    -- frames first, DF17 last -- must not; both a hundred times over, blocking and pipelined."""
+    import torch
+    from dump1090_rs_amd import Context
+    icao = 0x3C6589
+    df4 = ap_frame(bytes([0x20, 0x00, 0x05, 0x30]), icao)
+    df21 = ap_frame(bytes([0xA8, 0x00, 0x05, 0x30, 9, 8, 7, 6, 5, 4, 3]), icao)
+    fwd = synth.noise_numpy(CHUNK, seed=77)
+    synth.add_bursts(fwd, [synth.Burst(5 * 700 + 2, 23000, 1, synth.df17_frame(icao, 1))] +
+                     [synth.Burst(5 * (100000 + 4000 * q) + q % 5, 21000, q, df4 if q % 2 else df21) for q in range(7)])
+    rev = synth.noise_numpy(CHUNK, seed=78)
+    synth.add_bursts(rev, [synth.Burst(5 * (1000 + 4000 * q) + q % 5, 21000, q, df4 if q % 2 else df21) for q in range(7)] +
+                     [synth.Burst(5 * 126000 + 2, 23000, 1, synth.df17_frame(icao, 1))])
+    orc = oracle_mod.Oracle()
+    w_fwd, _ = orc.demod_iq(fwd)
+    orc.icao_flush()
+    w_rev, _ = orc.demod_iq(rev)
+    ap = lambda ws: [w for w in ws if w["buffer"] in (df4, df21)]
+    assert len(ap(w_fwd)) >= 7 and all(w["score"] == 1000 for w in ap(w_fwd)) and not ap(w_rev)
+    d_fwd, d_rev = torch.from_numpy(fwd).cuda(), torch.from_numpy(rev).cuda()
+    torch.cuda.synchronize()
+    with Context(0, 1) as c:
+        for rep in range(100):
+            c.icao_flush()
+            assert [key(m) for m in c.demod_iq_device(d_fwd.data_ptr(), CHUNK)] == [want_key(w) for w in w_fwd]
+            c.icao_flush()
+            assert [key(m) for m in c.demod_iq_device(d_rev.data_ptr(), CHUNK)] == [want_key(w) for w in w_rev]
+        for rep in range(50):   # pipelined, a flush in front of each: four one-launch passes in flight
+            for d in (d_fwd, d_rev, d_fwd, d_rev):
+                c.icao_flush()
+                c.submit_iq_device(d.data_ptr(), CHUNK)
+            for w in (w_fwd, w_rev, w_fwd, w_rev):
+                assert [key(m) for m in c.collect()] == [want_key(x) for x in w]
+        # caller-supplied magnitudes take the same one-launch form (adsb_demodulate2400)
+        c.icao_flush()
+        assert [key(m) for m in c.demodulate2400(c.to_mag(fwd))] == [want_key(w) for w in w_fwd]
+
+
+@pytest.mark.parametrize("n_chunks,cut", [(1, 0), (1, 50000), (2, 131071), (5, 4321), (16, 0), (16, 99), (17, 0), (17, 5000)])
+def test_every_entry_point_at_the_sizes_around_the_one_launch_limit(hip_lib, oracle_mod, n_chunks, cut):
+    """Host pointer (read in place from pinned staging), device pointer, submit / collect, the ring: a
+    capture of n_chunks buffers (the last cut short) through each, same frames as the oracle."""
+    import torch
+    from dump1090_rs_amd import Context
+    n = n_chunks * CHUNK - cut
+    iq = synth.make_iq(n, n_bursts=20 * n_chunks, seed=300 + 7 * n_chunks + cut % 11, n_icao=8, df11_every=3)
+    want = [want_key(w) for w in oracle_mod.Oracle().demod_iq(iq)[0]]
+    dev = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    with Context(0, n_chunks) as c:
+        c.icao_flush()
+        assert [key(m) for m in c.demod_iq(iq)] == want
+        c.icao_flush()
+        assert [key(m) for m in c.demod_iq_device(dev.data_ptr(), n)] == want
+        c.icao_flush()
+        c.submit_iq_device(dev.data_ptr(), n)
+        c.icao_flush()
+        c.submit_iq_device(dev.data_ptr(), n)
+        assert [key(m) for m in c.collect()] == want and [key(m) for m in c.collect()] == want
+        c.ring_create(n_chunks * CHUNK)
+        c.icao_flush()
+        got = ring_stream(c, iq, n_chunks * CHUNK, 2)
+        assert [key(m) for _, m in got] == want
+    # a context sized for one buffer takes the same capture buffer by buffer (the filter persists)
+    with Context(0, 1) as c:
+        c.icao_flush()
+        assert [key(m) for m in c.demod_iq(iq)] == want
+
+
+def test_one_launch_passes_between_long_passes_and_flushes(hip_lib, oracle_mod):
+    """One-launch passes, three-launch passes and icao_flush interleaved in one pipeline over captures
+    that share addresses: every ordering edge between the two forms (an event recorded on the spot where a
+    long pass has to wait for a one-launch pass, the bitmap a flush retires, the unsynchronised-pass
+    rule) against one oracle stream."""
+    import torch
+    from dump1090_rs_amd import Context
+    rng = np.random.default_rng(2024)
+    sizes = [1, 24, 2, 1, 40, 1, 16, 3, 30, 1, 1, 20, 5, 1]
+    caps = []
+    for k, nc in enumerate(sizes):
+        n = nc * CHUNK - int(rng.integers(0, 3000))
+        caps.append(synth.make_iq(n, n_bursts=15 * nc, seed=7000 + k, n_icao=5, df11_every=3))
+    flush_before = {0, 4, 5, 9, 12}
+    orc = oracle_mod.Oracle()
+    want = []
+    for k, iq in enumerate(caps):
+        if k in flush_before:
+            orc.icao_flush()
+        want.append([want_key(w) for w in orc.demod_iq(iq)[0]])
+    devs = [torch.from_numpy(iq).cuda() for iq in caps]
+    torch.cuda.synchronize()
+    with Context(0, 40) as c:
+        for rep in range(6):
+            depth = 1 + rep % 4
+            got, k_out = [], 0
+            for k, d in enumerate(devs):
+                if c.pending() == depth:
+                    got.append([key(m) for m in c.collect()])
+                if k in flush_before:
+                    c.icao_flush()
+                c.submit_iq_device(d.data_ptr(), len(caps[k]))
+            while c.pending():
+                got.append([key(m) for m in c.collect()])
+            assert got == want, (rep, [i for i, (g, w) in enumerate(zip(got, want)) if g != w])
