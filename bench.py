@@ -65,6 +65,9 @@ def parse(argv=None):
                          "GPU raises its clocks over ~50 ms of sustained load (a pass is 0.1 ms), and a stream "
                          "demodulator's throughput is what it sustains, not what the first 25 passes after "
                          "idling make; 0 = none.  Reported under config.clock_ramp with the cold step time.")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="further blocks of --steps steps after the timed one, each timed the same way: the line's "
+                         "ms_per_step_blocks (min / median / max); the headline stays the first block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pin", action="store_true",
                     help="leave the rank's CPU affinity alone (default: the cores of its GPU's NUMA node, from sysfs)")
@@ -189,6 +192,14 @@ class Env:
         from dump1090_rs_amd import sharding
         return sharding.reduce_timing(self.dist, elapsed, frames, device=self.reduce_device)
 
+    def max_each(self, values):
+        """element-wise MAX over ranks of a list of floats (a block takes as long as its slowest rank)"""
+        if self.dist is None or not values:
+            return list(values)
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.reduce_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu().tolist()]
+
     def gather(self, value: float):
         """One float per rank, on every rank (per-rank step times: a straggler must not hide behind the MAX)."""
         if self.dist is None:
@@ -296,6 +307,16 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     frames, tot, stamps = run_steps(warmup, steps, args.timed_profiling)
     env.fence()
     elapsed = time.perf_counter() - t0
+    # The spread: the same K steps again, block after block, each between the same fences.  Not the
+    # headline (that is the block above, as the driver's contract wants it) -- what one 2 ms sample cannot
+    # say about itself.
+    blocks = []
+    for b in range(max(0, args.blocks)):
+        env.fence()
+        tb = time.perf_counter()
+        run_steps(warmup + steps * (b + 1), steps, args.timed_profiling)
+        env.fence()
+        blocks.append((time.perf_counter() - tb) / steps * 1e3)
     gc.enable()
     stats = ctx.stats()
     tot2 = None
@@ -315,7 +336,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     iv = [b - a for a, b in zip(stamps, stamps[1:])]
     return {"ctx": ctx, "bufs": bufs, "n": n, "n_bursts": n_bursts, "cap": cap, "frames": frames, "elapsed": elapsed,
             "tot": tot, "tot2": tot2, "stats": stats, "intervals": iv, "depth": depth, "ramp": ramp,
-            "alone_ms": alone_ms}
+            "alone_ms": alone_ms, "blocks": blocks}
 
 
 def clock_ramp(env: Env, args, run) -> dict:
@@ -420,6 +441,7 @@ def resident_result(env: Env, args, r, workload: str):
     n, steps = r["n"], args.steps
     per_rank_ms = env.gather(r["elapsed"] / steps * 1e3)
     elapsed, frames = env.reduce(r["elapsed"], r["frames"])
+    blocks = env.max_each(r.get("blocks") or [])
     tot, tot2 = r["tot"], r["tot2"] or r["tot"]
     own_ms = tot["ms_scan"] / steps
     # Consecutive pipelined scans overlap (the next one's workgroups fill the CUs as the previous grid
@@ -449,6 +471,11 @@ def resident_result(env: Env, args, r, workload: str):
         "ms_per_step": round(elapsed / steps * 1e3, 4),
         "ms_per_step_median": round(_median(iv) * 1e3, 4) if iv else None,
         "ms_per_step_cold": r["ramp"]["cold_ms_per_step"],
+        "ms_per_step_blocks": None if not blocks else {
+            "is": f"{len(blocks)} further blocks of {steps} steps right after the timed one, each timed like it "
+                  "(fence, K steps, fence; MAX over ranks): the spread a single block cannot show",
+            "min": round(min(blocks), 4), "median": round(_median(blocks), 4), "max": round(max(blocks), 4),
+            "all": [round(x, 4) for x in blocks]},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

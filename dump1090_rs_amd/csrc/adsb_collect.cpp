@@ -192,6 +192,9 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
     }
     if (sl.profiled) {
         float ms = 0;
+        // (a one-launch pass publishes its summary a moment before its launch retires -- it still zeroes
+        // its counters -- and the launch's own stop event is what is read here)
+        if (sl.fused) HIP_TRY(c, hipEventSynchronize(sl.ev[1]));
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
         st.ms_scan += ms;
         // The device time this launch adds: the part of it after the latest scan end seen so far (the
