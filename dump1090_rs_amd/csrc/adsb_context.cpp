@@ -17,7 +17,7 @@ extern "C" {
 // same streams keeps every context of a process on the queues the first one got.
 struct StreamSet {
     int device = -1;
-    hipStream_t own = nullptr, scan[2] = {nullptr, nullptr}, tail = nullptr, score = nullptr, copy = nullptr;
+    hipStream_t own = nullptr, scan[kScanStreams] = {}, tail = nullptr, score = nullptr, copy = nullptr;
 };
 std::mutex g_stream_pool_mu;
 std::vector<StreamSet> g_stream_pool;
@@ -71,8 +71,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         const bool reuse = !tuning_env("ADSB_STREAM_PRIO") && !tuning_env("ADSB_SCORE_PRIO") && take_stream_set(device, pooled);
         if (reuse) {
             c->own_stream = pooled.own;
-            c->scan_stream[0] = pooled.scan[0];
-            c->scan_stream[1] = pooled.scan[1];
+            for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = pooled.scan[k];
             c->tail_stream = pooled.tail;
             c->score_stream = pooled.score;
             c->copy_stream_spare = pooled.copy;
@@ -106,6 +105,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, pt));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, p0));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, p1));
+            for (int k = 2; k < kScanStreams; k++)
+                HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[k], hipStreamNonBlocking, k & 1 ? p1 : p0));
             if (tuning_env("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
         }
         for (auto &e : c->input_ready)
@@ -343,16 +344,21 @@ void adsb_destroy(adsb_ctx *c)
         StreamSet set;
         set.device = c->device;
         set.own = c->own_stream;
-        set.scan[0] = c->scan_stream[0];
-        set.scan[1] = c->scan_stream[1];
+        bool all_scan = true;
+        for (int k = 0; k < kScanStreams; k++) {
+            set.scan[k] = c->scan_stream[k];
+            all_scan = all_scan && set.scan[k];
+        }
         set.tail = c->tail_stream;
         set.score = c->score_stream;
         set.copy = c->copy_stream ? c->copy_stream : c->copy_stream_spare;
-        if (set.own && set.scan[0] && set.scan[1] && set.tail && set.score) {
+        if (set.own && all_scan && set.tail && set.score) {
             std::lock_guard<std::mutex> lk(g_stream_pool_mu);
             g_stream_pool.push_back(set);
         } else {
-            for (hipStream_t q : {set.own, set.scan[0], set.scan[1], set.tail, set.score, set.copy})
+            for (hipStream_t q : {set.own, set.tail, set.score, set.copy})
+                if (q) (void)hipStreamDestroy(q);
+            for (hipStream_t q : set.scan)
                 if (q) (void)hipStreamDestroy(q);
         }
     }

@@ -79,6 +79,9 @@ struct Slot {
     // this pass's match may have missed it and the pass is redone through the three-launch path.
     bool fused = false;
     uint64_t unsynced_from = 0;
+    hipStream_t fused_q = nullptr;  // the stream the slot's latest one-launch pass ran on: its summary reaches the host a
+                                    // moment before the launch retires, so a pass that reuses the slot's lists from
+                                    // another stream orders itself behind that stream first
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int profiled = 0;  // profiling level the pass was enqueued with
@@ -86,6 +89,7 @@ struct Slot {
 
 constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 4: the device never waits for the host between passes (3 do for sparse streams; a dense one has a longer tail)
 constexpr int kBitmaps = kSlots + 1;
+constexpr int kScanStreams = 4;
 constexpr int kScanEvRing = kSlots + 3;  // scan start / stop event pairs in rotation (finish_pass: ms_scan_exclusive)
 
 constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup
@@ -121,7 +125,10 @@ struct adsb_ctx {
     // fill the CUs as the previous scan's persistent grid drains instead of waiting ~13 us
     // behind an in-order queue's end-of-kernel barrier.  `stream` (the caller's) only orders
     // the input: each scan waits for the point `stream` had reached at submit.
-    hipStream_t scan_stream[2] = {nullptr, nullptr};
+    // (four of them: three-launch passes alternate between the first two; one-launch passes of a few
+    // buffers, whose kernels are mostly latency -- a link read, one round of tiles, a one-workgroup tail --
+    // rotate over all four so that three or four of them overlap)
+    hipStream_t scan_stream[kScanStreams] = {};
     hipEvent_t prev_scanned = nullptr;      // the latest submission's scan-end event and the stream it is on
     hipStream_t prev_scan_stream = nullptr;
     bool prev_inline = false;               // ... and whether its match ran there rather than on the tail stream
@@ -129,7 +136,7 @@ struct adsb_ctx {
     hipEvent_t lazy_ev = nullptr;           // recorded on a stream at the moment somebody has to wait for a one-launch pass on it
     uint64_t last_new_insert_seq = 0;       // the latest pass whose replay put a NEW address into the filter
     uint64_t rematches = 0;                 // one-launch passes redone because a pass in flight beside them did
-    hipEvent_t input_ready[2] = {nullptr, nullptr};  // per slot: `stream` at submit (the caller's IQ is complete)
+    hipEvent_t input_ready[kScanStreams] = {};  // per scan stream: `stream` at submit (the caller's IQ is complete)
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;
     // Lists that hold the worst case of one buffer (every position sliced, five trials each), for

@@ -11,13 +11,15 @@
 // 131072-sample buffers exactly as consecutive SDR reads would be (no carry-over between
 // buffers, src/lib.rs:36-44); up to K of them (default 64) travel to the GPU per pass through the
 // pinned ring (adsb_ring_*), so reading, the copy and the scan overlap.  A slot does not wait to
-// fill up: when no input has arrived for T ms (default 100) the whole buffers read so far are
-// submitted as a shorter pass -- a live 2.4 MSPS pipe delivers a buffer every 55 ms and would
-// otherwise sit 3.5 s in a 64-buffer slot -- and the begun buffer moves on to the next slot, so the
-// cuts stay where consecutive reads of 131072 samples put them.  Raw-TCP clients are written
-// without blocking: one whose socket buffer is full (it stopped reading) is dropped, as the
-// reference drops a client whose write fails (main.rs:184-200), and never holds up the others or
-// the demodulation.  A pass with more frames than the output array gets them all
+// fill up: T ms (default 100) after its first whole buffer was complete, the whole buffers read so
+// far are submitted as a shorter pass -- a deadline, not an idle timer: a live 2.4 MSPS pipe delivers
+// data all the time, a buffer every 55 ms, and would otherwise sit 3.5 s in a 64-buffer slot -- and
+// the begun buffer moves on to the next slot, so the cuts stay where consecutive reads of 131072
+// samples put them.  Raw-TCP clients are written without blocking: one whose socket buffer stays
+// full for T ms (it stopped reading) is dropped, as the reference drops a client whose write fails
+// (main.rs:184-200); one that is merely slower than a burst of output is waited for that long, so an
+// offline replay, which produces lines far faster than real time, loses nobody who reads.  New
+// clients are accepted while waiting for input too.  A pass with more frames than the output array gets them all
 // (adsb_fetch_messages).  The ICAO filter is never flushed, as in the reference's loop.
 // No GPU -> exits non-zero.
 #include <arpa/inet.h>
@@ -71,17 +73,26 @@ struct Clients {
             socks.push_back(s);
         }
     }
-    // main.rs:184-199: drop a client when its write fails -- which includes a full socket buffer
-    // (EAGAIN: a partly written line could not be completed later without queueing per client)
-    void send_all(const std::string &lines)
+    // main.rs:184-199: drop a client when its write fails.  A full socket buffer (EAGAIN) is given
+    // `budget_ms` to drain -- the client is reading, only slower than this burst -- and counts as a
+    // failed write after that (a partly written line could not be completed later without queueing
+    // per client).
+    void send_all(const std::string &lines, int budget_ms)
     {
         for (size_t i = 0; i < socks.size();) {
             size_t off = 0;
             bool dead = false;
+            const auto t0 = std::chrono::steady_clock::now();
             while (off < lines.size()) {
                 const ssize_t w = ::send(socks[i], lines.data() + off, lines.size() - off, MSG_NOSIGNAL | MSG_DONTWAIT);
                 if (w <= 0) {
                     if (w < 0 && errno == EINTR) continue;
+                    if (w < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {
+                        const long spent = (long)std::chrono::duration_cast<std::chrono::milliseconds>(
+                                               std::chrono::steady_clock::now() - t0).count();
+                        pollfd p{socks[i], POLLOUT, 0};
+                        if (spent < budget_ms && ::poll(&p, 1, (int)(budget_ms - spent)) > 0 && (p.revents & POLLOUT)) continue;
+                    }
                     dead = true;
                     dropped++;
                     break;
@@ -202,7 +213,7 @@ int main(int argc, char **argv)
             std::fflush(stdout);
         }
         clients.accept_new();
-        if (!lines.empty()) clients.send_all(lines);
+        if (!lines.empty()) clients.send_all(lines, latency_ms);
         return ADSB_OK;
     };
 
@@ -225,16 +236,30 @@ int main(int argc, char **argv)
         size_t fill = begun_bytes;
         if (fill) std::memcpy(dst, begun.data(), fill);
         begun_bytes = 0;
-        // until the slot is full, the input ends, or -- with at least one whole buffer in hand --
-        // nothing has arrived for latency_ms; meanwhile finished passes are handed on
+        // until the slot is full, the input ends, or latency_ms have gone by since the slot's first whole
+        // buffer was complete (a deadline: data that keeps arriving does not put it off); meanwhile
+        // finished passes are handed on and new clients accepted
+        bool have_whole = fill >= buf_bytes;
+        auto t_whole = std::chrono::steady_clock::now();
         while (!eof && fill < cap * 4) {
-            const bool have_whole = fill >= buf_bytes;
+            int wait_ms = -1;   // nothing to hand on and no whole buffer yet: as long as it takes
+            if (have_whole) {
+                const long spent = (long)std::chrono::duration_cast<std::chrono::milliseconds>(
+                                       std::chrono::steady_clock::now() - t_whole).count();
+                if (spent >= latency_ms) break;   // a short pass
+                wait_ms = (int)(latency_ms - spent);
+            } else if (adsb_pending(ctx) > 0 || clients.listener >= 0) {
+                wait_ms = latency_ms;
+            }
             bool idle = false;
-            fill = read_once(in, dst, fill, cap * 4, have_whole || adsb_pending(ctx) > 0 ? latency_ms : -1, &eof, &idle);
-            if (!idle) continue;
-            if (adsb_pending(ctx) > 0)  // idle input: do not sit on results
+            fill = read_once(in, dst, fill, cap * 4, wait_ms, &eof, &idle);
+            if (!have_whole && fill >= buf_bytes) {
+                have_whole = true;
+                t_whole = std::chrono::steady_clock::now();
+            }
+            clients.accept_new();
+            if (idle && adsb_pending(ctx) > 0)  // idle input: do not sit on results
                 if ((st = drain_one()) != ADSB_OK) return die(ctx, "adsb_collect", st);
-            if (have_whole) break;      // idle with whole buffers in hand: a short pass
         }
         size_t bytes = fill;
         if (!eof && fill < cap * 4) {  // short pass: whole buffers only, the begun one waits for its rest

@@ -146,19 +146,29 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // odd slots scan on the second stream, unless something orders consecutive passes (the
     // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
     static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
-    const bool second = fast && !p.carry && advance_carry && !one_scan_stream && (c->submitted & 1u) != 0;
-    hipStream_t ss = c->scan_stream[second ? 1 : 0];
+    static const int fused_streams = tuning_env("ADSB_FUSED_STREAMS") ? std::atoi(tuning_env("ADSB_FUSED_STREAMS")) : kScanStreams;
+    const bool rotate = fast && !p.carry && advance_carry && !one_scan_stream;
+    // (a slot's passes of one kind always land on the same stream: kSlots is a multiple of both periods)
+    const int si = !rotate ? 0 : (int)(c->submitted % (uint64_t)(fused ? std::max(1, std::min(fused_streams, kScanStreams)) : 2));
+    hipStream_t ss = c->scan_stream[si];
     // the input is complete at `input_done` (the ring's copy), already (input_ready_now: pinned memory the
     // host has filled), or where `stream` stands now
     if (input_done != input_ready_now()) {
         HT(c, HT_IN_READY);
         hipEvent_t ready = input_done;
         if (!ready) {
-            ready = c->input_ready[second ? 1 : 0];
+            ready = c->input_ready[si];
             HIP_TRY(c, hipEventRecord(ready, c->stream));
         }
         HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     }
+    // (0) the slot's lists and counters: a one-launch pass that used them last on another stream may still
+    //     be zeroing them (the host goes by its summary, which it writes just before)
+    if (sl.fused_q && sl.fused_q != ss) {
+        HIP_TRY(c, hipEventRecord(c->lazy_ev, sl.fused_q));
+        HIP_TRY(c, hipStreamWaitEvent(ss, c->lazy_ev, 0));
+    }
+    sl.fused_q = fused ? ss : nullptr;
     if (n_chunks <= kInlineTailChunks) inline_tail = true;
     // ---- cross-stream edges (DESIGN.md section 5b is the table of them) -------------------------------
     // (1) A bitmap an icao_flush retired is cleared by this pass (its records kernel, or every workgroup

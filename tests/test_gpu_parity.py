@@ -1076,6 +1076,72 @@ def test_feed_tool_trickling_input_is_not_held_back_for_a_full_slot(hip_lib, ora
             feed.kill()
 
 
+def test_feed_tool_steady_input_is_cut_into_short_passes_by_a_deadline(hip_lib, oracle_mod):
+    """A live pipe is never idle: a writer that delivers an eighth of a buffer every 12 ms (faster than
+    a 2.4 MSPS receiver, same shape) for ten buffers.  With 64-buffer slots nothing would come out before
+    the input ends unless the slot is cut by a deadline -- --latency-ms after its first whole buffer was
+    complete -- rather than by an idle timer (the advisor's round-3 finding): the first buffer's frames
+    must be out while the writer is still writing, a client that connects meanwhile is accepted while the
+    feed waits for input, and the whole stream equals the oracle's."""
+    import os
+    import select
+    import threading
+    import time
+    n_buf = 10
+    n = n_buf * 131072
+    iq = synth.make_iq(n, n_bursts=300, seed=4242, n_icao=9, df11_every=4)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    lines = [f"*{w['buffer'].hex()};" for w in want]
+    first = [f"*{w['buffer'].hex()};" for w in want if w["chunk"] == 0]
+    assert len(first) >= 10
+    raw = np.ascontiguousarray(iq[:, ::-1]).tobytes()
+    feed, connect = _start_feed(["--buffers", "64", "--latency-ms", "100"])
+    done_at = {}
+
+    def writer():
+        piece = 131072 * 4 // 8
+        for off in range(0, len(raw), piece):
+            feed.stdin.write(raw[off:off + piece])
+            feed.stdin.flush()
+            time.sleep(0.012)
+        done_at["t"] = time.time()
+        time.sleep(0.5)        # (the client below connects and is accepted before the input ends)
+        feed.stdin.close()
+    try:
+        th = threading.Thread(target=writer)
+        th.start()
+        got, first_seen = b"", None
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            if select.select([feed.stdout], [], [], 0.05)[0]:
+                part = os.read(feed.stdout.fileno(), 1 << 16)
+                if not part:
+                    break
+                got += part
+                if first_seen is None and got.count(b"\n") >= len(first):
+                    first_seen = time.time()
+                    late = connect()          # accepted while the feed is busy reading
+        th.join(timeout=30)
+        err = feed.stderr.read().decode()
+        assert feed.wait(timeout=120) == 0, err
+        assert got.decode().splitlines() == lines
+        assert first_seen is not None and first_seen < done_at["t"] - 0.3, "no output until the input was nearly over"
+        assert f"{n} samples, {len(lines)} frames in " in err and " 0 short passes" not in err
+        late.settimeout(5)
+        tail = b""
+        while True:
+            part = late.recv(1 << 16)
+            if not part:
+                break
+            tail += part
+        late.close()
+        # the late client got the frames of the passes that were finished after it connected: a suffix
+        assert tail and ("\n".join(lines) + "\n").endswith(tail.decode())
+    finally:
+        if feed.poll() is None:
+            feed.kill()
+
+
 def test_feed_tool_drops_a_client_that_stops_reading_and_keeps_every_frame(hip_lib, oracle_mod):
     """One raw-TCP client never reads: once its socket buffer is full it is dropped (the reference drops
     a client whose write fails, main.rs:184-200) and neither the demodulation nor the other client waits

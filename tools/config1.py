@@ -30,6 +30,22 @@ assert len(ref_api()) == len(fused_host()) == len(fused_dev()) == 5
 print(f"to_mag + demodulate2400 (host buffers, the reference's API shape): {timeit(ref_api):8.1f} us")
 print(f"adsb_demod_iq (host IQ in, fused):                                {timeit(fused_host):8.1f} us")
 print(f"adsb_demod_iq_device (IQ resident):                               {timeit(fused_dev):8.1f} us")
+# the ABI calls alone (no Python list of messages built per call)
+from dump1090_rs_amd._lib import AdsbMsg
+import ctypes as C
+out = (AdsbMsg * 4096)(); nn = C.c_size_t(); L = ctx._L; h = ctx._h
+def raw_host():
+    L.adsb_icao_flush(h); L.adsb_demod_iq(h, iq.ctypes.data, len(iq), out, 4096, C.byref(nn))
+def raw_dev():
+    L.adsb_icao_flush(h); L.adsb_demod_iq_device(h, C.c_void_p(dev.data_ptr()), len(iq), out, 4096, C.byref(nn))
+def raw_dev_noflush():
+    L.adsb_demod_iq_device(h, C.c_void_p(dev.data_ptr()), len(iq), out, 4096, C.byref(nn))
+print(f"  raw ABI: icao_flush + adsb_demod_iq (host IQ):                  {timeit(raw_host):8.1f} us")
+print(f"  raw ABI: icao_flush + adsb_demod_iq_device:                     {timeit(raw_dev):8.1f} us")
+print(f"  raw ABI: adsb_demod_iq_device, no flush:                        {timeit(raw_dev_noflush):8.1f} us")
+ctx.set_profiling(0)
+print(f"  ... the same three with HIP-event timing off (adsb_set_profiling 0): {timeit(raw_host):6.1f} / {timeit(raw_dev):6.1f} / {timeit(raw_dev_noflush):6.1f} us")
+ctx.set_profiling(1)
 m = ctx.to_mag(iq)
 print(f"  adsb_to_mag alone:                                              {timeit(lambda: ctx.to_mag(iq)):8.1f} us")
 print(f"  adsb_demodulate2400 alone:                                      {timeit(lambda: (ctx.icao_flush(), ctx.demodulate2400(m))):8.1f} us")

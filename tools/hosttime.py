@@ -1,6 +1,7 @@
 """Host-side cost of a pass, call by call.
 
     python tools/hosttime.py ring [--chunks 1] [--passes 20000] [--depth 3]   # one ring slot per pass
+    python tools/hosttime.py resident [--chunks 1] [--depth 3]                # the same over device-resident IQ
     python tools/hosttime.py flush                                            # flush / stats / profiling levels
 
 `ring` drives the streaming ring the way bench.py's config-3 leg does (acquire, submit, collect with
@@ -69,6 +70,43 @@ def ring(args):
     ctx.close()   # (a tuning build with ADSB_HOST_TIMES=1 prints its table here)
 
 
+def resident(args):
+    """the same loop over device-resident IQ (adsb_submit_iq_device / adsb_collect): what a pass costs
+    without the link"""
+    n = args.chunks * CHUNK
+    ctx = Context(0, args.chunks)
+    cap = 1 << 16
+    out = (AdsbMsg * cap)()
+    bufs = [synth.make_iq_torch(n, n_bursts=max(1, 64 * args.chunks // 512), seed=synth.SEED_DEFAULT + k, device="cuda")
+            for k in range(4)]
+    torch.cuda.synchronize()
+    ctx.icao_flush()
+    for b in bufs:
+        ctx.demod_iq_device_raw(b.data_ptr(), n, out, cap)
+    ctx.set_profiling(args.profiling)
+    for flush_each in (False, True):
+        inflight = frames = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.passes):
+            if flush_each:
+                ctx.icao_flush()
+            ctx.submit_iq_device(bufs[i % 4].data_ptr(), n)
+            inflight += 1
+            if inflight >= args.depth:
+                frames += ctx.collect_raw(out, cap)
+                inflight -= 1
+        while inflight:
+            frames += ctx.collect_raw(out, cap)
+            inflight -= 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"resident, {args.chunks} buffer(s) per pass, {args.depth} in flight, profiling {args.profiling}, "
+              f"{'icao_flush before every pass' if flush_each else 'no flush'}: {dt * 1e6 / args.passes:.2f} us per pass = "
+              f"{n * args.passes / dt / 1e6:.0f} Msamples/s, {frames} frames", flush=True)
+    ctx.close()
+
+
 def flush(_args):
     n = 512 * CHUNK
     bufs = [synth.make_iq_torch(n, n_bursts=64, seed=synth.SEED_DEFAULT + b, device='cuda') for b in range(3)]
@@ -101,10 +139,10 @@ def flush(_args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ring", "flush"])
+    ap.add_argument("mode", choices=["ring", "resident", "flush"])
     ap.add_argument("--chunks", type=int, default=1)
     ap.add_argument("--passes", type=int, default=20000)
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--profiling", type=int, default=1)
     a = ap.parse_args()
-    (ring if a.mode == "ring" else flush)(a)
+    {"ring": ring, "resident": resident, "flush": flush}[a.mode](a)
