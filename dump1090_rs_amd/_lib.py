@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
     L.adsb_submit_iq_device.argtypes = [vp, vp, sz]
     L.adsb_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_pending.argtypes = [vp]
+    L.adsb_max_in_flight.argtypes = [vp]
+    L.adsb_max_in_flight.restype = C.c_int
     L.adsb_fetch_messages.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_ring_create.argtypes = [vp, sz]
     L.adsb_ring_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]

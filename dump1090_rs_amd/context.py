@@ -269,11 +269,23 @@ class Context:
         buf = (C.c_int16 * (2 * cap.value)).from_address(ptr.value)
         return np.ctypeslib.as_array(buf).reshape(-1, 2)
 
+    def ring_acquire_raw(self) -> int:
+        """adsb_ring_acquire without wrapping the buffer in an array (a host loop whose slots are already
+        filled): the buffer's address."""
+        if not hasattr(self, "_ring_ptr"):
+            self._ring_ptr, self._ring_cap = C.c_void_p(), C.c_size_t()
+        self._check(self._L.adsb_ring_acquire(self._h, C.byref(self._ring_ptr), C.byref(self._ring_cap)), "adsb_ring_acquire")
+        return self._ring_ptr.value
+
     def ring_submit(self, n_samples: int) -> None:
         self._check(self._L.adsb_ring_submit(self._h, n_samples), "adsb_ring_submit")
 
     def pending(self) -> int:
         return int(self._L.adsb_pending(self._h))
+
+    def max_in_flight(self) -> int:
+        """4, or 8 for a context created for at most 16 buffers per pass (adsb_max_in_flight)."""
+        return int(self._L.adsb_max_in_flight(self._h))
 
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._L.adsb_set_stream(self._h, C.c_void_p(hip_stream)), "adsb_set_stream")

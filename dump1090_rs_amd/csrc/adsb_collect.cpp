@@ -200,11 +200,11 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         // The device time this launch adds: the part of it after the latest scan end seen so far (the
         // "frontier": normally the previous pass's; scans on the two scan streams can also finish out of
         // order, and one that ended before the frontier adds nothing -- the union of the launches'
-        // intervals is what is being summed).  The frontier's events are intact for kScanEvRing - kSlots
+        // intervals is what is being summed).  The frontier's events are intact for kScanEvRing - n_slots
         // passes back: the ring is that much longer than what can be in flight.
         float excl = ms;
         bool advance = true;
-        if (c->last_stop && sl.scan_seq - c->last_scan_seq <= (uint64_t)(kScanEvRing - kSlots)) {
+        if (c->last_stop && sl.scan_seq - c->last_scan_seq <= (uint64_t)(kScanEvRing - c->n_slots)) {
             float since = 0;
             if (hipEventElapsedTime(&since, c->last_stop, sl.ev[1]) == hipSuccess) {
                 if (since <= 0) {
@@ -270,7 +270,7 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
 // later passes are a harmless superset in time.
 int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
 {
-    Slot &sl = c->slot[c->collected % kSlots];
+    Slot &sl = c->slot[c->collected % (uint64_t)c->n_slots];
     adsb_stats st{};
     st.n_samples = sl.n_samples;
     st.n_chunks = sl.n_chunks;
@@ -343,7 +343,7 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
 int park_pending(adsb_ctx *c)
 {
     while (c->collected < c->submitted) {
-        Slot &sl = c->slot[c->collected % kSlots];
+        Slot &sl = c->slot[c->collected % (uint64_t)c->n_slots];
         sl.parked_msgs.clear();
         sl.park_rc = collect_oldest(c, sl.parked_msgs);
         sl.parked_stats = c->stats;
@@ -356,7 +356,7 @@ int park_pending(adsb_ctx *c)
 int collect_next(adsb_ctx *c, std::vector<adsb_msg> &out)
 {
     if (c->delivered < c->collected) {
-        Slot &sl = c->slot[c->delivered % kSlots];
+        Slot &sl = c->slot[c->delivered % (uint64_t)c->n_slots];
         out.swap(sl.parked_msgs);
         sl.parked_msgs.clear();
         c->stats = sl.parked_stats;

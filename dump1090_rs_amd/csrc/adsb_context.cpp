@@ -48,6 +48,9 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     if (!c) return ADSB_ERR_NOMEM;
     c->device = device;
     c->max_chunks = max_chunks;
+    // (a context for passes of a few buffers: one launch each, eight in flight -- adsb_ctx.h)
+    c->n_slots = max_chunks <= kInlineTailChunks ? ADSB_MAX_IN_FLIGHT_SMALL : ADSB_MAX_IN_FLIGHT;
+    c->n_bitmaps = c->n_slots + 1;
     if (const char *ds = tuning_env("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     if (const char *st = tuning_env("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
     // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
@@ -112,8 +115,9 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
         HIP_TRY(c, hipEventCreateWithFlags(&c->lazy_ev, hipEventDisableTiming | hipEventDisableSystemFence));
-        for (auto &b : c->d_bitmap) HIP_TRY(c, hipMalloc((void **)&b, kBitmapAllocWords * sizeof(uint32_t)));
-        for (Slot &sl : c->slot) {
+        for (int k = 0; k < c->n_bitmaps; k++) HIP_TRY(c, hipMalloc((void **)&c->d_bitmap[k], kBitmapAllocWords * sizeof(uint32_t)));
+        for (int si = 0; si < c->n_slots; si++) {
+            Slot &sl = c->slot[si];
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
             sl.hits_cap = c->hits_cap;
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
@@ -149,7 +153,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                 if (const char *e = tuning_env("ADSB_SCORE_PRIO")) ps = std::atoi(e) == 2 ? greatest : (std::atoi(e) == 1 ? (least + greatest) / 2 : least);
                 HIP_TRY(c, hipStreamCreateWithPriority(&c->score_stream, hipStreamNonBlocking, ps));
             }
-            for (Slot &sl : c->slot) {
+            for (int si = 0; si < c->n_slots; si++) {
+                Slot &sl = c->slot[si];
                 ScoreDev &sd = sl.score;
                 sd = cd;
                 HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
@@ -165,7 +170,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                 HIP_TRY(c, hipEventCreateWithFlags(&sl.recorded, hipEventDisableTiming | hipEventDisableSystemFence));
             }
             const ScoreDev &sd = cd;
-            for (Slot &sl : c->slot) {
+            for (int si = 0; si < c->n_slots; si++) {
+                Slot &sl = c->slot[si];
                 HIP_TRY(c, hipHostMalloc((void **)&sl.h_msgs, (size_t)sd.cap * sizeof(adsb_msg), hipHostMallocMapped | hipHostMallocCoherent));
                 HIP_TRY(c, hipHostMalloc((void **)&sl.h_adds, (size_t)sd.cap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
                 HIP_TRY(c, hipHostMalloc((void **)&sl.h_ssum, sizeof(ScoreSummary), hipHostMallocMapped | hipHostMallocCoherent));
@@ -186,7 +192,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(uint32_t),
                                  hipMemcpyHostToDevice));
         }
-        for (Slot &sl : c->slot) {
+        for (int si = 0; si < c->n_slots; si++) {
+            Slot &sl = c->slot[si];
             // (mapped + coherent: the records kernel's write-through stores are visible to the host
             // when its completion event fires, whatever the runtime's default for pinned memory)
             HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocMapped | hipHostMallocCoherent));
@@ -208,8 +215,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         // both bitmaps clean and both counter blocks zero to start with; from then on each
         // pass cleans up for the next (the first pass needs no flush of its own)
-        for (int k = 0; k < kBitmaps; k++)
-            if (int e = launch_reset(c->slot[k % kSlots].d_ctr, c->d_bitmap[k], c->stream))
+        for (int k = 0; k < c->n_bitmaps; k++)
+            if (int e = launch_reset(c->slot[k % (uint64_t)c->n_slots].d_ctr, c->d_bitmap[k], c->stream))
                 return fail(c, (hipError_t)e, "launch_reset");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->flush_pending = false;
@@ -388,7 +395,8 @@ int adsb_set_carry_over(adsb_ctx *c, int enabled)
     HIP_TRY(c, hipSetDevice(c->device));
     c->carry_over = enabled != 0;
     // the stream starts here: nothing precedes the next call
-    for (Slot &sl : c->slot) HIP_TRY(c, hipMemsetAsync(sl.d_carry, 0, kCarrySamples * sizeof(uint32_t), c->stream));
+    for (int si = 0; si < c->n_slots; si++)
+        HIP_TRY(c, hipMemsetAsync(c->slot[si].d_carry, 0, kCarrySamples * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ADSB_OK;
@@ -445,6 +453,7 @@ int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
 uint64_t adsb_host_sorts(const adsb_ctx *c) { return c ? c->host_sorts : 0; }
 uint64_t adsb_host_replays(const adsb_ctx *c) { return c ? c->host_replays : 0; }
 uint64_t adsb_host_rematches(const adsb_ctx *c) { return c ? c->rematches : 0; }
+int adsb_max_in_flight(const adsb_ctx *c) { return c ? c->n_slots : 0; }
 
 int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 {

@@ -87,7 +87,12 @@ struct Slot {
     int profiled = 0;  // profiling level the pass was enqueued with
 };
 
-constexpr int kSlots = ADSB_MAX_IN_FLIGHT;  // 4: the device never waits for the host between passes (3 do for sparse streams; a dense one has a longer tail)
+// Passes in flight: 4 and the device never waits for the host between large passes (3 do for sparse
+// streams; a dense one has a longer tail).  A context created for passes of a few buffers gets 8: its
+// passes are one launch each and mostly latency (a link read, one round of tiles, a one-workgroup tail),
+// four run side by side on the four scan streams and four more are queued behind them, so that a launch
+// never waits for the host (adsb_ctx::n_slots).
+constexpr int kSlots = ADSB_MAX_IN_FLIGHT_SMALL;  // what the arrays hold
 constexpr int kBitmaps = kSlots + 1;
 constexpr int kScanStreams = 4;
 constexpr int kScanEvRing = kSlots + 3;  // scan start / stop event pairs in rotation (finish_pass: ms_scan_exclusive)
@@ -149,6 +154,8 @@ struct adsb_ctx {
     } fb;
 
     Slot slot[kSlots];
+    int n_slots = ADSB_MAX_IN_FLIGHT;  // slots in use (ADSB_MAX_IN_FLIGHT, or _SMALL for contexts of a few buffers)
+    int n_bitmaps = ADSB_MAX_IN_FLIGHT + 1;
     // start / stop events of the scans, in a ring one longer than the passes in flight: when pass N
     // is collected the stop event of pass N-1 is still its own (ms_scan_exclusive)
     hipEvent_t scan_ev[kScanEvRing][2] = {};

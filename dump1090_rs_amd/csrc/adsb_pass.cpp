@@ -69,7 +69,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.clean_bitmap = nullptr;
     if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the next clean one
         p.clean_bitmap = c->d_bitmap[c->cur_bitmap];
-        c->cur_bitmap = (c->cur_bitmap + 1) % kBitmaps;
+        c->cur_bitmap = (c->cur_bitmap + 1) % c->n_bitmaps;
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;
@@ -148,7 +148,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
     static const int fused_streams = tuning_env("ADSB_FUSED_STREAMS") ? std::atoi(tuning_env("ADSB_FUSED_STREAMS")) : kScanStreams;
     const bool rotate = fast && !p.carry && advance_carry && !one_scan_stream;
-    // (a slot's passes of one kind always land on the same stream: kSlots is a multiple of both periods)
+    // (a slot's passes of one kind always land on the same stream: the slot count is a multiple of both periods)
     const int si = !rotate ? 0 : (int)(c->submitted % (uint64_t)(fused ? std::max(1, std::min(fused_streams, kScanStreams)) : 2));
     hipStream_t ss = c->scan_stream[si];
     // the input is complete at `input_done` (the ring's copy), already (input_ready_now: pinned memory the
@@ -357,7 +357,7 @@ int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bo
 {
     const uint64_t n_chunks = from_mag ? 1 : (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks == 0 || n_chunks > kMaxChunks || n_chunks > c->max_chunks) return ADSB_ERR_INVALID;
-    Slot &sl = c->slot[c->submitted % kSlots];
+    Slot &sl = c->slot[c->submitted % (uint64_t)c->n_slots];
     if (sl.busy || sl.parked || c->shard_active) return ADSB_ERR_BUSY;
 #ifdef ADSB_TUNING
     const auto te0 = std::chrono::steady_clock::now();

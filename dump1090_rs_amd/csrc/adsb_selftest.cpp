@@ -136,7 +136,7 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
     static_assert(sizeof(Counters) >= 16, "digest result fits the counters block");
     // the counters block the next pass will use doubles as the 16-byte result area; it is
     // zeroed again afterwards
-    Counters *scratch = c->slot[c->submitted % kSlots].d_ctr;
+    Counters *scratch = c->slot[c->submitted % (uint64_t)c->n_slots].d_ctr;
     HIP_TRY(c, hipMemsetAsync(scratch, 0, sizeof(Counters), c->stream));
     if (int e = launch_mag_digest(first_bits, count, (unsigned long long *)scratch, c->stream))
         return fail(c, (hipError_t)e, "launch_mag_digest");

@@ -90,7 +90,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     uint32_t *retired = nullptr;
     if (c->flush_pending) {
         retired = c->d_bitmap[c->cur_bitmap];
-        c->cur_bitmap = (c->cur_bitmap + 1) % kBitmaps;
+        c->cur_bitmap = (c->cur_bitmap + 1) % c->n_bitmaps;
         c->filter.flush();
         c->flush_pending = false;
         // the device-side copy of the filter (exact bitmap, k_score) still holds the addresses from

@@ -61,6 +61,9 @@ typedef enum {
 } adsb_status;
 
 #define ADSB_MAX_IN_FLIGHT 4
+/* ... and for a context created with max_chunks <= 16, whose passes are a single launch each
+ * (adsb_max_in_flight tells which a context got) */
+#define ADSB_MAX_IN_FLIGHT_SMALL 8
 
 typedef struct adsb_ctx adsb_ctx;
 
@@ -153,8 +156,8 @@ int adsb_demod_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_sa
                          adsb_msg *out, size_t cap, size_t *n_out);
 
 /* Asynchronous form of adsb_demod_iq_device for a host that keeps the GPU fed: enqueue one
- * pass (kernels + result copy) and return at once; at most ADSB_MAX_IN_FLIGHT passes may
- * be pending.  adsb_collect waits for the OLDEST pending pass, replays it through the
+ * pass (kernels + result copy) and return at once; at most ADSB_MAX_IN_FLIGHT passes
+ * (adsb_max_in_flight) may be pending.  adsb_collect waits for the OLDEST pending pass, replays it through the
  * filter and returns its messages, so results come back in submission order and the
  * host replay of pass i overlaps the device scan of pass i+1.  adsb_icao_flush applies
  * to the passes submitted after it.  The synchronous calls return ADSB_ERR_BUSY while
@@ -165,6 +168,9 @@ int adsb_demod_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_sa
 int adsb_submit_iq_device(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples);
 int adsb_collect(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 int adsb_pending(const adsb_ctx *ctx);
+/* How many passes this context lets be in flight: ADSB_MAX_IN_FLIGHT, or ADSB_MAX_IN_FLIGHT_SMALL for a
+ * context created for at most 16 buffers per pass (the ring of such a context has that many slots). */
+int adsb_max_in_flight(const adsb_ctx *ctx);
 
 /* The complete message list of the most recent call that returned ADSB_ERR_CAPACITY
  * (adsb_demodulate2400, adsb_demod_iq[_device], adsb_collect): that call already ran the pass and
@@ -173,7 +179,7 @@ int adsb_pending(const adsb_ctx *ctx);
 int adsb_fetch_messages(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out);
 
 /* Streaming ring for a host that produces IQ (an SDR read loop, dump1090_rs/src/main.rs:
- * 154-167): ADSB_MAX_IN_FLIGHT (4) pinned host buffers of `samples_per_slot` samples (4 bytes
+ * 154-167): adsb_max_in_flight() (4 or 8) pinned host buffers of `samples_per_slot` samples (4 bytes
  * each) with a device staging buffer each.  Fill the buffer adsb_ring_acquire hands out (e.g.
  * read the SDR straight into it), adsb_ring_submit(n) starts its host-to-device copy on a copy
  * stream and the pass behind it, adsb_collect returns the oldest pass's messages.  While one

@@ -79,6 +79,7 @@ unsafe extern "C" {
     pub fn adsb_submit_iq_device(ctx: *mut AdsbCtx, device_iq: *const c_void, n_samples: usize) -> c_int;
     pub fn adsb_collect(ctx: *mut AdsbCtx, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_pending(ctx: *const AdsbCtx) -> c_int;
+    pub fn adsb_max_in_flight(ctx: *const AdsbCtx) -> c_int;
     pub fn adsb_fetch_messages(ctx: *mut AdsbCtx, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_ring_create(ctx: *mut AdsbCtx, samples_per_slot: usize) -> c_int;
     pub fn adsb_ring_acquire(ctx: *mut AdsbCtx, host_iq_re_im: *mut *mut i16, capacity_samples: *mut usize) -> c_int;

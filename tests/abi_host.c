@@ -40,7 +40,7 @@ _Static_assert(offsetof(adsb_stats, n_messages) == 40 && offsetof(adsb_stats, ms
                offsetof(adsb_stats, retries) == 64 && offsetof(adsb_stats, ms_scan_exclusive) == 68, "adsb_stats field offsets");
 _Static_assert(ADSB_OK == 0 && ADSB_ERR_INVALID == -1 && ADSB_ERR_NO_DEVICE == -2 && ADSB_ERR_HIP == -3 && ADSB_ERR_TOO_LONG == -4 &&
                ADSB_ERR_CAPACITY == -5 && ADSB_ERR_NOMEM == -6 && ADSB_ERR_BUSY == -7, "status codes");
-_Static_assert(ADSB_MAG_DATA_LEN == 131398 && ADSB_MAX_IN_FLIGHT == 4, "buffer geometry");
+_Static_assert(ADSB_MAG_DATA_LEN == 131398 && ADSB_MAX_IN_FLIGHT == 4 && ADSB_MAX_IN_FLIGHT_SMALL == 8, "buffer geometry");
 
 int main(int argc, char **argv)
 {

@@ -1480,19 +1480,18 @@ def test_abi_misuse_is_refused_not_crashed(hip_lib):
     assert L.adsb_ring_create(h, 131072) == 0
     assert L.adsb_ring_create(h, 131072) == INVALID                                                   # once only
     assert L.adsb_ring_submit(h, 131073) == INVALID
-    # four in flight (ADSB_MAX_IN_FLIGHT), the fifth is refused; blocking calls are refused while passes are pending
-    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
-    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
-    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
-    assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
+    # adsb_max_in_flight passes in flight (8: this context was created for two buffers per pass; 4 for a large
+    # one), one more is refused; blocking calls are refused while passes are pending
+    depth = L.adsb_max_in_flight(h)
+    assert depth == 8
+    for _ in range(depth):
+        assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == 0
     assert L.adsb_submit_iq_device(h, C.c_void_p(ptr), 131072) == BUSY
     assert L.adsb_demod_iq_device(h, C.c_void_p(ptr), 1000, out, 16, C.byref(n)) == BUSY
     assert L.adsb_set_carry_over(h, 1) == BUSY
-    assert L.adsb_pending(h) == 4
-    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and n.value == 0
-    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 2
-    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 1
-    assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and L.adsb_pending(h) == 0
+    assert L.adsb_pending(h) == depth
+    for left in range(depth - 1, -1, -1):
+        assert L.adsb_collect(h, out, 16, C.byref(n)) == 0 and n.value == 0 and L.adsb_pending(h) == left
     # too small an output array: the count comes back, the first `cap` entries are written
     iq = synth.make_iq(131072, n_bursts=20, seed=3)
     t = torch.from_numpy(iq).cuda()

@@ -56,7 +56,7 @@ def ring_stream(c, iq, per_slot, depth):
     return got
 
 
-@pytest.mark.parametrize("depth", [1, 3, 4])
+@pytest.mark.parametrize("depth", [1, 3, 4, 8])
 def test_ring_of_512kb_slots_equals_one_oracle_stream(hip_lib, oracle_mod, depth):
     """BASELINE config 3 as written: 96 slots of ONE 131072-sample buffer each (the last one ragged),
     `depth` passes in flight, against one oracle stream over the same bytes.  The stream keeps teaching

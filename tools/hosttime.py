@@ -33,7 +33,8 @@ def ring(args):
     cap = 1 << 16
     out = (AdsbMsg * cap)()
     ctx.icao_flush()
-    for k in range(4):
+    args.depth = min(args.depth, ctx.max_in_flight())
+    for k in range(ctx.max_in_flight()):
         buf = ctx.ring_acquire()
         buf[:] = synth.make_iq(n, n_bursts=max(1, 64 * args.chunks // 512), seed=synth.SEED_DEFAULT + k)
         ctx.ring_submit(n)
@@ -45,7 +46,7 @@ def ring(args):
     t0 = time.perf_counter()
     for i in range(args.passes):
         a = time.perf_counter()
-        ctx.ring_acquire()
+        ctx.ring_acquire_raw()
         b = time.perf_counter()
         ctx.ring_submit(n)
         c = time.perf_counter()

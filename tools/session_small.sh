@@ -10,23 +10,22 @@ fi
 cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
 python tools/config1.py > gpurun_out/${T}_config1.log 2>&1
 H=gpurun_out/${T}_hosttime_rel.log
-for prof in 1 0; do for depth in 3 4; do
+for prof in 1 0; do for depth in 4 6 8; do
   python tools/hosttime.py ring --chunks 1 --depth $depth --profiling $prof >> $H 2>&1
 done; done
 python tools/hosttime.py ring --chunks 1 --depth 1 --profiling 0 >> $H 2>&1
-python tools/hosttime.py ring --chunks 2 --depth 4 --profiling 0 --passes 10000 >> $H 2>&1
-python tools/hosttime.py ring --chunks 4 --depth 4 --profiling 0 --passes 8000 >> $H 2>&1
-python tools/hosttime.py ring --chunks 16 --depth 4 --profiling 0 --passes 3000 >> $H 2>&1
-python tools/hosttime.py resident --chunks 1 --depth 4 --profiling 0 >> $H 2>&1
+python tools/hosttime.py ring --chunks 2 --depth 8 --profiling 0 --passes 10000 >> $H 2>&1
+python tools/hosttime.py ring --chunks 4 --depth 8 --profiling 0 --passes 8000 >> $H 2>&1
+python tools/hosttime.py ring --chunks 8 --depth 8 --profiling 0 --passes 5000 >> $H 2>&1
+python tools/hosttime.py ring --chunks 16 --depth 8 --profiling 0 --passes 3000 >> $H 2>&1
+python tools/hosttime.py resident --chunks 1 --depth 8 --profiling 0 >> $H 2>&1
 python tools/hosttime.py resident --chunks 1 --depth 1 --profiling 0 >> $H 2>&1
 cp variants/lib_tune.so dump1090_rs_amd/libadsb_hip.so
 H=gpurun_out/${T}_hosttime.log
-ADSB_HOST_TIMES=1 python tools/hosttime.py ring --chunks 1 --depth 4 --profiling 0 >> $H 2>&1
-for k in 1 2 3; do
-  ADSB_FUSED_STREAMS=$k python tools/hosttime.py ring --chunks 1 --depth 4 --profiling 0 2>&1 | sed "s/^/fused streams $k: /" >> $H
-done
-for ch in 1 4 16; do
-  ADSB_RING_COPY=1 python tools/hosttime.py ring --chunks $ch --depth 4 --profiling 0 --passes 6000 2>&1 | sed "s/^/copy, then one launch: /" >> $H
+ADSB_HOST_TIMES=1 python tools/hosttime.py ring --chunks 1 --depth 8 --profiling 0 >> $H 2>&1
+ADSB_HOST_TIMES=1 python tools/hosttime.py resident --chunks 1 --depth 8 --profiling 0 >> $H 2>&1
+for ch in 8 16; do
+  ADSB_RING_COPY=1 python tools/hosttime.py ring --chunks $ch --depth 8 --profiling 0 --passes 4000 2>&1 | sed "s/^/copy, then one launch: /" >> $H
 done
 cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so
 grep -v amdgpu.ids gpurun_out/${T}_hosttime_rel.log gpurun_out/${T}_hosttime.log gpurun_out/${T}_config1.log
