@@ -138,7 +138,11 @@ class Context:
         return out
 
     def _collect(self, call, what: str, cap: int) -> List[ModeSMessage]:
-        buf = (AdsbMsg * cap)()
+        # (the output array is kept between calls: allocating and zeroing 4096 entries costs more than
+        # a one-buffer pass takes)
+        if getattr(self, "_out_cap", 0) != cap:
+            self._out_buf, self._out_cap = (AdsbMsg * cap)(), cap
+        buf = self._out_buf
         n = C.c_size_t()
         st = call(buf, cap, C.byref(n))
         if st == _lib.ADSB_ERR_CAPACITY:

@@ -190,11 +190,13 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         HT(c, HT_VERIFY);
         if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
     }
-    if (sl.profiled) {
+    if (sl.profiled && sl.fused) {
+        // a one-launch pass timed itself (device wall clock, 100 MHz): no events, nothing to wait for
+        const float ms = (float)sl.h_sum->ticks * 1e-5f;
+        st.ms_scan += ms;
+        st.ms_scan_exclusive += ms;
+    } else if (sl.profiled) {
         float ms = 0;
-        // (a one-launch pass publishes its summary a moment before its launch retires -- it still zeroes
-        // its counters -- and the launch's own stop event is what is read here)
-        if (sl.fused) HIP_TRY(c, hipEventSynchronize(sl.ev[1]));
         HIP_TRY(c, hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
         st.ms_scan += ms;
         // The device time this launch adds: the part of it after the latest scan end seen so far (the

@@ -309,7 +309,22 @@ void adsb_destroy(adsb_ctx *c)
     if (c->d_addrs) (void)hipFree(c->d_addrs);
     if (c->d_carry_next) (void)hipFree(c->d_carry_next);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    if (c->d_timeline && c->debug_stop == 100) {
+    if (c->d_timeline && tuning_env("ADSB_TIMELINE") && std::atoi(tuning_env("ADSB_TIMELINE")) == 3) {
+        // profiling aid: the stamps of the last one-launch pass (100 MHz wall clock)
+        unsigned long long t[10] = {};
+        if (hipMemcpy(t, c->d_timeline + 448, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[0]) {
+            if (t[8] > t[4] && t[7] > t[8])
+                std::fprintf(stderr, "  one-launch pass, second look: fill counts in LDS +%.2f us, entries compared +%.2f us, fence +%.2f us\n",
+                             (double)(long long)(t[8] - t[4]) / 100.0, (double)(long long)(t[7] - t[8]) / 100.0,
+                             (double)(long long)(t[5] - t[7]) / 100.0);
+            static const char *name[7] = {"entry", "tables in LDS, first tile requested", "tiles done", "own entries matched",
+                                          "counted in (last workgroup from here on)", "second look done", "records + summary + counters"};
+            for (int k = 1; k < 7; k++)
+                std::fprintf(stderr, "  one-launch pass: %-45s +%6.2f us  (at %6.2f)\n", name[k],
+                             (double)(long long)(t[k] - t[k - 1]) / 100.0, (double)(long long)(t[k] - t[0]) / 100.0);
+        }
+        (void)hipFree(c->d_timeline);
+    } else if (c->d_timeline && c->debug_stop == 100) {
         // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves
         std::vector<unsigned long long> tl(kTimelineWords);
         if (hipMemcpy(tl.data(), c->d_timeline, kTimelineWords * 8, hipMemcpyDeviceToHost) == hipSuccess) {

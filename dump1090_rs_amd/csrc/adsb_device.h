@@ -89,6 +89,8 @@ static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 // counter saturates near 90 atomics/us on this chip, and even an LDS counter is a round
 // trip per trial pass).  The simple kernel appends to a second list, `dap`, through one
 // shared counter: it is the slow path anyway.
+constexpr int kNewAddrCap = 16;
+constexpr int kFusedMaxTiles = 16 * 17;  // the largest one-launch pass: 16 buffers of 17 tiles
 constexpr int kApSegments = 1280;
 constexpr int kApWaveSegs = 4 * kApSegments;  // one per wave of a persistent workgroup
 
@@ -101,8 +103,13 @@ struct Counters {
     uint32_t n_cand_simple;  // candidates seen by the simple kernel (diagnostic)
     uint32_t blocks_done;    // records kernel: blocks that have finished (last one publishes)
     uint32_t rec_sum[2];     // records kernel: 64-bit sum of every u64 word of the records it wrote (8-byte aligned)
-    uint32_t learned_new;    // one-launch pass: a trial of this pass set an address bit that was clear before
+    uint32_t learned_new;    // one-launch pass: how often a trial of this pass set an address bit that was clear before
     uint32_t reserved1;
+    uint32_t new_addr[kNewAddrCap];  // ... and the first of those addresses
+    uint32_t unordered;      // one-launch pass: a workgroup gave up waiting for the tiles before its own (bounded wait)
+    uint32_t t_start[2];     // one-launch pass: the 100 MHz wall clock when its first workgroup started
+    uint32_t reserved2;
+    uint32_t tile_done[kFusedMaxTiles];  // one-launch pass: tile t's address bits and list entries are published
     uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
 };
@@ -119,6 +126,9 @@ struct Summary {
     uint32_t n_cand_total;  // all candidates
     uint32_t rec_sum_hi;
     uint32_t seq;           // the pass's sequence number (never 0): lets the host check it reads its own pass
+    uint32_t ticks;         // one-launch pass: its duration on the device's 100 MHz wall clock, first workgroup's
+                            // entry to the summary (written before seq): the launch needs no timing events
+    uint32_t pad;
 };
 
 // GF(2) tables, 256 u32 each (adsb_tables.h): F'0 F'1 F'2 | X56_0..2

@@ -138,11 +138,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.fused = fused;
     sl.unsynced_from = 0;
     p.fused_rec = fused ? sl.h_rec_dev : nullptr;
-    p.ev_start = ext_events && prof == 1 && fast ? sl.ev[0] : nullptr;
-    p.ev_stop = ext_events && prof == 1 && fast ? sl.ev[1] : nullptr;
+    // (a one-launch pass times itself on the device's wall clock and reports it with its summary)
+    p.ev_start = ext_events && prof == 1 && fast && !fused ? sl.ev[0] : nullptr;
+    p.ev_stop = ext_events && prof == 1 && fast && !fused ? sl.ev[1] : nullptr;
 
     c->flush_pending = false;
-    const bool classic = prof > 1 || (prof == 1 && (!fast || !ext_events));
+    const bool classic = !fused && (prof > 1 || (prof == 1 && (!fast || !ext_events)));
     // odd slots scan on the second stream, unless something orders consecutive passes (the
     // carry hand-off) or the pass is a one-off (fallback, caller-supplied magnitudes)
     static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
@@ -156,11 +157,14 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (input_done != input_ready_now()) {
         HT(c, HT_IN_READY);
         hipEvent_t ready = input_done;
-        if (!ready) {
+        // (no event at all when `stream` has nothing outstanding -- a query is a fraction of the record +
+        // wait pair, which is two thirds of what a one-launch pass costs the submitting thread)
+        const bool idle = !ready && hipStreamQuery(c->stream) == hipSuccess;
+        if (!ready && !idle) {
             ready = c->input_ready[si];
             HIP_TRY(c, hipEventRecord(ready, c->stream));
         }
-        HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
+        if (ready) HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     }
     // (0) the slot's lists and counters: a one-launch pass that used them last on another stream may still
     //     be zeroing them (the host goes by its summary, which it writes just before)

@@ -4,7 +4,7 @@
 using namespace adsb::host;
 
 namespace {
-constexpr uint64_t kRingInPlaceChunks = 8;
+constexpr uint64_t kRingInPlaceChunks = kInlineTailChunks;  // every one-launch size
 }
 
 extern "C" {
@@ -52,8 +52,8 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     // no copy command, no event, no staging -- the pass is as long as the transfer either way, and the
     // host side of it is a single launch.  Larger slots are copied while the slots before them compute.
     static const bool always_copy = tuning_env("ADSB_RING_COPY") != nullptr;
-    // (in place up to 8 buffers: measured 7.9 / 9.4 / 9.9 Gsample/s at 1 / 2 / 4 buffers per slot against 2.2 / - /
-    // 5.6 copied first; at 16 the copy engine's 44-51 GB/s beat the 39 GB/s a kernel reads over the link)
+    // (measured with eight in flight: 8.5 / 9.7 / 10.1 / 10.0 / 10.2 Gsample/s at 1 / 2 / 4 / 8 / 16 buffers per slot
+    // read in place; copied first and then one launch: 8.5 at 8, 10.2 at 16, and far less below)
     if (!always_copy && (n_samples + kChunkSamples - 1) / kChunkSamples <= kRingInPlaceChunks && !c->carry_over)
         return submit(c, r.h_iq_dev, false, n_samples, false, input_ready_now());
     // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's

@@ -488,7 +488,15 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint
     if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
         // (one-launch pass: an address bit that was clear until now means trials this pass has already
         // matched may have missed it -- its last workgroup then matches the lists once more)
-        if (learn && bitmap_set(p.bitmap, trial_addr(tr)) && p.fused_rec) atomicOr(&p.ctr->learned_new, 1u);
+        if (learn && p.fused_rec) {
+            const uint32_t addr = trial_addr(tr);
+            if (bitmap_set(p.bitmap, addr)) {
+                const uint32_t k = atomicAdd(&p.ctr->learned_new, 1u);
+                if (k < (uint32_t)kNewAddrCap) p.ctr->new_addr[k] = addr;
+            }
+        } else if (learn) {
+            bitmap_set(p.bitmap, trial_addr(tr));
+        }
     }
 }
 
@@ -518,9 +526,16 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
             acc_last = now_;                                      \
         }                                                         \
     } while (0)
+// (ADSB_TIMELINE=3): where a one-launch pass spends its time, on the 100 MHz wall clock: entry, tables in
+// LDS, tiles done, own match done, counted in (from here on: the last workgroup), second look done, end
+#define FSTAMP(k)                                                                                  \
+    do {                                                                                           \
+        if (FUSED && p.timeline && tid == 0) p.timeline[448 + (k)] = (unsigned long long)wall_clock64(); \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #define ACCT(k) do {} while (0)
+#define FSTAMP(k) do {} while (0)
 #endif
 
 // Persistent: the grid is what is resident at once and each workgroup walks tiles
@@ -530,6 +545,7 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
 template <bool FUSED>
 struct FusedLds {
     uint32_t x56[3 * 256];
+    uint32_t bits[168];   // per-bit residual constants (adsb_tables.h: build_bit_residuals) for the record builder
     uint32_t is_last;
 };
 template <>
@@ -538,10 +554,10 @@ struct FusedLds<false> {
 
 // One address/parity entry against the bitmap (k_match's test: adsb_aux.hip); a match goes to the hit
 // list and the entry is marked (code 15) so that a second look does not report it twice.
-__device__ __forceinline__ void fused_match_entry(const ScanParams &p, const uint32_t *x56, uint64_t *slot, uint64_t e)
+__device__ __forceinline__ bool fused_match_entry(const ScanParams &p, const uint32_t *x56, uint64_t *slot, uint64_t e)
 {
     const uint32_t code = entry_code(e);
-    if (code == 15u) return;
+    if (code == 15u) return false;
     uint32_t c = entry_value(e);
     if (code >= 5u && code < 10u) c = gf_apply(x56, c);
     // (agent scope: bits other workgroups of this launch have set, not a line this CU's cache holds)
@@ -551,7 +567,9 @@ __device__ __forceinline__ void fused_match_entry(const ScanParams &p, const uin
         if (idx < p.hits_cap) p.hits[idx] = e;
         else atomicOr(&p.ctr->overflow, 1u);
         *slot = e | (15ull << 24);
+        return true;
     }
+    return false;
 }
 
 template <bool FROM_MAG, bool SELFTEST = false, bool FUSED = false>
@@ -562,8 +580,15 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
+    FSTAMP(0);
     if constexpr (FUSED) {
+        if (blockIdx.x == 0 && tid == 0) {
+            const unsigned long long t0 = (unsigned long long)wall_clock64();
+            p.ctr->t_start[0] = (uint32_t)t0;
+            p.ctr->t_start[1] = (uint32_t)(t0 >> 32);
+        }
         for (int i = tid; i < 3 * 256; i += kThreads) fs.x56[i] = p.tables[kTabX56 * 256 + i];
+        if (tid < 168) fs.bits[tid] = p.tables[kTabBitsOff + tid];
         // an icao_flush retired a bitmap: every workgroup clears its share (k_records does it for the
         // passes of three launches)
         if (p.clean_bitmap) bitmap_clear(p.clean_bitmap, blockIdx.x * kThreads + tid, gridDim.x * kThreads);
@@ -617,6 +642,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
 #endif
 
     const bool late_prio = ADSB_PRIO_LATE != 0 && (ADSB_PRIO_LATE_DENSE != 0 || p.order_cnt == nullptr);
+    FSTAMP(1);
     uint32_t iter = 0;
     for (uint32_t t = t_first; t < t_end; t += t_stride, iter++) {
     const TileRef cur = tile_ref<FROM_MAG>(p, t);
@@ -917,51 +943,117 @@ tile_end:
     }
     if constexpr (FUSED) {
         // ============================================================ the tail of a one-launch pass
-        // (a) Each wave matches its own address/parity entries against the bitmap as it stands now: it
-        // holds every address of the passes before this one (stream order; the host redoes a pass whose
-        // predecessor on the other scan stream turns out to have learned one: adsb_collect.cpp) and
-        // whatever this pass has learned so far.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's entries have left
+        // (a) Publish this tile -- its address bits, list entries and counts -- and wait, for a bounded time,
+        // until every tile BEFORE it in the buffer order has done the same: a trial must see what earlier
+        // positions taught the filter (src/mode_s/mod.rs:71,115,130 read what :83,99 wrote), and workgroups
+        // finish in any order.  Workgroups only ever wait for tiles in front of them and publish before they
+        // wait, so the chain cannot close on itself; the wait is bounded anyway (a workgroup in front may
+        // not have been given a CU yet): whoever gives up says so, and then the last workgroup looks at
+        // every list once more (c).
+        FSTAMP(2);
+        static_assert(kFusedMaxTiles >= 16 * kTilesPerChunk, "tile flags of the largest one-launch pass");
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&p.ctr->tile_done[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 64) {
+            bool ordered = true;
+            for (uint32_t spins = 0;; spins++) {
+                bool all = true;
+                for (uint32_t k = (uint32_t)lane; k < blockIdx.x; k += 64u)
+                    all = all && __hip_atomic_load(&p.ctr->tile_done[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (__all(all)) break;
+                if (spins >= 200u) {  // ~0.2 ms
+                    ordered = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (lane == 0 && !ordered) atomicOr(&p.ctr->unordered, 1u);
+        }
+        __syncthreads();
+        // Each wave matches its own address/parity entries against the bitmap as it stands now: it holds
+        // every address of the passes before this one (stream order; the host redoes a pass whose
+        // predecessor on another scan stream turns out to have learned one: adsb_collect.cpp), what the
+        // tiles before this one learned, and whatever else this pass has learned so far (harmless: the host
+        // replay scores in order).
+        bool appended = false;
         {
             const uint32_t n_mine = min(ap_count, seg_cap);
             for (uint32_t i = (uint32_t)lane; i < n_mine; i += 64u)
-                fused_match_entry(p, fs.x56, &seg[i], __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                appended |= fused_match_entry(p, fs.x56, &seg[i], __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-        // (b) The last workgroup to get here runs the rest alone: release what this one wrote (list
-        // entries, marks, counts, address bits), count it in, acquire what the others wrote.
-        __threadfence();
+        // (b) The last workgroup to get here runs the rest alone: release what the match wrote (hits, marks;
+        // usually nothing -- the tile itself was published above), count this workgroup in, acquire what
+        // the others wrote.
+        FSTAMP(3);
+        if (__syncthreads_or(appended ? 1 : 0)) __threadfence();
         __syncthreads();
         if (tid == 0) fs.is_last = atomicAdd(&p.ctr->scan_blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
         __syncthreads();
         if (!fs.is_last) return;
         __threadfence();
-        // (c) An address bit that was clear when the pass began was set on the way: entries matched
-        // before that moment may have missed it (a trial must see what EARLIER positions taught, and a
-        // workgroup that scanned a later tile may have finished first -- extra hits are harmless, the
-        // host replay scores in order).  Once more over every segment, marked entries skipped.
-        if (__hip_atomic_load(&p.ctr->learned_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        FSTAMP(4);
+        // (c) The fallback: some workgroup matched without having seen all the tiles before it, and an
+        // address bit that was clear when the pass began was set on the way -- its entries may have missed
+        // it.  Once more over every segment, marked entries skipped.
+        const uint32_t n_new = __hip_atomic_load(&p.ctr->learned_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_new && __hip_atomic_load(&p.ctr->unordered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             const uint32_t nseg = gridDim.x * (uint32_t)kWaves;
-            constexpr uint32_t U = 8;  // segments a wave has in flight (each a chain count -> entry -> bitmap word)
+            // every segment's fill count into LDS first (one round trip for all of them), then each wave
+            // takes its segments nine at a time, their entries in flight together; with a handful of new
+            // addresses an entry is compared with those directly (no trip to the bitmap)
+            uint32_t *const cnt = s.plane;
+            static_assert(sizeof(s.plane) / 4 >= 4 * 16 * kTilesPerChunk, "fill counts of the largest one-launch pass");
+            for (uint32_t g = (uint32_t)tid; g < nseg; g += kThreads) cnt[g] = min(p.ctr->seg_ap[g], seg_cap);
+            uint32_t fresh[kNewAddrCap];
+            const bool by_list = n_new <= (uint32_t)kNewAddrCap;
+#pragma unroll
+            for (int k = 0; k < kNewAddrCap; k++)
+                fresh[k] = by_list && (uint32_t)k < n_new ? p.ctr->new_addr[k] : 0xFFFFFFFFu;
+            lds_barrier();
+            FSTAMP(8);
+            constexpr uint32_t U = 9;
             for (uint32_t g0 = (uint32_t)(tid >> 6) * U; g0 < nseg; g0 += kWaves * U) {
-                uint32_t n[U];
+                uint32_t n[U], nmax = 0;
 #pragma unroll
-                for (uint32_t u = 0; u < U; u++) n[u] = g0 + u < nseg ? min(p.ctr->seg_ap[g0 + u], seg_cap) : 0u;
-                uint32_t nmax = 0;
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) nmax = max(nmax, n[u]);
+                for (uint32_t u = 0; u < U; u++) {
+                    n[u] = g0 + u < nseg ? cnt[g0 + u] : 0u;
+                    nmax = max(nmax, n[u]);
+                }
                 for (uint32_t i = (uint32_t)lane; i < nmax; i += 64u) {
                     uint64_t e[U];
 #pragma unroll
                     for (uint32_t u = 0; u < U; u++) e[u] = i < n[u] ? p.ap[(uint64_t)(g0 + u) * seg_cap + i] : (15ull << 24);
 #pragma unroll
-                    for (uint32_t u = 0; u < U; u++) fused_match_entry(p, fs.x56, &p.ap[(uint64_t)(g0 + u) * seg_cap + i], e[u]);
+                    for (uint32_t u = 0; u < U; u++) {
+                        if (!by_list) {
+                            fused_match_entry(p, fs.x56, &p.ap[(uint64_t)(g0 + u) * seg_cap + i], e[u]);
+                            continue;
+                        }
+                        const uint32_t code = entry_code(e[u]);
+                        uint32_t c = entry_value(e[u]);
+                        if (code >= 5u && code < 10u) c = gf_apply(fs.x56, c);
+                        bool hit = false;
+#pragma unroll
+                        for (int k = 0; k < kNewAddrCap; k++) hit = hit || c == fresh[k];
+                        if (hit && code != 15u) {
+                            const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
+                            if (idx < p.hits_cap) p.hits[idx] = e[u];
+                            else atomicOr(&p.ctr->overflow, 1u);
+                        }
+                    }
                 }
             }
-            __threadfence();
+            FSTAMP(7);
+            // (this workgroup's own appends: written through, and read past this CU's cache by the record
+            // builder -- no cache write-back needed, only their completion)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        FSTAMP(5);
         // (d) records, checksum, summary into mapped host memory; the counters back to zero
-        records_block<FROM_MAG, false>(p, p.fused_rec, 0u, 1u, nullptr, false);
+        records_block<FROM_MAG, false, true>(p, p.fused_rec, 0u, 1u, nullptr, false, gridDim.x, fs.bits);
+        FSTAMP(6);
     }
 }
 

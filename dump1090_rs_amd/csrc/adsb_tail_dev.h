@@ -87,11 +87,19 @@ constexpr int kRecGroup = ADSB_REC_GROUP;  // hits a wave works on at once
 // one-launch small pass runs it as one block (its last workgroup to finish).  `sorted`: LDS for one
 // bucket (device-ordered launches only).  `clean`: this call also does its share of clearing a retired
 // bitmap (the one-launch pass has all its workgroups do that before they scan).
-template <bool FROM_MAG, bool BUCKETS>
+// SINGLE: the caller is the only block (the one-launch pass): no global atomics for the checksum or the block
+// count, totals and zeroing over the `used_blocks` scan workgroups' counters only, no wait for the records'
+// write acknowledgements before the summary (the host checks the checksum of what it finds and retries),
+// and the per-bit residual constants from `tb_lds` (LDS) instead of memory.
+template <bool FROM_MAG, bool BUCKETS, bool SINGLE = false>
 __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *rec, const uint32_t bid, const uint32_t nblk,
-                                              uint64_t *sorted, const bool clean)
+                                              uint64_t *sorted, const bool clean, const uint32_t used_blocks = 0,
+                                              const uint32_t *tb_lds = nullptr)
 {
-    const uint32_t n = min(p.ctr->n_hits, p.hits_cap);
+    // (SINGLE: other workgroups of this very launch, and this one's second look, counted hits in with
+    // atomics a moment ago: read past any line this CU's cache may still hold)
+    const uint32_t n_hits_now = SINGLE ? __hip_atomic_load(&p.ctr->n_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.ctr->n_hits;
+    const uint32_t n = min(n_hits_now, p.hits_cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Housekeeping so that no pass needs a reset launch: after an icao_flush retired a
     // bitmap, clear it here (address 0 always tests true, src/icao_filter.rs:71-80: bit 0
@@ -184,7 +192,9 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
 #pragma unroll
             for (int h = 0; h < kRecGroup; h++) {
                 // (every lane reads the same entry; made wave-uniform for the buffer resource below)
-                const uint64_t v = src[b0 - src_off + g0 + min((uint32_t)h, ng - 1u)];  // (past ng: a repeat, unused)
+                // (past ng: a repeat, unused.  SINGLE: the hit list was appended to by this very launch)
+                const uint64_t *at = &src[b0 - src_off + g0 + min((uint32_t)h, ng - 1u)];
+                const uint64_t v = SINGLE ? __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *at;
                 e[h] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
             }
@@ -254,7 +264,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
             unsigned long long half[kRecGroup][2];
             uint32_t crc[kRecGroup];
             unsigned long long pw[kRecGroup];
-            const uint32_t *tb = p.tables + kTabBitsOff;
+            const uint32_t *tb = SINGLE ? tb_lds : p.tables + kTabBitsOff;
 #pragma unroll
             for (int h = 0; h < kRecGroup; h++) {
                 const uint32_t tp = entry_tp(e[h]);
@@ -359,6 +369,49 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
         __syncthreads();  // stage is refilled by the next batch
     }
     }  // runs
+    if constexpr (SINGLE) {
+        // ---- the one-launch pass: this block is the whole tail
+        __shared__ unsigned long long wsum[4];
+        __shared__ uint32_t stot[2][4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) my_sum += __shfl_down(my_sum, off);
+        uint32_t ap = 0, cand = 0;
+        for (uint32_t i = threadIdx.x; i < 4u * used_blocks; i += blockDim.x) ap += p.ctr->seg_ap[i];
+        for (uint32_t i = threadIdx.x; i < used_blocks; i += blockDim.x) cand += p.ctr->seg_cand[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ap += __shfl_down(ap, off);
+            cand += __shfl_down(cand, off);
+        }
+        if (lane == 0) {
+            wsum[wave] = my_sum;
+            stot[0][wave] = ap;
+            stot[1][wave] = cand;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long rs = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            ap = stot[0][0] + stot[0][1] + stot[0][2] + stot[0][3];
+            cand = stot[1][0] + stot[1][1] + stot[1][2] + stot[1][3];
+            uint32_t *sm = (uint32_t *)p.summary;
+            const uint32_t ovf = __hip_atomic_load(&p.ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // how long the launch took, on the device's own clock (its first workgroup's entry to here)
+            const unsigned long long t0 = (unsigned long long)__hip_atomic_load(&p.ctr->t_start[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32 |
+                                          __hip_atomic_load(&p.ctr->t_start[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_store32(sm + 8, (uint32_t)((unsigned long long)wall_clock64() - t0));
+            const uint32_t vals[8] = {n_hits_now, ovf, (uint32_t)rs, p.ctr->n_dap,
+                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq};
+#pragma unroll
+            for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
+        }
+        __syncthreads();
+        // the counters this pass touched back to zero (the rest of the block never left it)
+        constexpr uint32_t kHead = offsetof(Counters, seg_ap) / 4;
+        for (uint32_t i = threadIdx.x; i < kHead; i += blockDim.x) ((uint32_t *)p.ctr)[i] = 0;
+        for (uint32_t i = threadIdx.x; i < 4u * used_blocks; i += blockDim.x) p.ctr->seg_ap[i] = 0;
+        for (uint32_t i = threadIdx.x; i < used_blocks; i += blockDim.x) p.ctr->seg_cand[i] = 0;
+        return;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's records have left
     // the pass's record checksum (the host recomputes it over what it finds in its memory)
     {

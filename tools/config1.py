@@ -14,10 +14,15 @@ iq = np.ascontiguousarray(raw[:, ::-1])           # file order is [im][re]
 ctx = Context(0, 1)
 dev = torch.from_numpy(iq).cuda()
 
-def timeit(fn, n=200):
-    for _ in range(20): fn()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): fn()
+def timeit(fn, seconds=1.0):
+    """mean over at least `seconds` of back-to-back calls after 0.3 s of them untimed (criterion warms up
+    for 3 s and measures for 5: a burst of 200 calls after idling times the GPU at its idle clocks)"""
+    t = time.perf_counter()
+    while time.perf_counter() - t < 0.3: fn()
+    torch.cuda.synchronize(); t = time.perf_counter(); n = 0
+    while time.perf_counter() - t < seconds:
+        for _ in range(50): fn()
+        n += 50
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
 
 def ref_api():
