@@ -402,12 +402,13 @@ def parity_leg(env: Env, r, chunks: int, baseline: bool = True):
             orc_mt = binding.Oracle(L)
             orc_mt.icao_flush()
             orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
-            orc_mt.icao_flush()
-            c0 = time.perf_counter()
-            want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr)
-            mt_s = time.perf_counter() - c0
-            if want_mt != want:
-                raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
+            times = []
+            for _ in range(3):   # (a pass over the buffer is tens of milliseconds on this many threads: median of three)
+                orc_mt.icao_flush()
+                want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr, timing=times)
+                if want_mt != want:
+                    raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
+            mt_s = _median(times)
     base = {
         "value": round(n / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": f"buffer 0 of the workload, all {chunks} x 131072 samples once, {cpu_s:.2f} s; "
@@ -416,8 +417,10 @@ def parity_leg(env: Env, r, chunks: int, baseline: bool = True):
     }
     if mt_s:
         base["all_cores"] = {"value": round(n / mt_s / 1e6, 2), "unit": "Msamples/s", "cores": n_thr,
-                             "sample": f"the same buffer, {n_thr} threads over the 131072-sample buffers + "
-                                       f"ordered replay, {mt_s:.2f} s"}
+                             "sample": f"the same buffer, {n_thr} threads: workers run to_mag + gates + slicer + DF / CRC "
+                                       f"class per 131072-sample buffer, only trials that can score or add reach the "
+                                       f"serial ordered replay (oracle/dump1090_oracle_mt.c); {mt_s * 1e3:.1f} ms inside the "
+                                       "C call, median of three"}
     if native is not None:
         try:
             os.unlink(native)

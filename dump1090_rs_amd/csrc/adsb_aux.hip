@@ -103,10 +103,16 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
                 if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
                     const uint32_t ch = (uint32_t)entry_chunk(e[k]);
                     const uint32_t at = atomicAdd(&p.order_cnt[ch], 1u);
-                    if (at < kOrderBucket) p.order_tmp[(size_t)ch * kOrderBucket + at] = e[k];
-                    else atomicOr(&p.ctr->overflow, 1u);
+                    if (at < kOrderBucket) {
+                        p.order_tmp[(size_t)ch * kOrderBucket + at] = e[k];
+                        // (an address/parity hit: no fields from the scan, the record builder slices it)
+                        if (p.hit_fields) p.hit_fields[((size_t)ch * kOrderBucket + at) * kHitFieldWords + 5] = 0u;
+                    } else {
+                        atomicOr(&p.ctr->overflow, 1u);
+                    }
                 } else if (idx < p.hits_cap) {
                     p.hits[idx] = e[k];
+                    if (p.hit_fields) p.hit_fields[(size_t)idx * kHitFieldWords + 5] = 0u;
                 } else {
                     atomicOr(&p.ctr->overflow, 1u);
                 }
@@ -515,7 +521,8 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
     if (from_mag)  // (one caller-supplied buffer: never device-ordered)
         hipLaunchKernelGGL((k_records<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     else if (p.order_cnt)  // device-ordered: dynamic LDS for the bucket being sorted
-        hipLaunchKernelGGL((k_records<false, true>), dim3(blocks), dim3(256), kOrderBucket * sizeof(uint64_t), (hipStream_t)stream, p, d_rec);
+        hipLaunchKernelGGL((k_records<false, true>), dim3(blocks), dim3(256), kOrderBucket * (sizeof(uint64_t) + sizeof(uint16_t)),
+                           (hipStream_t)stream, p, d_rec);
     else
         hipLaunchKernelGGL((k_records<false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     return hip_ok(hipGetLastError());

@@ -121,6 +121,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
             sl.hits_cap = c->hits_cap;
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_hit_fields, (size_t)c->hits_cap * kHitFieldWords * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_order_cnt, (max_chunks + 1) * sizeof(uint32_t)));
             HIP_TRY(c, hipMemset(sl.d_order_cnt, 0, (max_chunks + 1) * sizeof(uint32_t)));
@@ -266,6 +267,7 @@ void adsb_destroy(adsb_ctx *c)
         if (sl.scanned) (void)hipEventDestroy(sl.scanned);
         if (sl.d_ctr) (void)hipFree(sl.d_ctr);
         if (sl.d_hits) (void)hipFree(sl.d_hits);
+        if (sl.d_hit_fields) (void)hipFree(sl.d_hit_fields);
         if (sl.d_ap) (void)hipFree(sl.d_ap);
         if (sl.d_order_cnt) (void)hipFree(sl.d_order_cnt);
         if (sl.d_order_base) (void)hipFree(sl.d_order_base);

@@ -47,6 +47,7 @@ struct Slot {
     // stream) fills the other slot's
     Counters *d_ctr = nullptr;
     uint64_t *d_ap = nullptr, *d_hits = nullptr;
+    uint32_t *d_hit_fields = nullptr;  // per hit-list slot: the scan's five bit-class fields of a self-validating hit (ScanParams::hit_fields)
     // device-side ordering of the hit list: per-buffer counts and their prefix (max_chunks + 1
     // each), and the second list the counting sort scatters into
     uint32_t *d_order_cnt = nullptr, *d_order_base = nullptr;
@@ -103,6 +104,7 @@ struct adsb_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    bool own_stream_dirty = false;  // the library has enqueued something on own_stream that the next pass reads (a host-pointer call's copy)
     int profiling = 1;  // 0: no events, 1: around the scan kernel, 2: around every kernel
     bool flush_pending = true;  // consumed by the next pass: it switches to the clean spare bitmap
     uint32_t stagger_ticks = 0;

@@ -89,6 +89,7 @@ static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 // counter saturates near 90 atomics/us on this chip, and even an LDS counter is a round
 // trip per trial pass).  The simple kernel appends to a second list, `dap`, through one
 // shared counter: it is the slow path anyway.
+constexpr int kHitFieldWords = 8;  // ScanParams::hit_fields: f0..f4, flag, 2 spare
 constexpr int kNewAddrCap = 16;
 constexpr int kFusedMaxTiles = 16 * 17;  // the largest one-launch pass: 16 buffers of 17 tiles
 constexpr int kApSegments = 1280;
@@ -225,6 +226,12 @@ struct ScanParams {
     uint32_t cand_cap;
     // device-side scoring (k_score / k_emit; score.si null: the host replays the records)
     ScoreDev score;
+    // What the scan already knows about a self-validating hit, handed to the record builder: per slot of the
+    // hit list (p.hits index, or buffer * kOrderBucket + place in the bucket) eight words -- the five bit-class
+    // fields of the trial (message bit 5k + r = bit k of field r: all 112 sliced bits) and a flag that says
+    // they are there.  Hits the match finds (address/parity trials) clear the flag: their message is sliced
+    // from the samples as before.  Null: nobody writes or reads it.
+    uint32_t *hit_fields;
     // one-launch pass (k_scan_fast<.., FUSED>: scan + match + records in one kernel, for passes of a few
     // buffers): where its records go (mapped host memory), else null
     TrialRecord *fused_rec;
@@ -253,6 +260,7 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ
 // what the pass learned late, builds the records and publishes the summary; for passes of a few buffers
 int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream);
 int scan_resident_blocks();  // workgroups of the fast scan's persistent grid (<= kApSegments)
+bool scan_writes_hit_fields();
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);

@@ -74,6 +74,9 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;
     p.hits_cap = sl.hits_cap;
+    // (the slot's own hit list only: the fallback's worst-case list is filled by the reference-shaped kernel)
+    static const bool no_fields = tuning_env("ADSB_NO_HIT_FIELDS") != nullptr;
+    p.hit_fields = !force_simple && !no_fields && scan_writes_hit_fields() && sl.hits_cap == c->hits_cap ? sl.d_hit_fields : nullptr;
     p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
     p.seg_cap = c->seg_cap;
@@ -157,12 +160,16 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     if (input_done != input_ready_now()) {
         HT(c, HT_IN_READY);
         hipEvent_t ready = input_done;
-        // (no event at all when `stream` has nothing outstanding -- a query is a fraction of the record +
-        // wait pair, which is two thirds of what a one-launch pass costs the submitting thread)
-        const bool idle = !ready && hipStreamQuery(c->stream) == hipSuccess;
-        if (!ready && !idle) {
+        // No event at all when `stream` is the context's own and the library has put nothing on it that this
+        // pass could depend on (own_stream_dirty: the copies of the host-pointer entry points): the record +
+        // wait pair is two thirds of what a one-launch pass costs the submitting thread.  (hipStreamQuery is
+        // no substitute: on a stream that has seen work it took ~25 us, measured.)  A caller's stream
+        // (adsb_set_stream) is always waited for.
+        const bool nothing_to_wait_for = !ready && c->stream == c->own_stream && !c->own_stream_dirty;
+        if (!ready && !nothing_to_wait_for) {
             ready = c->input_ready[si];
             HIP_TRY(c, hipEventRecord(ready, c->stream));
+            c->own_stream_dirty = false;   // (what was on it is now behind this pass)
         }
         if (ready) HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     }
@@ -486,6 +493,7 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
     if (length) {
         HIP_TRY(c, hipMemcpyAsync(c->d_mag, data, kMagDataLen * sizeof(uint16_t),
                                   hipMemcpyHostToDevice, c->stream));
+        c->own_stream_dirty = true;
         int rc = run_sync(c, c->d_mag, true, length, msgs);
         if (rc) return rc;
     }
@@ -555,6 +563,7 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
     for (size_t off = 0; off < n_samples; off += piece) {
         const size_t n = std::min(piece, n_samples - off);
         HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq + 2 * off, n * 4, hipMemcpyHostToDevice, c->stream));
+        c->own_stream_dirty = true;
         std::vector<adsb_msg> part;
         rc = demod_device(c, c->d_stage, n, part);
         if (rc) return rc;

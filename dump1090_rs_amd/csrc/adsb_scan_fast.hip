@@ -65,6 +65,9 @@ using namespace fastgeo;
 #ifndef ADSB_GATE_ASM
 #define ADSB_GATE_ASM 1    // P4: the 19 magnitudes of a match as opaque zero-extended LDS reads (0 = C++ u16 loads)
 #endif
+#ifndef ADSB_HIT_FIELDS
+#define ADSB_HIT_FIELDS 1  // hand a self-validating hit's bit fields to the record builder (0: measurement)
+#endif
 #ifndef ADSB_SCAN_THREADS
 #define ADSB_SCAN_THREADS 256
 #endif
@@ -164,6 +167,9 @@ struct alignas(16) FastLds {
     uint16_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
     uint16_t cand[kWaves * kCandPerWave];  // per wave: slot (cand_entry() expands it for the trial stage)
     uint64_t hit[kHitCap];
+#if ADSB_HIT_FIELDS
+    uint32_t hitf[kHitCap][5];   // ... and the five bit-class fields of each (ScanParams::hit_fields)
+#endif
     uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
 };
 
@@ -315,8 +321,16 @@ __device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 
 }
 
 // a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
+__device__ __forceinline__ void put_hit_fields(const ScanParams &p, size_t place, const uint32_t (&f)[5])
+{
+    uint32_t *w = p.hit_fields + place * kHitFieldWords;
+#pragma unroll
+    for (int r = 0; r < 5; r++) w[r] = f[r];
+    w[5] = 1u;
+}
+
 __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane,
-                                          uint32_t par)
+                                          uint32_t par, const uint32_t (&f)[5])
 {
     const unsigned long long mh = __ballot(is_hit);
     if (!mh) return;
@@ -326,15 +340,24 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool 
     if (is_hit) {
         if (at < (uint32_t)kHitCap) {
             s.hit[at] = entry;
+#if ADSB_HIT_FIELDS
+#pragma unroll
+            for (int r = 0; r < 5; r++) s.hitf[at][r] = f[r];
+#endif
         } else {  // more hits in one tile than the staging holds: one by one
             const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
             if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
                 const uint32_t c = (uint32_t)entry_chunk(entry);
                 const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
-                if (k < kOrderBucket) p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
-                else atomicOr(&p.ctr->overflow, 1u);
+                if (k < kOrderBucket) {
+                    p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
+                    if (ADSB_HIT_FIELDS && p.hit_fields) put_hit_fields(p, (size_t)c * kOrderBucket + k, f);
+                } else {
+                    atomicOr(&p.ctr->overflow, 1u);
+                }
             } else if (gi < p.hits_cap) {
                 p.hits[gi] = entry;
+                if (ADSB_HIT_FIELDS && p.hit_fields) put_hit_fields(p, gi, f);
             } else {
                 atomicOr(&p.ctr->overflow, 1u);
             }
@@ -484,7 +507,7 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint
         if (is_ap && mine < seg_cap) seg[mine] = entry;
         ap_count += (uint32_t)__popcll(ma);
     }
-    if (__ballot(is_hit)) stage_hit(p, s, is_hit, entry, lane, par);  // rare
+    if (__ballot(is_hit)) stage_hit(p, s, is_hit, entry, lane, par, tr.f);  // rare
     if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
         // (one-launch pass: an address bit that was clear until now means trials this pass has already
         // matched may have missed it -- its last workgroup then matches the lists once more)
@@ -564,8 +587,12 @@ __device__ __forceinline__ bool fused_match_entry(const ScanParams &p, const uin
     const uint32_t w = __hip_atomic_load(&p.bitmap[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((w >> (c & 31)) & 1u) {
         const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
-        if (idx < p.hits_cap) p.hits[idx] = e;
-        else atomicOr(&p.ctr->overflow, 1u);
+        if (idx < p.hits_cap) {
+            p.hits[idx] = e;
+            if (p.hit_fields) p.hit_fields[(size_t)idx * kHitFieldWords + 5] = 0u;
+        } else {
+            atomicOr(&p.ctr->overflow, 1u);
+        }
         *slot = e | (15ull << 24);
         return true;
     }
@@ -925,7 +952,12 @@ tile_end:
         if (s.hit_base + nhit > dst_cap) {
             if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
         } else {
-            for (uint32_t i = tid; i < nhit; i += kThreads) dst[s.hit_base + i] = s.hit[i];
+            for (uint32_t i = tid; i < nhit; i += kThreads) {
+                dst[s.hit_base + i] = s.hit[i];
+#if ADSB_HIT_FIELDS
+                if (p.hit_fields) put_hit_fields(p, (size_t)(dst - (p.order_cnt ? p.order_tmp : p.hits)) + s.hit_base + i, s.hitf[i]);
+#endif
+            }
         }
     }
     ACCT(6);
@@ -1038,8 +1070,12 @@ tile_end:
                         for (int k = 0; k < kNewAddrCap; k++) hit = hit || c == fresh[k];
                         if (hit && code != 15u) {
                             const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
-                            if (idx < p.hits_cap) p.hits[idx] = e[u];
-                            else atomicOr(&p.ctr->overflow, 1u);
+                            if (idx < p.hits_cap) {
+                                p.hits[idx] = e[u];
+                                if (p.hit_fields) p.hit_fields[(size_t)idx * kHitFieldWords + 5] = 0u;
+                            } else {
+                                atomicOr(&p.ctr->overflow, 1u);
+                            }
                         }
                     }
                 }
@@ -1064,6 +1100,9 @@ inline void hip_clear() { (void)hipGetLastError(); }
 }  // namespace
 
 // persistent grid = what is resident at once (occupancy API x CUs), found once
+// whether this build's scan hands hit fields over (the host leaves ScanParams::hit_fields null otherwise)
+bool scan_writes_hit_fields() { return ADSB_HIT_FIELDS != 0; }
+
 int scan_resident_blocks()
 {
     // (a function-local static: initialised once, also when two threads create contexts at once)

@@ -133,6 +133,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
     for (;;) {
     const uint64_t *src;
     uint32_t src_off, run_first, run_last;
+    size_t field_base = 0;   // buckets: the bucket's first slot in ScanParams::hit_fields
     if constexpr (buckets) {
         if (overflowed || next_chunk >= p.n_chunks) break;
         const uint32_t c = next_chunk;
@@ -143,6 +144,8 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
         if (threadIdx.x == 0) p.order_cnt[c] = 0;
         uint64_t mine[kOrderBucket / 256];
         uint32_t rank[kOrderBucket / 256];
+        // (behind the sorted entries: where each one sat in the bucket -- its slot in ScanParams::hit_fields)
+        uint16_t *const sorted_at = reinterpret_cast<uint16_t *>(sorted + kOrderBucket);
 #pragma unroll
         for (int k = 0; k < (int)kOrderBucket / 256; k++) {
             const uint32_t i = threadIdx.x + 256u * k;
@@ -162,10 +165,14 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < (int)kOrderBucket / 256; k++)
-            if (threadIdx.x + 256u * k < bn) sorted[rank[k]] = mine[k];
+            if (threadIdx.x + 256u * k < bn) {
+                sorted[rank[k]] = mine[k];
+                sorted_at[rank[k]] = (uint16_t)(threadIdx.x + 256u * k);
+            }
         __syncthreads();
         src = sorted;
         src_off = lo;
+        field_base = (size_t)c * kOrderBucket;
         run_first = lo;
         run_last = lo + bn;
     } else {
@@ -198,6 +205,73 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                 e[h] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
             }
+            unsigned long long half[kRecGroup][2];
+            uint32_t crc[kRecGroup];
+            unsigned long long pw[kRecGroup];
+            // What the scan knew about a self-validating hit when it found it -- all 112 sliced bits, as the
+            // five bit-class fields, and the residual (the entry's value: 0 for a clean DF17 / DF18, the IID
+            // bits for a clean DF11) -- came along in hit_fields: such a hit needs no window, no slicer and no
+            // CRC here, only the 33-sample power (demod_2400.rs:191-196).  A group with a hit the match found
+            // (address/parity trial: flag clear) takes the whole road for all four.
+            bool from_fields = !FROM_MAG && p.hit_fields != nullptr;
+            size_t place[kRecGroup];
+            if (from_fields) {
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h++) {
+                    const uint32_t q = b0 - src_off + g0 + min((uint32_t)h, ng - 1u);
+                    if constexpr (buckets) place[h] = field_base + reinterpret_cast<const uint16_t *>(sorted + kOrderBucket)[q];
+                    else place[h] = q;
+                }
+                uint32_t all = 1u;
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h++) all &= p.hit_fields[place[h] * kHitFieldWords + 5];
+                from_fields = __builtin_amdgcn_readfirstlane((int)all) != 0;
+            }
+            if (from_fields) {
+                const uint32_t k0 = __umul24((uint32_t)lane, 13108u) >> 16, r0 = (uint32_t)lane - 5u * k0;          // lane / 5, % 5
+                const uint32_t k1 = __umul24((uint32_t)lane + 64u, 13108u) >> 16, r1 = (uint32_t)lane + 64u - 5u * k1;
+                uint32_t fw0[kRecGroup], fw1[kRecGroup], w[kRecGroup];
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h++) {
+                    fw0[h] = p.hit_fields[place[h] * kHitFieldWords + r0];
+                    fw1[h] = p.hit_fields[place[h] * kHitFieldWords + r1];
+                    // the IQ behind data[j + 19 + lane] (the range-checked resource of the full path below)
+                    const uint64_t chunk = entry_chunk(e[h]);
+                    const int len = chunk_len(p.n_samples, chunk);
+                    const uint32_t *iq = (const uint32_t *)p.src + chunk * (uint64_t)kChunkSamples;
+                    const bool lead = p.carry != nullptr && (chunk > 0 || p.lead_from_src);
+                    const int shift = lead ? kCarrySamples : 0;
+                    const __amdgpu_buffer_rsrc_t rsrc =
+                        __builtin_amdgcn_make_buffer_rsrc((void *)(iq - shift), 0, (len + shift) * 4, 0x00020000);
+                    int off = ((int)entry_j(e[h]) + 19 - kLead + shift + lane) * 4;
+                    asm volatile("" : "+v"(off));
+                    w[h] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+                    if (p.carry != nullptr && !lead) {
+                        const __amdgpu_buffer_rsrc_t crsrc =
+                            __builtin_amdgcn_make_buffer_rsrc((void *)p.carry, 0, kCarrySamples * 4, 0x00020000);
+                        int coff = off + kCarrySamples * 4;
+                        asm volatile("" : "+v"(coff));
+                        w[h] |= __builtin_amdgcn_raw_buffer_load_b32(crsrc, coff, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h += 2) {  // two magnitudes per pass of the packed arithmetic
+                    const uint32_t m2 = mag2(w[h], h + 1 < kRecGroup ? w[h + 1] : 0u);
+                    const unsigned long long ma = lane < 33 ? (m2 & 0xFFFFu) : 0u, mb = lane < 33 ? (m2 >> 16) : 0u;
+                    pw[h] = ma * ma;
+                    if (h + 1 < kRecGroup) pw[h + 1] = mb * mb;
+                }
+#pragma unroll
+                for (int h = 0; h < kRecGroup; h++) {
+                    half[h][0] = __brevll(__ballot(((fw0[h] >> k0) & 1u) != 0));
+                    half[h][1] = __brevll(__ballot(lane < 48 && ((fw1[h] >> k1) & 1u) != 0));
+                    crc[h] = entry_value(e[h]);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                    for (int h = 0; h < kRecGroup; h++) pw[h] += __shfl_xor(pw[h], off);
+            } else {
             // win[h][k] = data[j_h + 19 + k]
             if (FROM_MAG) {
 #pragma unroll
@@ -261,9 +335,6 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            unsigned long long half[kRecGroup][2];
-            uint32_t crc[kRecGroup];
-            unsigned long long pw[kRecGroup];
             const uint32_t *tb = SINGLE ? tb_lds : p.tables + kTabBitsOff;
 #pragma unroll
             for (int h = 0; h < kRecGroup; h++) {
@@ -302,6 +373,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                     crc[h] ^= __shfl_xor(crc[h], off);
                     pw[h] += __shfl_xor(pw[h], off);
                 }
+            }  // the whole road
             if ((uint32_t)lane < ng) {
                 uint64_t me = e[0];
                 unsigned long long h0 = half[0][0], h1 = half[0][1], mpw = pw[0];

@@ -144,17 +144,25 @@ class Oracle:
         assert n <= cap
         return [unpack(m) for m in out[:n]], st
 
-    def demod_iq(self, iq, cap: Optional[int] = None, threads: int = 1):
-        """threads > 1: workers per buffer + ordered replay (dump1090_oracle_mt.c), same result"""
+    def demod_iq(self, iq, cap: Optional[int] = None, threads: int = 1, timing: Optional[list] = None):
+        """threads > 1: workers per buffer + ordered replay (dump1090_oracle_mt.c), same result.
+        `timing`: a list that gets the seconds spent inside the C call appended (the output array --
+        40 MB for a million messages -- is allocated and zeroed outside of that)."""
+        import time
         a = as_iq(iq)
         cap = cap or max(4096, a.shape[0] // 64)
-        out = (OrcMsg * cap)()
+        if getattr(self, "_out_cap", 0) != cap:
+            self._out, self._out_cap = (OrcMsg * cap)(), cap
+        out = self._out
         st = OrcStats()
+        t0 = time.perf_counter()
         if threads > 1:
             n = self.L.orc_demod_iq_mt(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap,
                                        C.byref(st), threads)
         else:
             n = self.L.orc_demod_iq(C.byref(self.filter), a.ctypes.data, a.shape[0], out, cap, C.byref(st))
+        if timing is not None:
+            timing.append(time.perf_counter() - t0)
         assert n <= cap, "oracle output overflowed its buffer"
         return [unpack(m) for m in out[:n]], st
 
