@@ -13,14 +13,32 @@ namespace {
 // (src/lib.rs:36-50, src/utils.rs:43-58).
 // ---------------------------------------------------------------------------
 
+// Eight outputs per thread: one 16-byte store (the output may be pinned host memory, written over the link:
+// 2-byte stores would be 128 bytes per wave-instruction there); the eight samples behind them through a
+// buffer resource over the n input samples (a dword each, 4-byte aligned: the 326-sample lead-in shifts the
+// output by 6 of 8; out of range -- lead-in, tail -- reads as zero IQ, whose magnitude is zero).
 __global__ __launch_bounds__(256) void k_to_mag(const uint32_t *__restrict__ iq, uint32_t n,
                                                 uint16_t *__restrict__ data)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (uint32_t)kMagDataLen) return;
-    uint32_t v = 0;
-    if (i >= (uint32_t)kLead && i - kLead < n) v = mag_of_dword(iq[i - kLead]);
-    data[i] = (uint16_t)v;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i0 = 8u * t;                       // first output of this thread
+    if (i0 >= (uint32_t)kMagDataLen) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)iq, 0, (int)(n * 4u), 0x00020000);
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int off = ((int)i0 + i - kLead) * 4;          // negative in the lead-in: out of range, zero
+        asm volatile("" : "+v"(off));                 // (not folded into the immediate: adsb_tail_dev.h, records)
+        w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+    }
+    uint32_t pk[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) pk[i] = mag2(w[2 * i], w[2 * i + 1]);
+    if (i0 + 8u <= (uint32_t)kMagDataLen) {
+        *(uint4 *)(data + i0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    } else {  // the last, partial group (131398 = 8 * 16424 + 6)
+        for (uint32_t i = 0; i0 + i < (uint32_t)kMagDataLen; i++) data[i0 + i] = (uint16_t)(pk[i >> 1] >> (16 * (i & 1)));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -482,7 +500,7 @@ inline void hip_clear() { (void)hipGetLastError(); }
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream)
 {
     hip_clear();
-    const int blocks = (kMagDataLen + 255) / 256;
+    const int blocks = ((kMagDataLen + 7) / 8 + 255) / 256;
     hipLaunchKernelGGL(k_to_mag, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t *)d_iq, n, d_data);
     return hip_ok(hipGetLastError());

@@ -284,7 +284,8 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         // icao_flush: as for the overflow fallback, drain the streams and put the filter's addresses (the
         // state that preceded this pass) back into the bitmap in use.
         c->rematches++;
-        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
+        for (hipStream_t q : c->scan_stream)
+            if (q) HIP_TRY(c, hipStreamSynchronize(q));
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
         HIP_TRY(c, hipStreamSynchronize(c->score_stream));
         const bool keep_flush = c->flush_pending;
@@ -298,7 +299,8 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
     }
     if (rc > 0 && sl.from_mag) {  // a caller-supplied buffer denser than the fast scan's lists: again, the slow way
         st.retries++;
-        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));
+        for (hipStream_t q : c->scan_stream)
+            if (q) HIP_TRY(c, hipStreamSynchronize(q));
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
         HIP_TRY(c, hipStreamSynchronize(c->score_stream));
         const bool keep_flush = c->flush_pending;
@@ -311,7 +313,8 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out)
         c->flush_pending = keep_flush;
     } else if (rc > 0) {
         st.retries++;
-        for (hipStream_t q : c->scan_stream) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
+        for (hipStream_t q : c->scan_stream)
+            if (q) HIP_TRY(c, hipStreamSynchronize(q));  // later passes have their results on the host
         HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
         HIP_TRY(c, hipStreamSynchronize(c->score_stream));
         const bool keep_flush = c->flush_pending;

@@ -51,6 +51,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     // (a context for passes of a few buffers: one launch each, eight in flight -- adsb_ctx.h)
     c->n_slots = max_chunks <= kInlineTailChunks ? ADSB_MAX_IN_FLIGHT_SMALL : ADSB_MAX_IN_FLIGHT;
     c->n_bitmaps = c->n_slots + 1;
+    c->n_scan_streams = c->n_slots == ADSB_MAX_IN_FLIGHT_SMALL ? kScanStreams : 2;
     if (const char *ds = tuning_env("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     if (const char *st = tuning_env("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
     // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
@@ -75,6 +76,12 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         if (reuse) {
             c->own_stream = pooled.own;
             for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = pooled.scan[k];
+            for (int k = 2; k < c->n_scan_streams; k++)   // (the set comes from a context that had two)
+                if (!c->scan_stream[k]) {
+                    int least = 0, greatest = 0;
+                    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[k], hipStreamNonBlocking, greatest));
+                }
             c->tail_stream = pooled.tail;
             c->score_stream = pooled.score;
             c->copy_stream_spare = pooled.copy;
@@ -82,7 +89,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         }
         c->stream = c->own_stream;
-        HIP_TRY(c, hipMalloc((void **)&c->d_mag, kMagDataLen * sizeof(uint16_t)));
         if (!reuse) {
             // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
             // default, per priority) and two streams on one queue run strictly one after the other.
@@ -108,7 +114,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, pt));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, p0));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, p1));
-            for (int k = 2; k < kScanStreams; k++)
+            for (int k = 2; k < c->n_scan_streams; k++)
                 HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[k], hipStreamNonBlocking, k & 1 ? p1 : p0));
             if (tuning_env("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
         }
@@ -280,7 +286,6 @@ void adsb_destroy(adsb_ctx *c)
         if (sl.h_rec) (void)hipHostFree(sl.h_rec);
     }
     if (c->d_stage) (void)hipFree(c->d_stage);
-    if (c->d_mag) (void)hipFree(c->d_mag);
     for (auto &b : c->d_bitmap)
         if (b) (void)hipFree(b);
     for (hipStream_t q : c->scan_stream)
@@ -371,7 +376,7 @@ void adsb_destroy(adsb_ctx *c)
         bool all_scan = true;
         for (int k = 0; k < kScanStreams; k++) {
             set.scan[k] = c->scan_stream[k];
-            all_scan = all_scan && set.scan[k];
+            all_scan = all_scan && (set.scan[k] || k >= 2);   // (a large context has two)
         }
         set.tail = c->tail_stream;
         set.score = c->score_stream;

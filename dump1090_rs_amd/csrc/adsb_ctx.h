@@ -116,7 +116,6 @@ struct adsb_ctx {
     size_t stage_bytes = 0;
     void *h_stage = nullptr, *h_stage_dev = nullptr;  // ... pinned and mapped, for calls of a few buffers: the pass reads it in place
     size_t h_stage_bytes = 0;
-    uint16_t *d_mag = nullptr;  // one MagnitudeBuffer.data
     // Address bitmaps in rotation (one more than passes in flight): icao_flush moves on to the
     // next (clean) one, the retired one is cleared by that pass's records kernel and comes back
     // into use kSlots flushes later -- a pass that far ahead cannot even be submitted before the
@@ -136,6 +135,8 @@ struct adsb_ctx {
     // buffers, whose kernels are mostly latency -- a link read, one round of tiles, a one-workgroup tail --
     // rotate over all four so that three or four of them overlap)
     hipStream_t scan_stream[kScanStreams] = {};
+    int n_scan_streams = 2;  // 4 for a context of a few buffers per pass; a large one keeps the two it always had
+                             // (every further stream is another hardware queue for the tail streams to share)
     hipEvent_t prev_scanned = nullptr;      // the latest submission's scan-end event and the stream it is on
     hipStream_t prev_scan_stream = nullptr;
     bool prev_inline = false;               // ... and whether its match ran there rather than on the tail stream

@@ -260,7 +260,6 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ
 // what the pass learned late, builds the records and publishes the summary; for passes of a few buffers
 int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream);
 int scan_resident_blocks();  // workgroups of the fast scan's persistent grid (<= kApSegments)
-bool scan_writes_hit_fields();
 int launch_scan_simple(const ScanParams &p, bool from_mag, void *stream);  // reference-shaped path
 int launch_match(const ScanParams &p, void *stream);
 int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void *stream);

@@ -76,7 +76,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.hits_cap = sl.hits_cap;
     // (the slot's own hit list only: the fallback's worst-case list is filled by the reference-shaped kernel)
     static const bool no_fields = tuning_env("ADSB_NO_HIT_FIELDS") != nullptr;
-    p.hit_fields = !force_simple && !no_fields && scan_writes_hit_fields() && sl.hits_cap == c->hits_cap ? sl.d_hit_fields : nullptr;
+    p.hit_fields = nullptr;   // (set below, once it is known whether the pass is a dense stream's or one launch)
     p.ap = sl.d_ap;
     p.ap_cap = c->ap_cap;
     p.seg_cap = c->seg_cap;
@@ -141,6 +141,10 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.fused = fused;
     sl.unsynced_from = 0;
     p.fused_rec = fused ? sl.h_rec_dev : nullptr;
+    // the scan hands the bit fields of its self-validating hits to the record builder: where the record
+    // builder's instructions matter (dense streams: it shares the vector pipes with the next scan) and in
+    // one-launch passes; a sparse stream's scan stays the lean instantiation
+    if (fused || (order_on_device && !no_fields)) p.hit_fields = sl.d_hit_fields;
     // (a one-launch pass times itself on the device's wall clock and reports it with its summary)
     p.ev_start = ext_events && prof == 1 && fast && !fused ? sl.ev[0] : nullptr;
     p.ev_stop = ext_events && prof == 1 && fast && !fused ? sl.ev[1] : nullptr;
@@ -153,7 +157,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     static const int fused_streams = tuning_env("ADSB_FUSED_STREAMS") ? std::atoi(tuning_env("ADSB_FUSED_STREAMS")) : kScanStreams;
     const bool rotate = fast && !p.carry && advance_carry && !one_scan_stream;
     // (a slot's passes of one kind always land on the same stream: the slot count is a multiple of both periods)
-    const int si = !rotate ? 0 : (int)(c->submitted % (uint64_t)(fused ? std::max(1, std::min(fused_streams, kScanStreams)) : 2));
+    const int si = !rotate ? 0 : (int)(c->submitted % (uint64_t)(fused ? std::max(1, std::min(fused_streams, c->n_scan_streams)) : 2));
     hipStream_t ss = c->scan_stream[si];
     // the input is complete at `input_done` (the ring's copy), already (input_ready_now: pinned memory the
     // host has filled), or where `stream` stands now
@@ -260,7 +264,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
             HIP_TRY(c, hipStreamWaitEvent(ts, c->prev_scanned, 0));
         // edge (3): one-launch passes in flight on a stream this match is not behind
         for (hipStream_t q : c->scan_stream) {
-            if (q == ts || (q == ss && !inline_tail)) continue;   // (behind its own scan: behind everything on that stream)
+            if (!q || q == ts || (q == ss && !inline_tail)) continue;   // (behind its own scan: behind everything on that stream)
             bool any = false;
             for (Slot &other : c->slot) any = any || (&other != &sl && other.busy && other.fused && other.tail_q == q);
             if (!any) continue;
@@ -467,14 +471,20 @@ int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, si
     if (!c || (!iq && n) || !data_out) return ADSB_ERR_INVALID;
     if (n > kChunkSamples) return ADSB_ERR_TOO_LONG;  // reference: index panic, lib.rs:48
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_stage(c, (size_t)kChunkSamples * 4);
-    if (rc) return rc;
-    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_stage, iq, n * 4, hipMemcpyHostToDevice, c->stream));
-    if (int e = launch_to_mag(c->d_stage, (uint32_t)n, c->d_mag, c->stream))
+    // Through pinned, mapped memory both ways: one host copy in, the kernel reads the samples and writes
+    // the 131398 magnitudes in place over the link, one host copy out -- instead of two copy commands
+    // from / to pageable memory with their staging inside the runtime (62 -> ~36 us for the reference's
+    // own buffer size).
+    const size_t in_bytes = (size_t)kChunkSamples * 4, out_bytes = (size_t)kMagDataLen * sizeof(uint16_t);
+    const size_t out_off = (in_bytes + 255) & ~(size_t)255;
+    if (int rc = ensure_host_stage(c, out_off + out_bytes)) return rc;
+    if (n) std::memcpy(c->h_stage, iq, n * 4);
+    uint16_t *h_mag = reinterpret_cast<uint16_t *>((char *)c->h_stage + out_off);
+    uint16_t *h_mag_dev = reinterpret_cast<uint16_t *>((char *)c->h_stage_dev + out_off);
+    if (int e = launch_to_mag(c->h_stage_dev, (uint32_t)n, h_mag_dev, c->stream))
         return fail(c, (hipError_t)e, "launch_to_mag");
-    HIP_TRY(c, hipMemcpyAsync(data_out, c->d_mag, kMagDataLen * sizeof(uint16_t),
-                              hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(data_out, h_mag, out_bytes);
     if (length_out) *length_out = n;
     return ADSB_OK;
 }
@@ -491,10 +501,11 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
     c->stats.n_chunks = 1;
     std::vector<adsb_msg> msgs;
     if (length) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_mag, data, kMagDataLen * sizeof(uint16_t),
-                                  hipMemcpyHostToDevice, c->stream));
-        c->own_stream_dirty = true;
-        int rc = run_sync(c, c->d_mag, true, length, msgs);
+        // the caller's MagnitudeBuffer into pinned memory; the pass (one launch) reads it in place
+        const size_t bytes = (size_t)kMagDataLen * sizeof(uint16_t);
+        if (int rc = ensure_host_stage(c, bytes)) return rc;
+        std::memcpy(c->h_stage, data, bytes);
+        int rc = run_sync(c, c->h_stage_dev, true, length, msgs, input_ready_now());
         if (rc) return rc;
     }
     return deliver(c, msgs, out, cap, n_out);

@@ -65,9 +65,6 @@ using namespace fastgeo;
 #ifndef ADSB_GATE_ASM
 #define ADSB_GATE_ASM 1    // P4: the 19 magnitudes of a match as opaque zero-extended LDS reads (0 = C++ u16 loads)
 #endif
-#ifndef ADSB_HIT_FIELDS
-#define ADSB_HIT_FIELDS 1  // hand a self-validating hit's bit fields to the record builder (0: measurement)
-#endif
 #ifndef ADSB_SCAN_THREADS
 #define ADSB_SCAN_THREADS 256
 #endif
@@ -167,9 +164,6 @@ struct alignas(16) FastLds {
     uint16_t pat[kWaves * kPatPerWave];    // per wave: slot | branch (0..4) << 13
     uint16_t cand[kWaves * kCandPerWave];  // per wave: slot (cand_entry() expands it for the trial stage)
     uint64_t hit[kHitCap];
-#if ADSB_HIT_FIELDS
-    uint32_t hitf[kHitCap][5];   // ... and the five bit-class fields of each (ScanParams::hit_fields)
-#endif
     uint32_t nhit[2], hit_base;  // staged-hit count of a tile, double-buffered by tile parity
 };
 
@@ -329,8 +323,21 @@ __device__ __forceinline__ void put_hit_fields(const ScanParams &p, size_t place
     w[5] = 1u;
 }
 
-__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool is_hit, uint64_t entry, int lane,
-                                          uint32_t par, const uint32_t (&f)[5])
+// LDS only the instantiations that hand hit fields over have (FIELDS: dense streams, whose record builder is
+// what the scan's vector pipes share their cycles with, and one-launch passes).  The sparse stream's
+// instantiation stays at 102 registers and 31.2 KB: two registers more and a fifth workgroup no longer
+// fits a CU while consecutive launches overlap (measured: +3 % on the pipelined step).
+template <bool FIELDS>
+struct HitFieldLds {
+    uint32_t f[kHitCap][5];   // the five bit-class fields of each staged hit (ScanParams::hit_fields)
+};
+template <>
+struct HitFieldLds<false> {
+};
+
+template <bool FIELDS>
+__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS> &hf, bool is_hit, uint64_t entry,
+                                          int lane, uint32_t par, const uint32_t (&f)[5])
 {
     const unsigned long long mh = __ballot(is_hit);
     if (!mh) return;
@@ -340,10 +347,10 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool 
     if (is_hit) {
         if (at < (uint32_t)kHitCap) {
             s.hit[at] = entry;
-#if ADSB_HIT_FIELDS
+            if constexpr (FIELDS) {
 #pragma unroll
-            for (int r = 0; r < 5; r++) s.hitf[at][r] = f[r];
-#endif
+                for (int r = 0; r < 5; r++) hf.f[at][r] = f[r];
+            }
         } else {  // more hits in one tile than the staging holds: one by one
             const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
             if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
@@ -351,13 +358,13 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, bool 
                 const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
                 if (k < kOrderBucket) {
                     p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
-                    if (ADSB_HIT_FIELDS && p.hit_fields) put_hit_fields(p, (size_t)c * kOrderBucket + k, f);
+                    if constexpr (FIELDS) put_hit_fields(p, (size_t)c * kOrderBucket + k, f);
                 } else {
                     atomicOr(&p.ctr->overflow, 1u);
                 }
             } else if (gi < p.hits_cap) {
                 p.hits[gi] = entry;
-                if (ADSB_HIT_FIELDS && p.hit_fields) put_hit_fields(p, gi, f);
+                if constexpr (FIELDS) put_hit_fields(p, gi, f);
             } else {
                 atomicOr(&p.ctr->overflow, 1u);
             }
@@ -489,8 +496,9 @@ __device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s,
 }
 
 // One 64-lane pass of the trials: lane = (candidate entry ce, try_phase 4 + tpi).
-__device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint32_t ce, uint32_t tpi, bool live,
-                                           int jbase, uint32_t chunk, uint64_t *seg, uint32_t seg_cap,
+template <bool FUSED, bool FIELDS>
+__device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS> &hf, uint32_t ce, uint32_t tpi,
+                                           bool live, int jbase, uint32_t chunk, uint64_t *seg, uint32_t seg_cap,
                                            uint32_t &ap_count, int lane, uint32_t par)
 {
     Trial tr;
@@ -507,18 +515,20 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, uint
         if (is_ap && mine < seg_cap) seg[mine] = entry;
         ap_count += (uint32_t)__popcll(ma);
     }
-    if (__ballot(is_hit)) stage_hit(p, s, is_hit, entry, lane, par, tr.f);  // rare
+    if (__ballot(is_hit)) stage_hit<FIELDS>(p, s, hf, is_hit, entry, lane, par, tr.f);  // rare
     if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
         // (one-launch pass: an address bit that was clear until now means trials this pass has already
         // matched may have missed it -- its last workgroup then matches the lists once more)
-        if (learn && p.fused_rec) {
-            const uint32_t addr = trial_addr(tr);
-            if (bitmap_set(p.bitmap, addr)) {
-                const uint32_t k = atomicAdd(&p.ctr->learned_new, 1u);
-                if (k < (uint32_t)kNewAddrCap) p.ctr->new_addr[k] = addr;
+        if constexpr (FUSED) {
+            if (learn) {
+                const uint32_t addr = trial_addr(tr);
+                if (bitmap_set(p.bitmap, addr)) {
+                    const uint32_t k = atomicAdd(&p.ctr->learned_new, 1u);
+                    if (k < (uint32_t)kNewAddrCap) p.ctr->new_addr[k] = addr;
+                }
             }
-        } else if (learn) {
-            bitmap_set(p.bitmap, trial_addr(tr));
+        } else {
+            if (learn) bitmap_set(p.bitmap, trial_addr(tr));
         }
     }
 }
@@ -599,11 +609,12 @@ __device__ __forceinline__ bool fused_match_entry(const ScanParams &p, const uin
     return false;
 }
 
-template <bool FROM_MAG, bool SELFTEST = false, bool FUSED = false>
+template <bool FROM_MAG, bool SELFTEST = false, bool FUSED = false, bool FIELDS = false>
 __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIGNED void k_scan_fast(ScanParams p)
 {
     __shared__ FastLds s;
     __shared__ FusedLds<FUSED> fs;
+    __shared__ HitFieldLds<FIELDS> hf;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
                 const uint32_t t5 = tb + (uint32_t)lane;
                 uint32_t c, tpi;
                 split5(min(t5, ntrial - 1u), c, tpi);
-                trial_pass(p, s, cand_entry(wcand[c]), tpi, t5 < ntrial, jbase, chunk, seg, seg_cap, ap_count, lane, par);
+                trial_pass<FUSED, FIELDS>(p, s, hf, cand_entry(wcand[c]), tpi, t5 < ntrial, jbase, chunk, seg, seg_cap, ap_count, lane, par);
             }
             wave_lds_fence();  // wcand is reused by the next passes of the gates
         }
@@ -954,9 +965,8 @@ tile_end:
         } else {
             for (uint32_t i = tid; i < nhit; i += kThreads) {
                 dst[s.hit_base + i] = s.hit[i];
-#if ADSB_HIT_FIELDS
-                if (p.hit_fields) put_hit_fields(p, (size_t)(dst - (p.order_cnt ? p.order_tmp : p.hits)) + s.hit_base + i, s.hitf[i]);
-#endif
+                if constexpr (FIELDS)
+                    put_hit_fields(p, (size_t)(dst - (p.order_cnt ? p.order_tmp : p.hits)) + s.hit_base + i, hf.f[i]);
             }
         }
     }
@@ -1100,9 +1110,6 @@ inline void hip_clear() { (void)hipGetLastError(); }
 }  // namespace
 
 // persistent grid = what is resident at once (occupancy API x CUs), found once
-// whether this build's scan hands hit fields over (the host leaves ScanParams::hit_fields null otherwise)
-bool scan_writes_hit_fields() { return ADSB_HIT_FIELDS != 0; }
-
 int scan_resident_blocks()
 {
     // (a function-local static: initialised once, also when two threads create contexts at once)
@@ -1131,13 +1138,12 @@ int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream)
     hip_clear();
     const uint32_t tiles = p.n_chunks * kTilesPerChunk;  // one workgroup per tile: a pass of a few buffers
     if (tiles == 0 || !p.fused_rec) return (int)hipErrorInvalidValue;
+    // (one-launch passes always hand hit fields over: p.hit_fields is set for them)
+    if (!p.hit_fields) return (int)hipErrorInvalidValue;
     if (from_mag)
-        hipLaunchKernelGGL((k_scan_fast<true, false, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
-    else if (p.ev_start && p.ev_stop)
-        hipExtLaunchKernelGGL((k_scan_fast<false, false, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream,
-                              (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
+        hipLaunchKernelGGL((k_scan_fast<true, false, true, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((k_scan_fast<false, false, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_scan_fast<false, false, true, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 
@@ -1154,6 +1160,11 @@ int launch_scan(const ScanParams &p, bool from_mag, void *stream)
         hipLaunchKernelGGL((k_scan_fast<false, true>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     else if (from_mag)  // adsb_demodulate2400: one caller-supplied MagnitudeBuffer
         hipLaunchKernelGGL(k_scan_fast<true>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else if (p.hit_fields && p.ev_start && p.ev_stop)  // dense stream: the scan hands its hits' bit fields to the record builder
+        hipExtLaunchKernelGGL((k_scan_fast<false, false, false, true>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                              (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);
+    else if (p.hit_fields)
+        hipLaunchKernelGGL((k_scan_fast<false, false, false, true>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
     else if (p.ev_start && p.ev_stop)
         hipExtLaunchKernelGGL(k_scan_fast<false>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,
                               (hipEvent_t)p.ev_start, (hipEvent_t)p.ev_stop, 0, p);

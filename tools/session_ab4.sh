@@ -1,0 +1,16 @@
+#!/bin/bash
+T=${TAG:-s}; mkdir -p gpurun_out; O=gpurun_out/${T}_ab.log
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 >> $O
+fmt='import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("ms/step",d["ms_per_step"],"median",d["ms_per_step_median"],"kernel_alone",d["roofline"]["kernel_avg_ms"],"device",d["roofline"]["sustained"]["device_ms_per_launch"])'
+for rep in 1 2 3; do
+  for wl in sparse dense; do
+    echo -n "r3 $wl: " >> $O; ( cd variants/r3tree && timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-also --workload $wl 2>/dev/null | python -c "$fmt" ) >> $O 2>&1
+    echo -n "now $wl: " >> $O
+    timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-also --blocks 0 --workload $wl 2>/dev/null | python -c "$fmt" >> $O 2>&1
+  done
+done
+echo "== tail kernels (dense, blocking)" >> $O; ./tools/pmc_records.sh pmcrec_${T} >> $O 2>&1
+python tools/config1.py >> $O 2>&1
+python tools/hosttime.py ring --chunks 1 --depth 8 --profiling 1 >> $O 2>&1
+grep -v amdgpu $O
