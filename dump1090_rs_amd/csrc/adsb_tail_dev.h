@@ -213,7 +213,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
             // bits for a clean DF11) -- came along in hit_fields: such a hit needs no window, no slicer and no
             // CRC here, only the 33-sample power (demod_2400.rs:191-196).  A group with a hit the match found
             // (address/parity trial: flag clear) takes the whole road for all four.
-            bool from_fields = !FROM_MAG && p.hit_fields != nullptr;
+            bool from_fields = p.hit_fields != nullptr;
             size_t place[kRecGroup];
             if (from_fields) {
 #pragma unroll
@@ -235,6 +235,11 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                 for (int h = 0; h < kRecGroup; h++) {
                     fw0[h] = p.hit_fields[place[h] * kHitFieldWords + r0];
                     fw1[h] = p.hit_fields[place[h] * kHitFieldWords + r1];
+                    if constexpr (FROM_MAG) {   // caller-supplied magnitudes: data[j + 19 + lane] as it is
+                        const int d = (int)entry_j(e[h]) + 19 + lane;
+                        w[h] = d < kMagDataLen ? ((const uint16_t *)p.src)[d] : 0u;
+                        continue;
+                    }
                     // the IQ behind data[j + 19 + lane] (the range-checked resource of the full path below)
                     const uint64_t chunk = entry_chunk(e[h]);
                     const int len = chunk_len(p.n_samples, chunk);
@@ -256,7 +261,8 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                 }
 #pragma unroll
                 for (int h = 0; h < kRecGroup; h += 2) {  // two magnitudes per pass of the packed arithmetic
-                    const uint32_t m2 = mag2(w[h], h + 1 < kRecGroup ? w[h + 1] : 0u);
+                    const uint32_t m2 = FROM_MAG ? (w[h] & 0xFFFFu) | (h + 1 < kRecGroup ? w[h + 1] << 16 : 0u)
+                                                 : mag2(w[h], h + 1 < kRecGroup ? w[h + 1] : 0u);
                     const unsigned long long ma = lane < 33 ? (m2 & 0xFFFFu) : 0u, mb = lane < 33 ? (m2 >> 16) : 0u;
                     pw[h] = ma * ma;
                     if (h + 1 < kRecGroup) pw[h + 1] = mb * mb;

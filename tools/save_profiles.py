@@ -22,11 +22,14 @@ stats(R / f'gpurun_out/psync_{tag}/bench_kernel_stats.csv', R / f'profiles/{name
 for src, dst in ((f'gpurun_out/bench_{tag}.json', f'profiles/{name}_bench.json'), (f'gpurun_out/bench_sync_{tag}.json', f'profiles/{name}_sync_bench.json')):
     line = [l for l in open(R / src).read().splitlines() if l.startswith('{')][-1]
     (R / dst).write_text(line + '\n')
-for w in ('dense', 'stream', 'shard', 'gloo2', 'gloo2_shard'):  # tools/profile_all.sh
+for w in ('dense', 'stream', 'shard', 'live', 'gloo2', 'gloo2_shard', 'gloo8', 'gloo8_shard'):  # tools/profile_all.sh
     src = R / f'gpurun_out/bench_{w}_{tag}.json'
     if src.exists():
         line = [l for l in src.read_text().splitlines() if l.startswith('{')][-1]
         (R / f'profiles/{name}_{w}_bench.json').write_text(line + '\n')
+for src, dst in ((f'gpurun_out/hosttime_ring_{tag}.txt', f'profiles/{name}_hosttime_ring.txt'), (f'gpurun_out/config1_{tag}.txt', f'profiles/{name}_config1.txt')):
+    if (R / src).exists():
+        (R / dst).write_text(''.join(l for l in open(R / src) if 'amdgpu.ids' not in l))
 if (R / f'gpurun_out/pdense_{tag}/bench_kernel_stats.csv').exists():
     stats(R / f'gpurun_out/pdense_{tag}/bench_kernel_stats.csv', R / f'profiles/{name}_dense_sync_kernel_stats.csv')
 tr = json.loads([l for l in open(R / f'gpurun_out/traffic_{tag}.json').read().splitlines() if l.startswith('{')][-1])
