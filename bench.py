@@ -401,16 +401,27 @@ def parity_leg(env: Env, r, chunks: int, baseline: bool = True):
     with env.all_cores():   # (the rank itself is pinned to its GPU's NUMA node; the baseline gets the whole box)
         n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), chunks))
         if n_thr > 1:
+            # the all-core figure over FOUR repetitions of the buffer as one stream (1 GiB, 2048 buffers): one call
+            # starts its threads, faults in their scratch memory and joins them -- ~15 ms that a 256 MiB sample
+            # (4 ms of work per thread) would mostly measure.  Checked against the one-thread oracle over the
+            # same bytes (the filter persists across the repetitions, so this is not four times the same list).
+            import numpy as np
+            reps = 4
+            big = np.ascontiguousarray(np.tile(host, (reps, 1)))
+            ref = binding.Oracle(L)
+            ref.icao_flush()
+            want_big, _ = ref.demod_iq(big, cap=cap)
             orc_mt = binding.Oracle(L)
             orc_mt.icao_flush()
             orc_mt.demod_iq(host[: min(n, 16 * CHUNK)], cap=cap, threads=n_thr)  # spin the threads up once
             times = []
-            for _ in range(3):   # (a pass over the buffer is tens of milliseconds on this many threads: median of three)
+            for _ in range(3):   # (tens of milliseconds each: median of three)
                 orc_mt.icao_flush()
-                want_mt, _ = orc_mt.demod_iq(host, cap=cap, threads=n_thr, timing=times)
-                if want_mt != want:
+                want_mt, _ = orc_mt.demod_iq(big, cap=cap, threads=n_thr, timing=times)
+                if want_mt != want_big:
                     raise SystemExit("cpu_baseline: the multi-threaded oracle disagrees with the single-threaded one")
-            mt_s = _median(times)
+            mt_s = _median(times) / reps     # per 256 MiB
+            del big
     base = {
         "value": round(n / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": f"buffer 0 of the workload, all {chunks} x 131072 samples once, {cpu_s:.2f} s; "
@@ -419,10 +430,10 @@ def parity_leg(env: Env, r, chunks: int, baseline: bool = True):
     }
     if mt_s:
         base["all_cores"] = {"value": round(n / mt_s / 1e6, 2), "unit": "Msamples/s", "cores": n_thr,
-                             "sample": f"the same buffer, {n_thr} threads: workers run to_mag + gates + slicer + DF / CRC "
-                                       f"class per 131072-sample buffer, only trials that can score or add reach the "
-                                       f"serial ordered replay (oracle/dump1090_oracle_mt.c); {mt_s * 1e3:.1f} ms inside the "
-                                       "C call, median of three"}
+                             "sample": f"the same buffer four times over as one 1 GiB stream, {n_thr} threads: workers run to_mag + "
+                                       f"gates + slicer + DF / CRC class per 131072-sample buffer, only trials that can score or "
+                                       f"add reach the serial ordered replay (oracle/dump1090_oracle_mt.c); {mt_s * 4e3:.1f} ms "
+                                       "inside the C call, median of three; equal to the one-thread oracle over the same bytes"}
     if native is not None:
         try:
             os.unlink(native)
@@ -647,11 +658,16 @@ def run_stream(env: Env, chunks: int, steps: int, warmup: int, min_seconds: floa
             done += 1
         return i, frames, scan_ms
 
+    # (no collector pause inside a loop of 15 us passes: after the resident legs this process's heap is large
+    # and a full collection takes milliseconds -- the resident timed region does the same)
+    gc.collect()
+    gc.disable()
     env.fence()
     t0 = time.perf_counter()
     i, frames, scan_ms = loop(steps, min_seconds, not lean)
     env.fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if lean:
         ctx.set_profiling(1)
         k, _, ms = loop(2000, 0.0, True)
