@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
     L.adsb_selftest_stage_lists.restype = C.c_int
     L.adsb_selftest_gate_stages.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]
     L.adsb_selftest_gate_stages.restype = C.c_int
+    L.adsb_selftest_set_order_polls.argtypes = [vp, C.c_uint32]
+    L.adsb_selftest_set_order_polls.restype = C.c_int
     L.adsb_selftest_crc_table.argtypes = [vp]
     L.adsb_selftest_crc_table.restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]

@@ -144,6 +144,7 @@ struct adsb_ctx {
     hipEvent_t lazy_ev = nullptr;           // recorded on a stream at the moment somebody has to wait for a one-launch pass on it
     uint64_t last_new_insert_seq = 0;       // the latest pass whose replay put a NEW address into the filter
     uint64_t rematches = 0;                 // one-launch passes redone because a pass in flight beside them did
+    uint32_t order_polls = 200;             // ScanParams::order_polls (adsb_selftest_set_order_polls)
     hipEvent_t input_ready[kScanStreams] = {};  // per scan stream: `stream` at submit (the caller's IQ is complete)
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;

@@ -235,6 +235,8 @@ struct ScanParams {
     // one-launch pass (k_scan_fast<.., FUSED>: scan + match + records in one kernel, for passes of a few
     // buffers): where its records go (mapped host memory), else null
     TrialRecord *fused_rec;
+    uint32_t order_polls;   // ... how often a workgroup polls for the tiles before its own before it gives up
+                            // (200, ~0.2 ms; the self-test hook sets 0: every tile gives up, the second look decides)
 };
 
 

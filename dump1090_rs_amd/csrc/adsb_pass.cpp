@@ -141,6 +141,7 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     sl.fused = fused;
     sl.unsynced_from = 0;
     p.fused_rec = fused ? sl.h_rec_dev : nullptr;
+    p.order_polls = c->order_polls;
     // the scan hands the bit fields of its self-validating hits to the record builder: where the record
     // builder's instructions matter (dense streams: it shares the vector pipes with the next scan) and in
     // one-launch passes; a sparse stream's scan stays the lean instantiation

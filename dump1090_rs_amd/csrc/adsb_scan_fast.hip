@@ -1004,7 +1004,7 @@ tile_end:
                 for (uint32_t k = (uint32_t)lane; k < blockIdx.x; k += 64u)
                     all = all && __hip_atomic_load(&p.ctr->tile_done[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                 if (__all(all)) break;
-                if (spins >= 200u) {  // ~0.2 ms
+                if (spins >= p.order_polls) {  // 200: ~0.2 ms
                     ordered = false;
                     break;
                 }

@@ -167,6 +167,14 @@ int adsb_selftest_gate_stages(adsb_ctx *c, const void *d_iq, size_t n_samples, u
     return hand_out(pre, preamble, preamble_cap, n_preamble, sn, snr, snr_cap, n_snr);
 }
 
+int adsb_selftest_set_order_polls(adsb_ctx *c, uint32_t polls)
+{
+    if (!c) return ADSB_ERR_INVALID;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+    c->order_polls = polls;
+    return ADSB_OK;
+}
+
 int adsb_selftest_crc_table(uint32_t *out256)
 {
     if (!out256) return ADSB_ERR_INVALID;

@@ -101,14 +101,18 @@ typedef struct {
 /* Create a context on HIP device `device` (>= 0), sized to demodulate up to
  * `max_chunks` 131072-sample buffers per call (host-pointer calls stage through
  * a device buffer of that size; device-pointer calls only size the lists).
- * Footprint (ADSB_MAX_IN_FLIGHT = 4 passes in flight, each with its own lists):
- *   device   seven 2 MiB address bitmaps (five in rotation for the superset test, two for the
- *            device-side copy of the filter) = 14.7 MB, plus per pass in flight the address/parity
- *            list, hit lists and scoring buffers: ~1.1 MB each for max_chunks = 1 (~19 MB in all),
- *            ~84 MB each for 512 (~350 MB in all);
+ * A context created with max_chunks <= 16 is one for the reference's own call shape (one read, one
+ * demodulation, dump1090_rs/src/main.rs:161-167): each of its passes is a single kernel launch, and it
+ * keeps ADSB_MAX_IN_FLIGHT_SMALL (8) of them in flight instead of ADSB_MAX_IN_FLIGHT (4).
+ * Footprint (each pass in flight has its own lists):
+ *   device   2 MiB address bitmaps (passes in flight + 1 in rotation for the superset test, two for the
+ *            device-side copy of the filter), plus per pass in flight the address/parity list, the hit
+ *            list with the scan's bit fields per hit, and the scoring buffers: ~1.25 MB each for
+ *            max_chunks = 1 (~33 MB in all, 23 of them bitmaps), ~101 MB each for 512 (~420 MB in all);
  *   pinned host (mapped, written by the kernels)  per pass in flight 32 B per trial record
  *            (4096 + 1024 max_chunks of them) + 44 B per scored message slot (min(that, 131072)):
- *            ~1.6 MB in all for max_chunks = 1, ~90 MB for 512.
+ *            ~3 MB in all for max_chunks = 1, ~90 MB for 512; host-pointer calls of a few buffers add a
+ *            pinned staging buffer of their size.
  * Input denser than the lists are sized for (several times a busy airspace) is still
  * demodulated exactly, buffer by buffer through worst-case lists allocated on first use
  * (another 10 MB of device and 20 MB of pinned memory; stats.retries). */
@@ -284,6 +288,13 @@ int adsb_selftest_stage_lists(adsb_ctx *ctx, const void *device_iq_re_im, size_t
  * ADSB_ERR_HIP if the two ever disagree.  Same conventions as adsb_selftest_stage_lists. */
 int adsb_selftest_gate_stages(adsb_ctx *ctx, const void *device_iq_re_im, size_t n_samples, uint64_t *preamble,
                               size_t preamble_cap, size_t *n_preamble, uint64_t *snr, size_t snr_cap, size_t *n_snr);
+
+/* Test hook for the one-launch pass (passes of at most 16 buffers): inside such a pass a workgroup matches
+ * its address/parity trials once every tile before its own has published its address bits, and waits for
+ * that at most `polls` polls (200 by default, ~0.2 ms); a workgroup that gives up leaves the decision to a
+ * second look by the pass's last workgroup.  0 makes every workgroup give up at once, so that a test can
+ * run the second look on purpose; results never depend on the value.  ADSB_ERR_BUSY while passes are pending. */
+int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
 
 /* The 256-entry CRC-24 table the host replay scores with (src/crc.rs:3-260 CRC_TABLE): for the test that
  * pins it against the reference's constants.  Host only, no context. */

@@ -92,6 +92,7 @@ unsafe extern "C" {
     pub fn adsb_selftest_mag_digest(ctx: *mut AdsbCtx, first_bits: u32, count: u32, sum_out: *mut u64, xor_out: *mut u64) -> c_int;
     pub fn adsb_selftest_stage_lists(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, cand: *mut u64, cand_cap: usize, n_cand: *mut usize, ap: *mut u64, ap_cap: usize, n_ap: *mut usize) -> c_int;
     pub fn adsb_selftest_gate_stages(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, preamble: *mut u64, preamble_cap: usize, n_preamble: *mut usize, snr: *mut u64, snr_cap: usize, n_snr: *mut usize) -> c_int;
+    pub fn adsb_selftest_set_order_polls(ctx: *mut AdsbCtx, polls: u32) -> c_int;
     pub fn adsb_selftest_crc_table(out256: *mut u32) -> c_int;
     pub fn adsb_get_stats(ctx: *const AdsbCtx, out: *mut AdsbStats) -> c_int;
     pub fn adsb_host_sorts(ctx: *const AdsbCtx) -> u64;

@@ -25,7 +25,7 @@
  * the result is identical to orc_demod_iq on one thread (tests/test_oracle_golden.py checks
  * that on the reference captures and on synthetic IQ, bench.py on every run).
  *
- * The capture is processed in rounds of threads * 8 buffers: classify (parallel), barrier,
+ * The capture is processed in rounds of threads * 4 buffers: classify (parallel), barrier,
  * keep / drop the address/parity trials (parallel), barrier, replay (serial, microseconds).
  */
 #define _POSIX_C_SOURCE 200809L /* pthread barriers under -std=c11 */
@@ -33,13 +33,23 @@
 
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 typedef struct {
     orc_trial *trials; /* kept trials of the buffer, (j, try_phase) ascending; pad: 1 = address/parity */
     uint32_t *residual; /* ... and their CRC residual */
     size_t n, sliced;   /* kept; all trials the buffer sliced (statistics) */
+    int owned;          /* malloc'ed for this buffer (the round's slab was full), else a piece of the slab */
 } chunk_result;
 
 typedef struct {
@@ -49,6 +59,13 @@ typedef struct {
     size_t round_first, round_n;
     atomic_size_t next1, next2; /* work counters of the two parallel phases */
     _Atomic uint32_t *seen;     /* 2^24 bits: addresses the filter may hold (superset in time) */
+    /* one slab for the kept trials of a round, handed out with an atomic bump: 256 threads that each malloc
+     * and free ~125 KB per buffer spend their time in the allocator's mprotect calls (a write lock on the
+     * process's address space that every page fault of every thread then waits for) */
+    orc_trial *slab;
+    uint32_t *slab_res;
+    size_t slab_cap;
+    atomic_size_t slab_used;
     pthread_barrier_t bar;
     atomic_int failed, quit;
 } mt_job;
@@ -64,7 +81,8 @@ static inline int seen_test(const mt_job *job, uint32_t addr)
 }
 
 /* phase 1: one buffer -> its candidate trials */
-static void classify_chunk(mt_job *job, size_t c, orc_magbuf *mb, orc_trial **scratch, size_t *scratch_cap)
+static void classify_chunk(mt_job *job, size_t c, orc_magbuf *mb, orc_trial **scratch, size_t *scratch_cap,
+                           uint32_t **res_tmp, size_t *res_cap)
 {
     chunk_result *r = &job->res[c - job->round_first];
     const size_t off = c * (size_t)ORC_MODES_MAG_BUF_SAMPLES;
@@ -88,11 +106,17 @@ static void classify_chunk(mt_job *job, size_t c, orc_magbuf *mb, orc_trial **sc
     /* in place: kept trials move to the front, order preserved */
     orc_trial *t = *scratch;
     size_t keep = 0;
-    uint32_t *res = (uint32_t *)malloc((got ? got : 1) * sizeof(uint32_t));
-    if (!res) {
-        atomic_store(&job->failed, 1);
-        return;
+    if (got > *res_cap) {
+        free(*res_tmp);
+        *res_cap = got;
+        *res_tmp = (uint32_t *)malloc(got * sizeof(uint32_t));
+        if (!*res_tmp) {
+            *res_cap = 0;
+            atomic_store(&job->failed, 1);
+            return;
+        }
     }
+    uint32_t *res = *res_tmp;
     for (size_t i = 0; i < got; i++) {
         const uint8_t *m = t[i].msg;
         const unsigned df = m[0] >> 3;                       /* mod.rs:41 */
@@ -131,14 +155,22 @@ static void classify_chunk(mt_job *job, size_t c, orc_magbuf *mb, orc_trial **sc
         res[keep] = crc;
         keep++;
     }
-    r->trials = (orc_trial *)malloc((keep ? keep : 1) * sizeof(orc_trial));
-    if (!r->trials) {
-        free(res);
-        atomic_store(&job->failed, 1);
-        return;
+    const size_t at = atomic_fetch_add(&job->slab_used, keep);
+    if (at + keep <= job->slab_cap) {
+        r->trials = job->slab + at;
+        r->residual = job->slab_res + at;
+        r->owned = 0;
+    } else { /* a round far denser than the slab was sized for */
+        r->trials = (orc_trial *)malloc((keep ? keep : 1) * sizeof(orc_trial));
+        r->residual = (uint32_t *)malloc((keep ? keep : 1) * sizeof(uint32_t));
+        r->owned = 1;
+        if (!r->trials || !r->residual) {
+            atomic_store(&job->failed, 1);
+            return;
+        }
     }
     memcpy(r->trials, t, keep * sizeof(orc_trial));
-    r->residual = res;
+    memcpy(r->residual, res, keep * sizeof(uint32_t));
     r->n = keep;
 }
 
@@ -162,9 +194,10 @@ static void *worker(void *arg)
 {
     mt_job *job = (mt_job *)arg;
     orc_magbuf *mb = (orc_magbuf *)malloc(sizeof(orc_magbuf));
-    size_t scratch_cap = 16384;
+    size_t scratch_cap = 16384, res_cap = 16384;
     orc_trial *scratch = (orc_trial *)malloc(scratch_cap * sizeof(orc_trial));
-    if (!mb || !scratch)
+    uint32_t *res_tmp = (uint32_t *)malloc(res_cap * sizeof(uint32_t));
+    if (!mb || !scratch || !res_tmp)
         atomic_store(&job->failed, 1);
     for (;;) {
         pthread_barrier_wait(&job->bar); /* round start (the caller has set it up) */
@@ -175,7 +208,7 @@ static void *worker(void *arg)
             if (k >= job->round_n)
                 break;
             if (!atomic_load(&job->failed))
-                classify_chunk(job, job->round_first + k, mb, &scratch, &scratch_cap);
+                classify_chunk(job, job->round_first + k, mb, &scratch, &scratch_cap, &res_tmp, &res_cap);
         }
         pthread_barrier_wait(&job->bar); /* every address of the round is in the set */
         for (;;) {
@@ -187,6 +220,7 @@ static void *worker(void *arg)
         }
         pthread_barrier_wait(&job->bar); /* the caller replays */
     }
+    free(res_tmp);
     free(scratch);
     free(mb);
     return NULL;
@@ -245,14 +279,20 @@ size_t orc_demod_iq_mt(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
         return 0;
     if ((size_t)threads > job.n_chunks)
         threads = (int)job.n_chunks;
-    const size_t round_max = (size_t)threads * 8;
+    const size_t round_max = (size_t)threads * 4 < job.n_chunks ? (size_t)threads * 4 : job.n_chunks;
     job.res = (chunk_result *)calloc(round_max, sizeof(chunk_result));
+    job.slab_cap = round_max * 4096; /* noise keeps ~3 200 of a buffer's ~7 000 trials until the round's addresses are known */
+    job.slab = (orc_trial *)malloc(job.slab_cap * sizeof(orc_trial));
+    job.slab_res = (uint32_t *)malloc(job.slab_cap * sizeof(uint32_t));
     job.seen = (_Atomic uint32_t *)calloc(1u << 19, sizeof(uint32_t));
     pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
-    if (!job.res || !job.seen || !th || pthread_barrier_init(&job.bar, NULL, (unsigned)threads + 1) != 0) {
+    if (!job.res || !job.seen || !th || !job.slab || !job.slab_res ||
+        pthread_barrier_init(&job.bar, NULL, (unsigned)threads + 1) != 0) {
         free(job.res);
         free((void *)job.seen);
         free(th);
+        free(job.slab);
+        free(job.slab_res);
         return 0;
     }
     /* what the filter holds on entry can match from the first sample on; 0 always tests true */
@@ -271,10 +311,16 @@ size_t orc_demod_iq_mt(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
             job.round_n = job.n_chunks - first < round_max ? job.n_chunks - first : round_max;
             atomic_store(&job.next1, 0);
             atomic_store(&job.next2, 0);
+            atomic_store(&job.slab_used, 0);
             memset(job.res, 0, round_max * sizeof(chunk_result));
+            const double t0 = now_s();
             pthread_barrier_wait(&job.bar); /* start */
             pthread_barrier_wait(&job.bar); /* classified */
+            const double t1 = now_s();
             pthread_barrier_wait(&job.bar); /* filtered */
+            const double t2 = now_s();
+            size_t kept = 0;
+            for (size_t k = 0; k < job.round_n; k++) kept += job.res[k].n;
             for (size_t k = 0; k < job.round_n; k++) {
                 chunk_result *r = &job.res[k];
                 if (!atomic_load(&job.failed)) {
@@ -286,9 +332,14 @@ size_t orc_demod_iq_mt(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
                         stats->quiet_pass += r->sliced / 5;
                     }
                 }
-                free(r->trials);
-                free(r->residual);
+                if (r->owned) {
+                    free(r->trials);
+                    free(r->residual);
+                }
             }
+            if (getenv("ORC_MT_TIMES")) /* (diagnostic: where a round's time goes) */
+                fprintf(stderr, "orc_demod_iq_mt: round of %zu buffers: classify %.1f ms, filter %.1f ms, replay of %zu trials %.1f ms\n",
+                        job.round_n, 1e3 * (t1 - t0), 1e3 * (t2 - t1), kept, 1e3 * (now_s() - t2));
         }
         atomic_store(&job.quit, 1);
         pthread_barrier_wait(&job.bar);
@@ -307,5 +358,7 @@ size_t orc_demod_iq_mt(orc_filter *f, const int16_t *iq_re_im, size_t n_samples,
     free(th);
     free(job.res);
     free((void *)job.seen);
+    free(job.slab);
+    free(job.slab_res);
     return failed ? 0 : found;
 }

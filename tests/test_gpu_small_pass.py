@@ -121,20 +121,24 @@ def test_address_taught_early_in_a_buffer_reaches_a_frame_late_in_it_and_not_the
     d_fwd, d_rev = torch.from_numpy(fwd).cuda(), torch.from_numpy(rev).cuda()
     torch.cuda.synchronize()
     with Context(0, 1) as c:
-        for rep in range(100):
-            c.icao_flush()
-            assert [key(m) for m in c.demod_iq_device(d_fwd.data_ptr(), CHUNK)] == [want_key(w) for w in w_fwd]
-            c.icao_flush()
-            assert [key(m) for m in c.demod_iq_device(d_rev.data_ptr(), CHUNK)] == [want_key(w) for w in w_rev]
-        for rep in range(50):   # pipelined, a flush in front of each: four one-launch passes in flight
-            for d in (d_fwd, d_rev, d_fwd, d_rev):
+        # polls = 0: no workgroup waits for the tiles before it (adsb_selftest_set_order_polls), so whenever the
+        # pass learns an address its last workgroup looks at every list once more -- the fallback, on purpose
+        for polls in (200, 0):
+            assert c._L.adsb_selftest_set_order_polls(c._h, polls) == 0
+            for rep in range(100):
                 c.icao_flush()
-                c.submit_iq_device(d.data_ptr(), CHUNK)
-            for w in (w_fwd, w_rev, w_fwd, w_rev):
-                assert [key(m) for m in c.collect()] == [want_key(x) for x in w]
-        # caller-supplied magnitudes take the same one-launch form (adsb_demodulate2400)
-        c.icao_flush()
-        assert [key(m) for m in c.demodulate2400(c.to_mag(fwd))] == [want_key(w) for w in w_fwd]
+                assert [key(m) for m in c.demod_iq_device(d_fwd.data_ptr(), CHUNK)] == [want_key(w) for w in w_fwd]
+                c.icao_flush()
+                assert [key(m) for m in c.demod_iq_device(d_rev.data_ptr(), CHUNK)] == [want_key(w) for w in w_rev]
+            for rep in range(50):   # pipelined, a flush in front of each: four one-launch passes in flight
+                for d in (d_fwd, d_rev, d_fwd, d_rev):
+                    c.icao_flush()
+                    c.submit_iq_device(d.data_ptr(), CHUNK)
+                for w in (w_fwd, w_rev, w_fwd, w_rev):
+                    assert [key(m) for m in c.collect()] == [want_key(x) for x in w]
+            # caller-supplied magnitudes take the same one-launch form (adsb_demodulate2400)
+            c.icao_flush()
+            assert [key(m) for m in c.demodulate2400(c.to_mag(fwd))] == [want_key(w) for w in w_fwd]
 
 
 @pytest.mark.parametrize("n_chunks,cut", [(1, 0), (1, 50000), (2, 131071), (5, 4321), (16, 0), (16, 99), (17, 0), (17, 5000)])
