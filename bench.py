@@ -33,6 +33,14 @@ import sys
 import time
 from pathlib import Path
 
+# The HIP runtime gives streams hardware queues from pools of GPU_MAX_HW_QUEUES (4 by default) per priority;
+# streams beyond that share a queue, i.e. run one after the other.  This process runs a 512-buffer context
+# (two high-priority scan streams) AND contexts for one-buffer passes (four) side by side -- the `also` legs --,
+# six in all: with the default two of them share (the one-buffer ring: 6.9 instead of 8.8-9.0 Gsample/s;
+# dump1090_rs_amd/csrc/adsb_context.cpp).  A process with one kind of context needs nothing.  Must be in the
+# environment before the runtime starts (torch is imported later); a value already set is left alone.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
@@ -527,6 +535,7 @@ def resident_result(env: Env, args, r, workload: str):
             "kernels": "k_scan_fast (mag + sign planes + preamble + gates + trial syndromes) -> k_match -> "
                        "k_order_prefix -> k_records (bucket sort) -> host replay, or k_score -> k_emit on dense streams",
             "library": library,
+            "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "host_affinity": env.affinity_summary(),
             "clock_ramp": {**r["ramp"], "what": "untimed passes of this workload before the W warm-up steps, until the "
                            "GPU holds its clocks under the load (bench.py: clock_ramp); ms_per_step_cold = the first 20 "

@@ -17,16 +17,19 @@ extern "C" {
 // same streams keeps every context of a process on the queues the first one got.
 struct StreamSet {
     int device = -1;
+    int n_scan = 2;   // sets of contexts for passes of a few buffers (four scan streams) and of large contexts
+                      // (two) are kept apart: a large context's set extended by two streams created later did not
+                      // behave like four created in a row (the one-buffer ring: 6.9 instead of 8.8 Gsample/s)
     hipStream_t own = nullptr, scan[kScanStreams] = {}, tail = nullptr, score = nullptr, copy = nullptr;
 };
 std::mutex g_stream_pool_mu;
 std::vector<StreamSet> g_stream_pool;
 
-bool take_stream_set(int device, StreamSet &out)
+bool take_stream_set(int device, int n_scan, StreamSet &out)
 {
     std::lock_guard<std::mutex> lk(g_stream_pool_mu);
     for (size_t i = 0; i < g_stream_pool.size(); i++)
-        if (g_stream_pool[i].device == device) {
+        if (g_stream_pool[i].device == device && g_stream_pool[i].n_scan == n_scan) {
             out = g_stream_pool[i];
             g_stream_pool.erase(g_stream_pool.begin() + (long)i);
             return true;
@@ -34,6 +37,13 @@ bool take_stream_set(int device, StreamSet &out)
     return false;
 }
 
+// The runtime multiplexes streams onto hardware queues: GPU_MAX_HW_QUEUES (4 by default) per priority, and
+// streams beyond that SHARE queues, i.e. run one after the other.  A process with one kind of context stays
+// within four high-priority streams (two scan streams, or four).  A process that mixes a large context with
+// contexts for passes of a few buffers has six, and two of them share: measured (tools/ring_history_probe.py),
+// the one-buffer ring then runs at 6.8 instead of 8.8 Gsample/s when the large context's streams were used
+// first, and the large stream at 0.129 instead of 0.097 ms per step when the small ones were.  Such a
+// process sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (bench.py does): then nothing shares.
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
 {
     if (!out) return ADSB_ERR_INVALID;
@@ -72,16 +82,10 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     auto body = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
         StreamSet pooled;
-        const bool reuse = !tuning_env("ADSB_STREAM_PRIO") && !tuning_env("ADSB_SCORE_PRIO") && take_stream_set(device, pooled);
+        const bool reuse = !tuning_env("ADSB_STREAM_PRIO") && !tuning_env("ADSB_SCORE_PRIO") && take_stream_set(device, c->n_scan_streams, pooled);
         if (reuse) {
             c->own_stream = pooled.own;
             for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = pooled.scan[k];
-            for (int k = 2; k < c->n_scan_streams; k++)   // (the set comes from a context that had two)
-                if (!c->scan_stream[k]) {
-                    int least = 0, greatest = 0;
-                    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                    HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[k], hipStreamNonBlocking, greatest));
-                }
             c->tail_stream = pooled.tail;
             c->score_stream = pooled.score;
             c->copy_stream_spare = pooled.copy;
@@ -372,11 +376,12 @@ void adsb_destroy(adsb_ctx *c)
         // its streams are simply destroyed)
         StreamSet set;
         set.device = c->device;
+        set.n_scan = c->n_scan_streams;
         set.own = c->own_stream;
         bool all_scan = true;
         for (int k = 0; k < kScanStreams; k++) {
             set.scan[k] = c->scan_stream[k];
-            all_scan = all_scan && (set.scan[k] || k >= 2);   // (a large context has two)
+            all_scan = all_scan && (set.scan[k] || k >= c->n_scan_streams);
         }
         set.tail = c->tail_stream;
         set.score = c->score_stream;
