@@ -144,6 +144,18 @@ int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size
     return ADSB_ERR_HIP;
 }
 
+// The summary is ten separate posted writes with the sequence word issued last; a host that polls for it
+// takes the summary only when its own checksum covers what it reads (a word that overtook its neighbours
+// on the way would otherwise pair this pass's sequence number with the previous pass's counts).
+static bool summary_landed(const Summary *s, uint32_t seq)
+{
+    if (__atomic_load_n(&s->seq, __ATOMIC_ACQUIRE) != seq) return false;
+    uint32_t w[10];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(s);
+    for (int k = 0; k < 10; k++) w[k] = __atomic_load_n(&src[k], __ATOMIC_RELAXED);
+    return w[7] == seq && summary_check(w) == w[9];
+}
+
 // Wait for the pass in `sl` and replay it.  Returns 1 when a device list overflowed
 // (caller re-runs in smaller pieces), 0 on success, < 0 on error.
 int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out)
@@ -160,7 +172,7 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
             const auto t0 = std::chrono::steady_clock::now();
             bool seen = false;
             for (uint32_t spin = 0; !seen; spin++) {
-                seen = __atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) == sl.seq;
+                seen = summary_landed(sl.h_sum, sl.seq);
                 if (seen) break;
                 __builtin_ia32_pause();
                 if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
@@ -173,9 +185,18 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
 #ifdef ADSB_TUNING
     c->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
 #endif
-    if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
-        c->last_error = "pass completed without publishing its summary";
-        return ADSB_ERR_HIP;
+    {
+        // (behind an event or a stream synchronisation every word has landed; the retries are for the
+        // polled case that fell through to the stream wait with the last words still on their way)
+        bool whole = false;
+        for (int attempt = 0; attempt < 200 && !whole; attempt++) {
+            whole = summary_landed(sl.h_sum, sl.seq);
+            if (!whole) for (volatile int spin = 0; spin < 2000; spin++) {}
+        }
+        if (!whole) {
+            c->last_error = "pass completed without publishing a whole summary";
+            return ADSB_ERR_HIP;
+        }
     }
     if (sl.h_sum->overflow) return 1;
     // A one-launch pass did not wait for the passes that were in flight on the other scan stream.  If one

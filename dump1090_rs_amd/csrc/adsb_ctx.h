@@ -145,6 +145,7 @@ struct adsb_ctx {
     uint64_t last_new_insert_seq = 0;       // the latest pass whose replay put a NEW address into the filter
     uint64_t rematches = 0;                 // one-launch passes redone because a pass in flight beside them did
     uint32_t order_polls = 200;             // ScanParams::order_polls (adsb_selftest_set_order_polls)
+    const unsigned long long *next_src_ready = nullptr;  // ScanParams::src_ready of the next pass enqueued (adsb_demod_iq)
     hipEvent_t input_ready[kScanStreams] = {};  // per scan stream: `stream` at submit (the caller's IQ is complete)
     uint32_t *d_tables = nullptr;
     uint32_t hits_cap = 0, ap_cap = 0, seg_cap = 0;
@@ -272,6 +273,7 @@ int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp);
 // pinned memory the caller has filled); null: wherever `stream` stands now.  no_fuse: three launches even
 // for a pass of a few buffers.
 inline hipEvent_t input_ready_now() { return reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(1)); }
+bool one_launch_pass(const adsb_ctx *c, uint32_t n_chunks);
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples, uint32_t n_chunks,
                  bool inline_tail = false, bool lead_from_src = false, bool advance_carry = true,
                  bool force_simple = false, hipEvent_t input_done = nullptr, bool no_fuse = false);

@@ -129,8 +129,17 @@ struct Summary {
     uint32_t seq;           // the pass's sequence number (never 0): lets the host check it reads its own pass
     uint32_t ticks;         // one-launch pass: its duration on the device's 100 MHz wall clock, first workgroup's
                             // entry to the summary (written before seq): the launch needs no timing events
-    uint32_t pad;
+    uint32_t check;         // summary_check() of the nine words above: the ten words are separate posted writes,
+                            // and a host that polls `seq` must not pair it with a neighbour that has not landed
 };
+
+// The summary's own checksum: each word rotated by its index (a swap of two words changes it), folded.
+__host__ __device__ inline uint32_t summary_check(const uint32_t w[9])
+{
+    uint32_t x = 0xA5D5B17Cu;
+    for (int k = 0; k < 9; k++) x ^= (w[k] << (k + 1)) | (w[k] >> (31 - k));
+    return x;
+}
 
 // GF(2) tables, 256 u32 each (adsb_tables.h): F'0 F'1 F'2 | X56_0..2
 constexpr int kTabF = 0, kTabX56 = 3, kTabCount = 6;
@@ -235,6 +244,9 @@ struct ScanParams {
     // one-launch pass (k_scan_fast<.., FUSED>: scan + match + records in one kernel, for passes of a few
     // buffers): where its records go (mapped host memory), else null
     TrialRecord *fused_rec;
+    // ... a host-pointer call copies its samples into pinned memory WHILE the launch is on its way: how many
+    // samples of src are there so far (a word in mapped host memory the copying thread advances; null: all)
+    const unsigned long long *src_ready;
     uint32_t order_polls;   // ... how often a workgroup polls for the tiles before its own before it gives up
                             // (200, ~0.2 ms; the self-test hook sets 0: every tile gives up, the second look decides)
 };

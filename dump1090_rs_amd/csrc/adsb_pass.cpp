@@ -48,6 +48,13 @@ int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other)
 
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
+// Whether a plain pass of n_chunks buffers submitted now goes out as one launch.
+bool one_launch_pass(const adsb_ctx *c, uint32_t n_chunks)
+{
+    static const bool never_fuse = tuning_env("ADSB_NO_FUSE") != nullptr;
+    return !never_fuse && c->profiling <= 1 && n_chunks <= (uint32_t)kInlineTailChunks;
+}
+
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
                  uint32_t n_chunks, bool inline_tail, bool lead_from_src,
                  bool advance_carry, bool force_simple, hipEvent_t input_done, bool no_fuse)
@@ -136,12 +143,13 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     // A pass of a few buffers is all launch overhead and event traffic: it goes out as ONE launch whose
     // last workgroup matches, builds the records and publishes the summary (k_scan_fast<.., FUSED>), with
     // no event behind it.  (Level-2 profiling wants the three kernels apart.)
-    static const bool never_fuse = tuning_env("ADSB_NO_FUSE") != nullptr;
-    const bool fused = !force_simple && !no_fuse && !never_fuse && prof <= 1 && n_chunks <= kInlineTailChunks;
+    const bool fused = !force_simple && !no_fuse && one_launch_pass(c, n_chunks);
     sl.fused = fused;
     sl.unsynced_from = 0;
     p.fused_rec = fused ? sl.h_rec_dev : nullptr;
     p.order_polls = c->order_polls;
+    p.src_ready = fused && !from_mag ? c->next_src_ready : nullptr;
+    c->next_src_ready = nullptr;
     // the scan hands the bit fields of its self-validating hits to the record builder: where the record
     // builder's instructions matter (dense streams: it shares the vector pipes with the next scan) and in
     // one-launch passes; a sparse stream's scan stays the lean instantiation
@@ -547,9 +555,36 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
     // 131072-sample buffer) is one launch that reads the samples in place from pinned host memory: one
     // host copy into it instead of a copy command, its staging inside the runtime and an event.
     const bool in_place = n_samples <= (size_t)kInlineTailChunks * kChunkSamples && !c->carry_over;
-    int rc = in_place ? ensure_host_stage(c, std::max<size_t>(n_samples, 1) * 4)
+    int rc = in_place ? ensure_host_stage(c, std::max<size_t>(n_samples, 1) * 4 + 512)   // (+ the progress word)
                       : ensure_stage(c, std::min(piece, std::max<size_t>(n_samples, 1)) * 4);
     if (rc) return rc;
+    if (in_place && n_samples && n_samples <= piece &&
+        one_launch_pass(c, (uint32_t)((n_samples + kChunkSamples - 1) / kChunkSamples))) {
+        // One pass of one launch: launch it FIRST and copy the samples into the pinned buffer while the launch is on its way
+        // (dispatch latency ~5 us, the copy ~10): each workgroup waits for the host's progress word to pass the
+        // end of its tile (ScanParams::src_ready), so the copy and the first tiles overlap instead of adding up.
+        const size_t ready_off = (n_samples * 4 + 255) & ~(size_t)255;
+        if (int rc2 = ensure_host_stage(c, ready_off + 64)) return rc2;
+        unsigned long long *ready = reinterpret_cast<unsigned long long *>((char *)c->h_stage + ready_off);
+        __atomic_store_n(ready, 0ull, __ATOMIC_RELEASE);
+        if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+        c->next_src_ready = reinterpret_cast<const unsigned long long *>((char *)c->h_stage_dev + ready_off);
+        rc = submit(c, c->h_stage_dev, false, n_samples, true, input_ready_now());
+        c->next_src_ready = nullptr;
+        // (whatever submit said, the copy is finished before anything else: a pass that was launched reads it)
+        constexpr size_t kStep = 16384;   // samples per progress update: 64 KB, two tiles
+        for (size_t done = 0; done < n_samples;) {
+            const size_t k = std::min(kStep, n_samples - done);
+            std::memcpy((char *)c->h_stage + done * 4, iq + 2 * done, k * 4);
+            done += k;
+            __atomic_store_n(ready, (unsigned long long)done, __ATOMIC_RELEASE);
+        }
+        if (rc) return rc;
+        rc = collect_next(c, msgs);
+        if (rc) return rc;
+        c->stats.n_samples = n_samples;
+        return deliver(c, msgs, out, cap, n_out);
+    }
     if (in_place && n_samples) {
         std::memcpy(c->h_stage, iq, n_samples * 4);
         for (size_t off = 0; off < n_samples; off += piece) {

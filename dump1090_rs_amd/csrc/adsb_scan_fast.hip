@@ -661,6 +661,28 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
         t_end = ((x + 1u) * n_tiles) >> 3;
         t_stride = gridDim.x >> 3;
     }
+    if constexpr (FUSED && !FROM_MAG) {
+        // The samples may still be on their way into the pinned buffer (adsb_demod_iq copies them there while this
+        // launch travels to the device): wait until the host has copied what this tile reads.  One thread polls
+        // the host's word over the link (~1.5 us a poll; the whole copy is ~10 us); bounded -- a host that never
+        // finishes is reported as an overflow, and the pass is redone once the call has all its samples.
+        if (p.src_ready != nullptr && t_first < t_end) {
+            const TileRef r0 = tile_ref<FROM_MAG>(p, t_first);
+            const long long last = min((long long)r0.len, (long long)r0.jbase - kPad - kLead + kAllocSlots);
+            const unsigned long long need = (unsigned long long)r0.chunk * kChunkSamples + (unsigned long long)max(last, 0ll);
+            if (tid == 0) {
+                uint32_t polls = 0;
+                while (__hip_atomic_load(p.src_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+                    if (++polls > 40000u) {   // tens of milliseconds
+                        atomicOr(&p.ctr->overflow, 32u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
+    }
     if (t_first < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t_first), tid, pre);
 
     // Workgroups that share a CU start a fraction of a tile period apart, so that the

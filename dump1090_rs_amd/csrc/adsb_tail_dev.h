@@ -476,11 +476,13 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
             // how long the launch took, on the device's own clock (its first workgroup's entry to here)
             const unsigned long long t0 = (unsigned long long)__hip_atomic_load(&p.ctr->t_start[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32 |
                                           __hip_atomic_load(&p.ctr->t_start[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            host_store32(sm + 8, (uint32_t)((unsigned long long)wall_clock64() - t0));
-            const uint32_t vals[8] = {n_hits_now, ovf, (uint32_t)rs, p.ctr->n_dap,
-                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq};
+            const uint32_t vals[9] = {n_hits_now, ovf, (uint32_t)rs, p.ctr->n_dap,
+                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq,
+                                      (uint32_t)((unsigned long long)wall_clock64() - t0)};
+            host_store32(sm + 9, summary_check(vals));
+            host_store32(sm + 8, vals[8]);
 #pragma unroll
-            for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
+            for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);  // seq last
         }
         __syncthreads();
         // the counters this pass touched back to zero (the rest of the block never left it)
@@ -541,10 +543,12 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                 p.score.state->scored = ok ? 1u : 0u;
             }
             const unsigned long long rs = atomicAdd((unsigned long long *)p.ctr->rec_sum, 0ull);
-            const uint32_t vals[8] = {p.ctr->n_hits, p.ctr->overflow, (uint32_t)rs, p.ctr->n_dap,
-                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq};
+            const uint32_t vals[9] = {p.ctr->n_hits, p.ctr->overflow, (uint32_t)rs, p.ctr->n_dap,
+                                      ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq, 0u};
+            host_store32(sm + 9, summary_check(vals));
+            host_store32(sm + 8, 0u);
 #pragma unroll
-            for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
+            for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);  // seq last
         }
     }
     __syncthreads();

@@ -813,6 +813,7 @@ def test_submit_collect_matches_blocking_calls_and_orders_flushes(ctx, oracle_mo
     ctx.submit_iq_device(bufs[1].data_ptr(), n)
     assert ctx.pending() == 2
     spare = torch.zeros(4 * 131072, dtype=torch.int32, device="cuda")   # ADSB_MAX_IN_FLIGHT = 4
+    torch.cuda.synchronize()   # (torch fills it on ITS stream: the library's streams do not wait for that one)
     ctx.submit_iq_device(spare.data_ptr(), 131072)
     ctx.submit_iq_device(spare.data_ptr(), 131072)
     with pytest.raises(AdsbError) as ei:                      # a fifth one does not fit
@@ -1465,6 +1466,7 @@ def test_abi_misuse_is_refused_not_crashed(hip_lib):
     n = C.c_size_t()
     out = (AdsbMsg * 16)()
     dev = torch.zeros((3 * 131072, 2), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
     ptr = dev.data_ptr()
     INVALID, BUSY, CAPACITY = -1, -7, -5
     assert L.adsb_demod_iq_device(h, None, 100, out, 16, C.byref(n)) == INVALID
