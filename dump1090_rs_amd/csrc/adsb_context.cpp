@@ -20,7 +20,7 @@ struct StreamSet {
     int n_scan = 2;   // sets of contexts for passes of a few buffers (four scan streams) and of large contexts
                       // (two) are kept apart: a large context's set extended by two streams created later did not
                       // behave like four created in a row (the one-buffer ring: 6.9 instead of 8.8 Gsample/s)
-    hipStream_t own = nullptr, scan[kScanStreams] = {}, tail = nullptr, score = nullptr, copy = nullptr;
+    hipStream_t own = nullptr, scan[kScanStreams] = {}, tail = nullptr, score = nullptr;
 };
 std::mutex g_stream_pool_mu;
 std::vector<StreamSet> g_stream_pool;
@@ -88,7 +88,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = pooled.scan[k];
             c->tail_stream = pooled.tail;
             c->score_stream = pooled.score;
-            c->copy_stream_spare = pooled.copy;
         } else {
             HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         }
@@ -252,7 +251,7 @@ void adsb_destroy(adsb_ctx *c)
                      (unsigned long long)c->collected, 1e6 * c->t_enqueue / (c->collected ? c->collected : 1),
                      1e6 * c->t_wait / (c->collected ? c->collected : 1), 1e6 * c->t_replay / (c->collected ? c->collected : 1));
     if (tuning_env("ADSB_HOST_TIMES")) {
-        static const char *name[HT_COUNT] = {"ring: hipMemcpyAsync", "ring: event record (copied)", "input-ready record + wait",
+        static const char *name[HT_COUNT] = {"ring: hipMemcpyAsync", "ring: (unused)", "input-ready record + wait",
                                              "scan launch", "scanned record + waits", "match (+ order) launch", "records launch",
                                              "recorded / done records", "collect: wait for the pass", "collect: record checksum",
                                              "collect: replay"};
@@ -313,13 +312,11 @@ void adsb_destroy(adsb_ctx *c)
     if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &r : c->ring) {
-        if (r.copied) (void)hipEventDestroy(r.copied);
         if (r.h_iq) (void)hipHostFree(r.h_iq);
         if (r.d_iq) (void)hipFree(r.d_iq);
     }
     if (c->d_addrs) (void)hipFree(c->d_addrs);
     if (c->d_carry_next) (void)hipFree(c->d_carry_next);
-    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->d_timeline && tuning_env("ADSB_TIMELINE") && std::atoi(tuning_env("ADSB_TIMELINE")) == 3) {
         // profiling aid: the stamps of the last one-launch pass (100 MHz wall clock)
         unsigned long long t[10] = {};
@@ -385,12 +382,11 @@ void adsb_destroy(adsb_ctx *c)
         }
         set.tail = c->tail_stream;
         set.score = c->score_stream;
-        set.copy = c->copy_stream ? c->copy_stream : c->copy_stream_spare;
         if (set.own && all_scan && set.tail && set.score) {
             std::lock_guard<std::mutex> lk(g_stream_pool_mu);
             g_stream_pool.push_back(set);
         } else {
-            for (hipStream_t q : {set.own, set.tail, set.score, set.copy})
+            for (hipStream_t q : {set.own, set.tail, set.score})
                 if (q) (void)hipStreamDestroy(q);
             for (hipStream_t q : set.scan)
                 if (q) (void)hipStreamDestroy(q);

@@ -175,18 +175,15 @@ struct adsb_ctx {
     bool dense_mode = false;
     uint32_t next_seq = 1;
 
-    // streaming ring (adsb_ring_*): per slot a pinned host buffer the caller fills and a
-    // device staging buffer; the H2D copy of one slot runs on its own stream while the
-    // other slot's pass computes
+    // streaming ring (adsb_ring_*): per slot a pinned host buffer the caller fills and a device staging
+    // buffer; a slot is read in place by its pass or copied on that pass's scan stream in front of it
+    // (adsb_ring.cpp: adsb_ring_submit) while the passes on the other scan streams compute
     struct RingSlot {
         int16_t *h_iq = nullptr;
-        void *h_iq_dev = nullptr;  // the same pinned buffer as the device addresses it (slots of a few buffers are read in place)
+        void *h_iq_dev = nullptr;  // the same pinned buffer as the device addresses it
         void *d_iq = nullptr;
-        hipEvent_t copied = nullptr;
     } ring[kSlots];
     size_t ring_samples = 0;
-    hipStream_t copy_stream = nullptr;
-    hipStream_t copy_stream_spare = nullptr;  // a pooled copy stream this context has not needed (yet)
 
     bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
     uint32_t *d_carry_next = nullptr;  // the end of the latest submission's input: the next one's lead-in
@@ -274,6 +271,7 @@ int fallback_slot(adsb_ctx *c, const Slot &sl, Slot &tmp);
 // for a pass of a few buffers.
 inline hipEvent_t input_ready_now() { return reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(1)); }
 bool one_launch_pass(const adsb_ctx *c, uint32_t n_chunks);
+hipStream_t next_scan_stream(const adsb_ctx *c, uint32_t n_chunks);
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples, uint32_t n_chunks,
                  bool inline_tail = false, bool lead_from_src = false, bool advance_carry = true,
                  bool force_simple = false, hipEvent_t input_done = nullptr, bool no_fuse = false);

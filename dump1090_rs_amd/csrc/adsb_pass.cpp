@@ -55,6 +55,16 @@ bool one_launch_pass(const adsb_ctx *c, uint32_t n_chunks)
     return !never_fuse && c->profiling <= 1 && n_chunks <= (uint32_t)kInlineTailChunks;
 }
 
+// The scan stream the next plain IQ pass of n_chunks buffers will run on (enqueue_pass's own rule).
+hipStream_t next_scan_stream(const adsb_ctx *c, uint32_t n_chunks)
+{
+    static const int fused_streams = tuning_env("ADSB_FUSED_STREAMS") ? std::atoi(tuning_env("ADSB_FUSED_STREAMS")) : kScanStreams;
+    static const bool one_scan_stream = tuning_env("ADSB_ONE_SCAN_STREAM") != nullptr;
+    if (c->carry_over || one_scan_stream) return c->scan_stream[0];
+    const int period = one_launch_pass(c, n_chunks) ? std::max(1, std::min(fused_streams, c->n_scan_streams)) : 2;
+    return c->scan_stream[c->submitted % (uint64_t)period];
+}
+
 int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64_t n_samples,
                  uint32_t n_chunks, bool inline_tail, bool lead_from_src,
                  bool advance_carry, bool force_simple, hipEvent_t input_done, bool no_fuse)

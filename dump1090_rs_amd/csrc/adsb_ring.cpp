@@ -4,7 +4,8 @@
 using namespace adsb::host;
 
 namespace {
-constexpr uint64_t kRingInPlaceChunks = kInlineTailChunks;  // every one-launch size
+// Slots up to this many buffers are always read in place; up to the one-launch size when nothing else is in flight.
+constexpr uint32_t kRingInPlaceChunks = 2;
 }
 
 extern "C" {
@@ -14,20 +15,21 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
     if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
     if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->copy_stream_spare) {
-        c->copy_stream = c->copy_stream_spare;
-        c->copy_stream_spare = nullptr;
-    } else {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    }
     for (int k = 0; k < c->n_slots; k++) {
         auto &r = c->ring[k];
         // (mapped and coherent: slots of a few buffers are read in place by the pass itself)
         HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(c, hipHostGetDevicePointer(&r.h_iq_dev, r.h_iq, 0));
         HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
-        HIP_TRY(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
     }
+    // One small copy per slot now, on an idle stream.  The runtime sets something up on the first copy between a
+    // pair of buffers; left to the first pipelined submit (a ring that starts with its slots read in place) every
+    // later hipMemcpyAsync of the ring took 12-19 us of the submitting thread instead of 2-5 (measured: 16-buffer
+    // slots, eight in flight, 12.5 Gsample/s instead of 13.2; profiles/r4_ring_copy_ab.txt).
+    const size_t warm = std::min<size_t>(samples_per_slot * 4, 64 << 10);
+    for (int k = 0; k < c->n_slots; k++)
+        HIP_TRY(c, hipMemcpyAsync(c->ring[k].d_iq, c->ring[k].h_iq, warm, hipMemcpyHostToDevice, c->scan_stream[k % c->n_scan_streams]));
+    for (int k = 0; k < c->n_scan_streams; k++) HIP_TRY(c, hipStreamSynchronize(c->scan_stream[k]));
     c->ring_samples = samples_per_slot;
     return ADSB_OK;
 }
@@ -47,26 +49,32 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     if (c->slot[c->submitted % (uint64_t)c->n_slots].busy || c->slot[c->submitted % (uint64_t)c->n_slots].parked) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipSetDevice(c->device));
     auto &r = c->ring[c->submitted % (uint64_t)c->n_slots];
-    // A slot of a few buffers (the reference reads and demodulates 131072 samples at a time,
-    // dump1090_rs/src/main.rs:161-167) is one launch that reads the pinned buffer in place over the link:
-    // no copy command, no event, no staging -- the pass is as long as the transfer either way, and the
-    // host side of it is a single launch.  Larger slots are copied while the slots before them compute.
-    static const bool always_copy = tuning_env("ADSB_RING_COPY") != nullptr;
-    // (measured with eight in flight: 8.5 / 9.7 / 10.1 / 10.0 / 10.2 Gsample/s at 1 / 2 / 4 / 8 / 16 buffers per slot
-    // read in place; copied first and then one launch: 8.5 at 8, 10.2 at 16, and far less below)
-    if (!always_copy && (n_samples + kChunkSamples - 1) / kChunkSamples <= kRingInPlaceChunks && !c->carry_over)
-        return submit(c, r.h_iq_dev, false, n_samples, false, input_ready_now());
-    // H2D on the copy stream; the pass on the compute stream waits for it, so this slot's
-    // transfer overlaps the other slot's kernels
+    const uint32_t n_chunks = (uint32_t)((n_samples + kChunkSamples - 1) / kChunkSamples);
+    // Two ways for a slot to reach the pass (dump1090_rs/src/main.rs:161-167 reads and demodulates 131072
+    // samples at a time; a host may batch more per slot):
+    //  * read in place over the link by the pass's one launch (no copy command, no staging: the host side is
+    //    a single launch).  A kernel pulls ~39 GB/s through the link and the pass is as long as that transfer:
+    //    the shortest way from a filled slot to its frames, and the fastest at one or two buffers per slot
+    //    whatever is in flight (a copy command costs the submitting thread more than the launch itself);
+    //  * copied by the copy engine (~52 GB/s) on the pass's OWN scan stream, in order in front of its first
+    //    launch -- no event, no copy stream: while it runs, the passes on the other scan streams compute.  From
+    //    three buffers per slot with another pass in flight this is the faster pipeline (4 / 8 / 16 buffers,
+    //    three in flight: 10.9 / 11.0 / 13.1 Gsample/s against 9.1 / 9.5 / 10.2 in place; one in flight: 6.3 /
+    //    8.1 / 9.7 against 7.6 / 9.4 / 10.1 -- profiles/r4_ring_copy_ab.txt), and the only way for slots of more
+    //    than one launch.
+    bool in_place = one_launch_pass(c, n_chunks) && !c->carry_over &&
+                    (n_chunks <= kRingInPlaceChunks || c->submitted == c->delivered);
+    if (const char *e = tuning_env("ADSB_RING_COPY")) {   // measurement aid (tuning build only): 0 in place where possible, else copy
+        const int mode = std::atoi(e);
+        const bool can = one_launch_pass(c, n_chunks) && !c->carry_over;
+        in_place = can && mode == 0;
+    }
+    if (in_place) return submit(c, r.h_iq_dev, false, n_samples, false, input_ready_now());
     {
         HT(c, HT_RING_MEMCPY);
-        HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, next_scan_stream(c, n_chunks)));
     }
-    {
-        HT(c, HT_RING_EVENT);
-        HIP_TRY(c, hipEventRecord(r.copied, c->copy_stream));
-    }
-    return submit(c, r.d_iq, false, n_samples, false, r.copied);
+    return submit(c, r.d_iq, false, n_samples, false, input_ready_now());
 }
 
 }  // extern "C"

@@ -37,7 +37,7 @@ def rematches(c) -> int:
     return int(c._L.adsb_host_rematches(c._h))
 
 
-def ring_stream(c, iq, per_slot, depth):
+def ring_stream(c, iq, per_slot, depth, flush_before=()):
     """`iq` through the ring in slots of `per_slot` samples, `depth` passes in flight; (slot, message) pairs."""
     n_slots = (len(iq) + per_slot - 1) // per_slot
     got, collected = [], 0
@@ -45,6 +45,8 @@ def ring_stream(c, iq, per_slot, depth):
         if c.pending() == depth:
             got += [(collected, m) for m in c.collect()]
             collected += 1
+        if b in flush_before:
+            c.icao_flush()
         part = iq[b * per_slot:(b + 1) * per_slot]
         buf = c.ring_acquire()
         buf[: len(part)] = part
@@ -95,6 +97,31 @@ def test_ring_of_512kb_slots_equals_one_oracle_stream(hip_lib, oracle_mod, depth
         assert frames(df4) == [32, 35]
         assert sorted({s for s, m in again if m.buffer() == df4}) == [30, 32, 35]    # 30 decodes now
         assert rematches(c) == before
+
+
+@pytest.mark.parametrize("per_slot,depth", [(3, 2), (3, 8), (6, 4), (16, 8), (16, 1), (20, 4), (20, 2)])
+def test_ring_slots_copied_in_front_of_their_pass(hip_lib, oracle_mod, per_slot, depth):
+    """Slots of three buffers and more reach their pass through the copy engine, queued on the pass's own scan
+    stream in front of its first launch (no event), unless nothing else is in flight (then the first one is read
+    in place): 16 is the largest one-launch slot, 20 takes three launches.  A stream that keeps teaching the
+    filter, a flush in the middle, the last slot ragged; against one oracle stream."""
+    from dump1090_rs_amd import Context
+    n_slots = 13
+    n = (n_slots - 1) * per_slot * CHUNK + 31007
+    iq = synth.make_iq(n, n_bursts=30 * n_slots * per_slot, seed=5100 + per_slot + depth, n_icao=30, df11_every=4)
+    flush_before = {0, 7}
+    orc = oracle_mod.Oracle()
+    want = []
+    for b in range(n_slots):
+        if b in flush_before:
+            orc.icao_flush()
+        want += [(b,) + want_key(w) for w in orc.demod_iq(iq[b * per_slot * CHUNK:(b + 1) * per_slot * CHUNK])[0]]
+    assert len(want) > 20 * n_slots
+    with Context(0, per_slot) as c:
+        c.ring_create(per_slot * CHUNK)
+        for rep in range(2):
+            got = ring_stream(c, iq, per_slot * CHUNK, depth, flush_before)
+            assert [(s,) + key(m) for s, m in got] == want
 
 
 def test_address_taught_early_in_a_buffer_reaches_a_frame_late_in_it_and_not_the_reverse(hip_lib, oracle_mod):
