@@ -331,6 +331,29 @@ void adsb_destroy(adsb_ctx *c)
                 std::fprintf(stderr, "  one-launch pass: %-45s +%6.2f us  (at %6.2f)\n", name[k],
                              (double)(long long)(t[k] - t[k - 1]) / 100.0, (double)(long long)(t[k] - t[0]) / 100.0);
         }
+        // ... and of the last sixteen, workgroup by workgroup: when the first and the last workgroup passed each
+        // stage, from the pass's first entry (passes in flight side by side: how they stretch each other)
+        std::vector<unsigned long long> w(16 * 32 * 8);
+        if (hipMemcpy(w.data(), c->d_timeline + 1024, w.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long origin = ~0ull;
+            for (unsigned long long v : w) if (v && v < origin) origin = v;
+            for (int ps = 0; ps < 16; ps++) {
+                unsigned long long lo[8], hi[8] = {};
+                for (auto &v : lo) v = ~0ull;
+                for (int g = 0; g < 32; g++)
+                    for (int k = 0; k < 8; k++) {
+                        const unsigned long long v = w[(ps * 32 + g) * 8 + k];
+                        if (!v) continue;
+                        lo[k] = std::min(lo[k], v);
+                        hi[k] = std::max(hi[k], v);
+                    }
+                if (!hi[0]) continue;
+                std::fprintf(stderr, "  pass %2d entered at %8.2f us:", ps, (double)(lo[0] - origin) / 100.0);
+                for (int k = 0; k < 7; k++)
+                    if (hi[k]) std::fprintf(stderr, "  s%d %.1f..%.1f", k, (double)(lo[k] - lo[0]) / 100.0, (double)(hi[k] - lo[0]) / 100.0);
+                std::fprintf(stderr, "\n");
+            }
+        }
         (void)hipFree(c->d_timeline);
     } else if (c->d_timeline && c->debug_stop == 100) {
         // profiling aid: phase / barrier-wait totals of the last scan, summed over all waves

@@ -95,7 +95,10 @@ struct Slot {
 // never waits for the host (adsb_ctx::n_slots).
 constexpr int kSlots = ADSB_MAX_IN_FLIGHT_SMALL;  // what the arrays hold
 constexpr int kBitmaps = kSlots + 1;
-constexpr int kScanStreams = 4;
+#ifndef ADSB_SCAN_STREAMS
+#define ADSB_SCAN_STREAMS 4
+#endif
+constexpr int kScanStreams = ADSB_SCAN_STREAMS;
 constexpr int kScanEvRing = kSlots + 3;  // scan start / stop event pairs in rotation (finish_pass: ms_scan_exclusive)
 
 constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves x 8 counters per workgroup

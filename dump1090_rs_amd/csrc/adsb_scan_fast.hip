@@ -315,12 +315,13 @@ __device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 
 }
 
 // a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
+template <bool SHARED>
 __device__ __forceinline__ void put_hit_fields(const ScanParams &p, size_t place, const uint32_t (&f)[5])
 {
     uint32_t *w = p.hit_fields + place * kHitFieldWords;
 #pragma unroll
-    for (int r = 0; r < 5; r++) w[r] = f[r];
-    w[5] = 1u;
+    for (int r = 0; r < 5; r++) st_shared<SHARED>(&w[r], f[r]);
+    st_shared<SHARED>(&w[5], 1u);
 }
 
 // LDS only the instantiations that hand hit fields over have (FIELDS: dense streams, whose record builder is
@@ -335,7 +336,7 @@ template <>
 struct HitFieldLds<false> {
 };
 
-template <bool FIELDS>
+template <bool FUSED, bool FIELDS>
 __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS> &hf, bool is_hit, uint64_t entry,
                                           int lane, uint32_t par, const uint32_t (&f)[5])
 {
@@ -358,13 +359,13 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFi
                 const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
                 if (k < kOrderBucket) {
                     p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
-                    if constexpr (FIELDS) put_hit_fields(p, (size_t)c * kOrderBucket + k, f);
+                    if constexpr (FIELDS) put_hit_fields<FUSED>(p, (size_t)c * kOrderBucket + k, f);
                 } else {
                     atomicOr(&p.ctr->overflow, 1u);
                 }
             } else if (gi < p.hits_cap) {
-                p.hits[gi] = entry;
-                if constexpr (FIELDS) put_hit_fields(p, gi, f);
+                st_shared<FUSED>(&p.hits[gi], entry);
+                if constexpr (FIELDS) put_hit_fields<FUSED>(p, gi, f);
             } else {
                 atomicOr(&p.ctr->overflow, 1u);
             }
@@ -512,10 +513,10 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitF
     const unsigned long long ma = __ballot(is_ap);
     if (ma) {
         const uint32_t mine = mask_rank(ma, ap_count);
-        if (is_ap && mine < seg_cap) seg[mine] = entry;
+        if (is_ap && mine < seg_cap) st_shared<FUSED>(&seg[mine], entry);   // (the last workgroup may look at it again)
         ap_count += (uint32_t)__popcll(ma);
     }
-    if (__ballot(is_hit)) stage_hit<FIELDS>(p, s, hf, is_hit, entry, lane, par, tr.f);  // rare
+    if (__ballot(is_hit)) stage_hit<FUSED, FIELDS>(p, s, hf, is_hit, entry, lane, par, tr.f);  // rare
     if (__ballot(learn)) {  // rare: the host replay will add this address to the filter
         // (one-launch pass: an address bit that was clear until now means trials this pass has already
         // matched may have missed it -- its last workgroup then matches the lists once more)
@@ -524,7 +525,7 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitF
                 const uint32_t addr = trial_addr(tr);
                 if (bitmap_set(p.bitmap, addr)) {
                     const uint32_t k = atomicAdd(&p.ctr->learned_new, 1u);
-                    if (k < (uint32_t)kNewAddrCap) p.ctr->new_addr[k] = addr;
+                    if (k < (uint32_t)kNewAddrCap) st_shared<true>(&p.ctr->new_addr[k], addr);
                 }
             }
         } else {
@@ -563,7 +564,10 @@ __device__ __forceinline__ void split5(uint32_t t5, uint32_t &c, uint32_t &tpi)
 // LDS, tiles done, own match done, counted in (from here on: the last workgroup), second look done, end
 #define FSTAMP(k)                                                                                  \
     do {                                                                                           \
-        if (FUSED && p.timeline && tid == 0) p.timeline[448 + (k)] = (unsigned long long)wall_clock64(); \
+        if (FUSED && p.timeline && tid == 0) {                                                      \
+            p.timeline[448 + (k)] = (unsigned long long)wall_clock64();                            \
+            if ((k) < 8) p.timeline[1024 + ((p.seq & 15u) * 32u + min(blockIdx.x, 31u)) * 8u + (k)] = (unsigned long long)wall_clock64(); \
+        }                                                                                          \
     } while (0)
 #else
 #define STAMP(slot) do {} while (0)
@@ -598,12 +602,12 @@ __device__ __forceinline__ bool fused_match_entry(const ScanParams &p, const uin
     if ((w >> (c & 31)) & 1u) {
         const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
         if (idx < p.hits_cap) {
-            p.hits[idx] = e;
-            if (p.hit_fields) p.hit_fields[(size_t)idx * kHitFieldWords + 5] = 0u;
+            st_shared<true>(&p.hits[idx], e);
+            if (p.hit_fields) st_shared<true>(&p.hit_fields[(size_t)idx * kHitFieldWords + 5], 0u);
         } else {
             atomicOr(&p.ctr->overflow, 1u);
         }
-        *slot = e | (15ull << 24);
+        st_shared<true>(slot, e | (15ull << 24));
         return true;
     }
     return false;
@@ -622,8 +626,8 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
     if constexpr (FUSED) {
         if (blockIdx.x == 0 && tid == 0) {
             const unsigned long long t0 = (unsigned long long)wall_clock64();
-            p.ctr->t_start[0] = (uint32_t)t0;
-            p.ctr->t_start[1] = (uint32_t)(t0 >> 32);
+            st_shared<true>(&p.ctr->t_start[0], (uint32_t)t0);
+            st_shared<true>(&p.ctr->t_start[1], (uint32_t)(t0 >> 32));
         }
         for (int i = tid; i < 3 * 256; i += kThreads) fs.x56[i] = p.tables[kTabX56 * 256 + i];
         if (tid < 168) fs.bits[tid] = p.tables[kTabBitsOff + tid];
@@ -986,9 +990,9 @@ tile_end:
             if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
         } else {
             for (uint32_t i = tid; i < nhit; i += kThreads) {
-                dst[s.hit_base + i] = s.hit[i];
+                st_shared<FUSED>(&dst[s.hit_base + i], s.hit[i]);
                 if constexpr (FIELDS)
-                    put_hit_fields(p, (size_t)(dst - (p.order_cnt ? p.order_tmp : p.hits)) + s.hit_base + i, hf.f[i]);
+                    put_hit_fields<FUSED>(p, (size_t)(dst - (p.order_cnt ? p.order_tmp : p.hits)) + s.hit_base + i, hf.f[i]);
             }
         }
     }
@@ -1003,7 +1007,7 @@ tile_end:
     if (lane == 0 && cand_count) atomicAdd(&p.ctr->seg_cand[blockIdx.x], cand_count);
     if (lane == 0) {
         if (ap_count > seg_cap) atomicOr(&p.ctr->overflow, 2u);
-        p.ctr->seg_ap[my_seg] = min(ap_count, seg_cap);
+        st_shared<FUSED>(&p.ctr->seg_ap[my_seg], min(ap_count, seg_cap));
     }
     if constexpr (FUSED) {
         // ============================================================ the tail of a one-launch pass
@@ -1016,7 +1020,9 @@ tile_end:
         // every list once more (c).
         FSTAMP(2);
         static_assert(kFusedMaxTiles >= 16 * kTilesPerChunk, "tile flags of the largest one-launch pass");
-        __threadfence();
+        // (release: everything this workgroup wrote for others went through to the memory side -- st_shared,
+        // atomics -- and is acknowledged from there; no cache write-back: adsb_tail_dev.h, st_shared)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&p.ctr->tile_done[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 64) {
@@ -1050,12 +1056,13 @@ tile_end:
         // usually nothing -- the tile itself was published above), count this workgroup in, acquire what
         // the others wrote.
         FSTAMP(3);
-        if (__syncthreads_or(appended ? 1 : 0)) __threadfence();
+        (void)appended;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // what the match wrote (hits, marks) has arrived
         __syncthreads();
         if (tid == 0) fs.is_last = atomicAdd(&p.ctr->scan_blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
         __syncthreads();
         if (!fs.is_last) return;
-        __threadfence();
+        // (acquire: nothing -- from here on what the other workgroups wrote is read with ld_shared)
         FSTAMP(4);
         // (c) The fallback: some workgroup matched without having seen all the tiles before it, and an
         // address bit that was clear when the pass began was set on the way -- its entries may have missed
@@ -1068,12 +1075,12 @@ tile_end:
             // addresses an entry is compared with those directly (no trip to the bitmap)
             uint32_t *const cnt = s.plane;
             static_assert(sizeof(s.plane) / 4 >= 4 * 16 * kTilesPerChunk, "fill counts of the largest one-launch pass");
-            for (uint32_t g = (uint32_t)tid; g < nseg; g += kThreads) cnt[g] = min(p.ctr->seg_ap[g], seg_cap);
+            for (uint32_t g = (uint32_t)tid; g < nseg; g += kThreads) cnt[g] = min(ld_shared<true>(&p.ctr->seg_ap[g]), seg_cap);
             uint32_t fresh[kNewAddrCap];
             const bool by_list = n_new <= (uint32_t)kNewAddrCap;
 #pragma unroll
             for (int k = 0; k < kNewAddrCap; k++)
-                fresh[k] = by_list && (uint32_t)k < n_new ? p.ctr->new_addr[k] : 0xFFFFFFFFu;
+                fresh[k] = by_list && (uint32_t)k < n_new ? ld_shared<true>(&p.ctr->new_addr[k]) : 0xFFFFFFFFu;
             lds_barrier();
             FSTAMP(8);
             constexpr uint32_t U = 9;
@@ -1087,7 +1094,7 @@ tile_end:
                 for (uint32_t i = (uint32_t)lane; i < nmax; i += 64u) {
                     uint64_t e[U];
 #pragma unroll
-                    for (uint32_t u = 0; u < U; u++) e[u] = i < n[u] ? p.ap[(uint64_t)(g0 + u) * seg_cap + i] : (15ull << 24);
+                    for (uint32_t u = 0; u < U; u++) e[u] = i < n[u] ? ld_shared<true>(&p.ap[(uint64_t)(g0 + u) * seg_cap + i]) : (15ull << 24);
 #pragma unroll
                     for (uint32_t u = 0; u < U; u++) {
                         if (!by_list) {
@@ -1103,8 +1110,8 @@ tile_end:
                         if (hit && code != 15u) {
                             const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
                             if (idx < p.hits_cap) {
-                                p.hits[idx] = e[u];
-                                if (p.hit_fields) p.hit_fields[(size_t)idx * kHitFieldWords + 5] = 0u;
+                                st_shared<true>(&p.hits[idx], e[u]);
+                                if (p.hit_fields) st_shared<true>(&p.hit_fields[(size_t)idx * kHitFieldWords + 5], 0u);
                             } else {
                                 atomicOr(&p.ctr->overflow, 1u);
                             }

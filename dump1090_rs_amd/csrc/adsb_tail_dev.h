@@ -75,6 +75,31 @@ __device__ __forceinline__ uint32_t score_hash_insert(const ScoreDev &sd, uint32
 
 __device__ __forceinline__ uint64_t score_pos(const TrialRecord &r) { return (uint64_t)r.chunk << 24 | (r.j_tp & 0xFFFFFFu); }
 
+// What one workgroup of a one-launch pass writes for another one to read (hits, their bit fields, list entries,
+// fill counts), and how that one reads it: written THROUGH to the memory side and read from there (agent scope),
+// access by access.  The alternative -- plain accesses with a release fence on one side and an acquire fence on
+// the other -- writes back / invalidates the XCD's whole L2, and such a fence does not come back before every
+// read in flight through that L2 has, including the 512 KB another pass beside this one is pulling over the link
+// (tools/pcie_read_probe.hip pass: one fence per workgroup, four passes side by side: +2.5 us per pass; the
+// one-buffer ring: kernels of 56 us instead of 28).  With these, "release" is s_waitcnt vmcnt(0) -- the
+// write-through stores are acknowledged from the memory side -- and "acquire" is nothing.
+template <typename T>
+struct as_is {
+    typedef T type;
+};
+template <bool SHARED, typename T>
+__device__ __forceinline__ void st_shared(T *at, typename as_is<T>::type v)
+{
+    if constexpr (SHARED) __hip_atomic_store(at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *at = v;
+}
+template <bool SHARED, typename T>
+__device__ __forceinline__ T ld_shared(const T *at)
+{
+    if constexpr (SHARED) return __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *at;
+}
+
 constexpr int kRecWindow = 296;   // magnitudes a trial can touch: data[j+19 .. j+290], rounded up
 constexpr int kRecRow = 320;      // a window's row in LDS: five magnitudes per lane, stored unguarded
 constexpr int kRecBatch = 64;     // records a block stages before writing them out together
@@ -117,7 +142,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
     const uint32_t per = (n + nblk - 1) / nblk;
     const uint32_t first = bid * per, last = min(n, first + per);
     unsigned long long my_sum = 0;  // of the u64 words this thread sent to the host
-    const bool overflowed = p.ctr->overflow != 0;                             // (uniform) the host redoes the pass
+    const bool overflowed = ld_shared<SINGLE>(&p.ctr->overflow) != 0;         // (uniform) the host redoes the pass
     const bool do_score = p.score.si && n <= p.score.cap && !overflowed;      // (uniform) k_score follows
     // The hits come in runs.  Host-ordered passes: one run, this block's share of the hit list as it
     // was filled.  Device-ordered passes (dense streams): one run per buffer this block takes -- the
@@ -224,7 +249,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                 }
                 uint32_t all = 1u;
 #pragma unroll
-                for (int h = 0; h < kRecGroup; h++) all &= p.hit_fields[place[h] * kHitFieldWords + 5];
+                for (int h = 0; h < kRecGroup; h++) all &= ld_shared<SINGLE>(&p.hit_fields[place[h] * kHitFieldWords + 5]);
                 from_fields = __builtin_amdgcn_readfirstlane((int)all) != 0;
             }
             if (from_fields) {
@@ -233,8 +258,8 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
                 uint32_t fw0[kRecGroup], fw1[kRecGroup], w[kRecGroup];
 #pragma unroll
                 for (int h = 0; h < kRecGroup; h++) {
-                    fw0[h] = p.hit_fields[place[h] * kHitFieldWords + r0];
-                    fw1[h] = p.hit_fields[place[h] * kHitFieldWords + r1];
+                    fw0[h] = ld_shared<SINGLE>(&p.hit_fields[place[h] * kHitFieldWords + r0]);
+                    fw1[h] = ld_shared<SINGLE>(&p.hit_fields[place[h] * kHitFieldWords + r1]);
                     if constexpr (FROM_MAG) {   // caller-supplied magnitudes: data[j + 19 + lane] as it is
                         const int d = (int)entry_j(e[h]) + 19 + lane;
                         w[h] = d < kMagDataLen ? ((const uint16_t *)p.src)[d] : 0u;
@@ -454,8 +479,8 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) my_sum += __shfl_down(my_sum, off);
         uint32_t ap = 0, cand = 0;
-        for (uint32_t i = threadIdx.x; i < 4u * used_blocks; i += blockDim.x) ap += p.ctr->seg_ap[i];
-        for (uint32_t i = threadIdx.x; i < used_blocks; i += blockDim.x) cand += p.ctr->seg_cand[i];
+        for (uint32_t i = threadIdx.x; i < 4u * used_blocks; i += blockDim.x) ap += ld_shared<true>(&p.ctr->seg_ap[i]);
+        for (uint32_t i = threadIdx.x; i < used_blocks; i += blockDim.x) cand += ld_shared<true>(&p.ctr->seg_cand[i]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             ap += __shfl_down(ap, off);
