@@ -105,7 +105,7 @@ struct Counters {
     uint32_t blocks_done;    // records kernel: blocks that have finished (last one publishes)
     uint32_t rec_sum[2];     // records kernel: 64-bit sum of every u64 word of the records it wrote (8-byte aligned)
     uint32_t learned_new;    // one-launch pass: how often a trial of this pass set an address bit that was clear before
-    uint32_t reserved1;
+    uint32_t n_rec;          // one-launch pass: records its workgroups have written in place (k_scan_fast: emit_records)
     uint32_t new_addr[kNewAddrCap];  // ... and the first of those addresses
     uint32_t unordered;      // one-launch pass: a workgroup gave up waiting for the tiles before its own (bounded wait)
     uint32_t t_start[2];     // one-launch pass: the 100 MHz wall clock when its first workgroup started

@@ -314,6 +314,76 @@ __device__ __forceinline__ uint32_t trial_addr(const Trial &t)  // message bits 
     return addr;
 }
 
+// One-launch pass: the record of a hit is built where the hit is found, by the wave that found it, from what the
+// tile has in LDS -- the trial's five bit fields are all 112 sliced bits, the 33 magnitudes behind j + 19 are in
+// s.mag (demod_2400.rs:158-182, 191-196) -- and goes straight into the pass's records in mapped host memory.  No
+// hit list, no second pass over the samples: the record builder of the three-launch passes (k_records) reads the
+// IQ behind every hit again, which for a slot read in place is a round trip over the link per hit, queued behind
+// the 512 KB the passes beside this one are pulling through it.
+// `m`: the lanes that hold a hit (a ballot); f / cslot / entry / residual: that lane's trial.
+// One hit (wave-uniform arguments: its five fields, its LDS slot, its entry, its residual), built by the whole wave.
+__device__ __forceinline__ void emit_record(const ScanParams &p, const FastLds &s, const uint32_t (&ff)[5], uint32_t cs, uint64_t me,
+                                            uint32_t mcrc, int lane)
+{
+    const uint32_t k0 = __umul24((uint32_t)lane, 13108u) >> 16, r0 = (uint32_t)lane - 5u * k0;          // lane / 5, % 5
+    const uint32_t k1 = __umul24((uint32_t)lane + 64u, 13108u) >> 16, r1 = (uint32_t)lane + 64u - 5u * k1;
+    // lane n: message bits n and n + 64 (bit 5k + r of the message is bit k of field r)
+    const uint32_t w0 = r0 == 0 ? ff[0] : r0 == 1 ? ff[1] : r0 == 2 ? ff[2] : r0 == 3 ? ff[3] : ff[4];
+    const uint32_t w1 = r1 == 0 ? ff[0] : r1 == 1 ? ff[1] : r1 == 2 ? ff[2] : r1 == 3 ? ff[3] : ff[4];
+    const unsigned long long h0 = __brevll(__ballot(((w0 >> k0) & 1u) != 0));
+    const unsigned long long h1 = __brevll(__ballot(lane < 48 && ((w1 >> k1) & 1u) != 0));
+    unsigned long long pw = lane < 33 ? (unsigned long long)s.mag[cs + 19u + (uint32_t)lane] : 0ull;
+    pw *= pw;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pw += __shfl_xor(pw, off);
+    if (lane == 0) {
+        const uint32_t j = entry_j(me), tp = entry_tp(me);
+        TrialRecord r;
+        r.power = pw | ((unsigned long long)mcrc << 40);  // pw < 2^38
+        r.chunk = (uint32_t)entry_chunk(me);
+        r.j_tp = j | (tp << 24);
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.msg[k] = (uint8_t)(h0 >> (56 - 8 * k));
+#pragma unroll
+        for (int k = 0; k < 6; k++) r.msg[8 + k] = (uint8_t)(h1 >> (56 - 8 * k));
+        // (as k_records: what this DF will ask the filter about, hashed for the host replay)
+        const uint32_t df = (uint32_t)(h0 >> 59);
+        const bool ap = ((0xFF310031u >> df) & 1u) != 0;
+        const uint32_t addr = (uint32_t)(h0 >> 32) & 0xFFFFFFu;
+        r.pad = (uint16_t)(3u | (icao_hash_dev(ap ? mcrc : addr) << 4));
+        const uint32_t idx = atomicAdd(&p.ctr->n_rec, 1u);
+        if (idx < p.hits_cap) {
+            u32x4_t q[2];
+            __builtin_memcpy(q, &r, sizeof(r));
+            host_store128((char *)(p.fused_rec + idx), q[0]);
+            host_store128((char *)(p.fused_rec + idx) + 16, q[1]);
+            unsigned long long w[4];
+            __builtin_memcpy(w, &r, sizeof(r));
+            atomicAdd((unsigned long long *)p.ctr->rec_sum, w[0] + w[1] + w[2] + w[3]);
+        } else {
+            atomicOr(&p.ctr->overflow, 1u);
+        }
+    }
+}
+
+// `m`: the lanes that hold a hit (a ballot); f / cslot / entry / residual: that lane's trial.
+__device__ __forceinline__ void emit_records(const ScanParams &p, const FastLds &s, unsigned long long m, const uint32_t (&f)[5],
+                                             uint32_t cslot, uint64_t entry, uint32_t residual, int lane)
+{
+    while (m) {
+        const int from = (int)__builtin_ctzll(m);   // (wave-uniform: m is)
+        m &= m - 1ull;
+        uint32_t ff[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) ff[r] = (uint32_t)__builtin_amdgcn_readlane((int)f[r], from);
+        const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cslot, from);
+        const uint32_t mcrc = (uint32_t)__builtin_amdgcn_readlane((int)residual, from);
+        const uint64_t me = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(entry >> 32), from) << 32 |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, from);
+        emit_record(p, s, ff, cs, me, mcrc, lane);
+    }
+}
+
 // a self-validating trial: staged in LDS, flushed to the hit list at the end of the tile
 template <bool SHARED>
 __device__ __forceinline__ void put_hit_fields(const ScanParams &p, size_t place, const uint32_t (&f)[5])
@@ -659,7 +729,9 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
     // blocks walk it side by side: the 368 samples two neighbouring tiles share are then read from
     // HBM once and found in that XCD's L2 by the neighbour.  Any other grid: plain round robin.
     uint32_t t_first = blockIdx.x, t_end = n_tiles, t_stride = gridDim.x;
-    if ((gridDim.x & 7u) == 0 && n_tiles >= gridDim.x) {
+    // (a one-launch pass: tile = block -- its workgroups publish and wait for each other in tile order by their
+    // block index, and a pass of a few buffers has nothing to gain from the placement)
+    if (!FUSED && (gridDim.x & 7u) == 0 && n_tiles >= gridDim.x) {
         const uint32_t x = blockIdx.x & 7u;
         t_first = ((x * n_tiles) >> 3) + (blockIdx.x >> 3);
         t_end = ((x + 1u) * n_tiles) >> 3;
@@ -977,6 +1049,17 @@ tile_end:
     // ---------------------------------------------------------------- tile epilogue
     // (the AP fill counts are registers; they are written back when the workgroup retires)
     const uint32_t nhit = min(s.nhit[par], (uint32_t)kHitCap);
+    if constexpr (FUSED && FIELDS) {
+        // one-launch pass: the staged hits' records are built here and now, a wave a hit (emit_record); only what
+        // did not fit the staging went to the hit list (stage_hit), for the record builder at the end
+        for (uint32_t i = (uint32_t)(tid >> 6); i < nhit; i += (uint32_t)kWaves) {
+            const uint64_t me = s.hit[i];
+            uint32_t ff[5];
+#pragma unroll
+            for (int r = 0; r < 5; r++) ff[r] = hf.f[i][r];
+            emit_record(p, s, ff, (uint32_t)((int)entry_j(me) - (jbase - kPad)), me, entry_value(me), lane);
+        }
+    } else
     if (nhit) {  // rare: a handful per chunk
         // (a tile's hits share its buffer: on a dense stream they go into that buffer's bucket)
         uint64_t *const dst = p.order_cnt ? p.order_tmp + (size_t)chunk * kOrderBucket : p.hits;
@@ -1046,17 +1129,32 @@ tile_end:
         // predecessor on another scan stream turns out to have learned one: adsb_collect.cpp), what the
         // tiles before this one learned, and whatever else this pass has learned so far (harmless: the host
         // replay scores in order).
-        bool appended = false;
         {
+            // (a match's record is built here and now: this workgroup's tile is still in LDS -- emit_records)
             const uint32_t n_mine = min(ap_count, seg_cap);
-            for (uint32_t i = (uint32_t)lane; i < n_mine; i += 64u)
-                appended |= fused_match_entry(p, fs.x56, &seg[i], __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int slot0 = tile_ref<FROM_MAG>(p, blockIdx.x).jbase - kPad;   // data index of LDS slot 0 (one tile per workgroup)
+            for (uint32_t i0 = 0; i0 < n_mine; i0 += 64u) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const uint64_t e = i < n_mine ? ld_shared<true>(&seg[i]) : (15ull << 24);
+                const uint32_t code = entry_code(e);
+                uint32_t c = entry_value(e);
+                if (code >= 5u && code < 10u) c = gf_apply(fs.x56, c);
+                // (agent scope: bits other workgroups of this launch have set, not a line this CU's cache holds)
+                const bool hit = code != 15u && ((ld_shared<true>(&p.bitmap[c >> 5]) >> (c & 31u)) & 1u) != 0u;
+                const unsigned long long mm = __ballot(hit);
+                if (mm) {
+                    const uint32_t cs = hit ? (uint32_t)((int)entry_j(e) - slot0) : (uint32_t)kPad;
+                    Trial tr;
+                    trial_eval(s, cand_entry(cs), code % 5u, tr);
+                    emit_records(p, s, mm, tr.f, cs, e, c, lane);
+                    if (hit) st_shared<true>(&seg[i], e | (15ull << 24));   // the second look must not report it again
+                }
+            }
         }
         // (b) The last workgroup to get here runs the rest alone: release what the match wrote (hits, marks;
         // usually nothing -- the tile itself was published above), count this workgroup in, acquire what
         // the others wrote.
         FSTAMP(3);
-        (void)appended;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // what the match wrote (hits, marks) has arrived
         __syncthreads();
         if (tid == 0) fs.is_last = atomicAdd(&p.ctr->scan_blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
@@ -1127,6 +1225,7 @@ tile_end:
         __syncthreads();
         FSTAMP(5);
         // (d) records, checksum, summary into mapped host memory; the counters back to zero
+        // (the records built in place are there already; what is left is what the second look found, if it ran)
         records_block<FROM_MAG, false, true>(p, p.fused_rec, 0u, 1u, nullptr, false, gridDim.x, fs.bits);
         FSTAMP(6);
     }
@@ -1167,7 +1266,8 @@ int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream)
     hip_clear();
     const uint32_t tiles = p.n_chunks * kTilesPerChunk;  // one workgroup per tile: a pass of a few buffers
     if (tiles == 0 || !p.fused_rec) return (int)hipErrorInvalidValue;
-    // (one-launch passes always hand hit fields over: p.hit_fields is set for them)
+    // (one-launch passes stage their hits with their bit fields: p.hit_fields is set for them, for the hits of
+    // a tile that did not fit the staging)
     if (!p.hit_fields) return (int)hipErrorInvalidValue;
     if (from_mag)
         hipLaunchKernelGGL((k_scan_fast<true, false, true, true>), dim3(tiles), dim3(kThreads), 0, (hipStream_t)stream, p);

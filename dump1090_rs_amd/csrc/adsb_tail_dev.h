@@ -123,7 +123,19 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
 {
     // (SINGLE: other workgroups of this very launch, and this one's second look, counted hits in with
     // atomics a moment ago: read past any line this CU's cache may still hold)
-    const uint32_t n_hits_now = SINGLE ? __hip_atomic_load(&p.ctr->n_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.ctr->n_hits;
+    uint32_t n_hits_now = SINGLE ? __hip_atomic_load(&p.ctr->n_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.ctr->n_hits;
+    // SINGLE: the pass's workgroups have written `placed` records in place already (k_scan_fast: emit_records);
+    // the hit list holds only what the second look found (usually nothing), its records go behind those
+    uint32_t placed = 0;
+    if constexpr (SINGLE) {
+        placed = ld_shared<true>(&p.ctr->n_rec);
+        if (placed > p.hits_cap || n_hits_now > p.hits_cap - placed) {   // (emit_records has flagged its own overflow)
+            if (threadIdx.x == 0) atomicOr(&p.ctr->overflow, 1u);
+            placed = min(placed, p.hits_cap);
+            n_hits_now = 0;
+        }
+        rec += placed;
+    }
     const uint32_t n = min(n_hits_now, p.hits_cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Housekeeping so that no pass needs a reset launch: after an icao_flush retired a
@@ -493,7 +505,8 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned long long rs = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            const unsigned long long rs = wsum[0] + wsum[1] + wsum[2] + wsum[3] +
+                                          atomicAdd((unsigned long long *)p.ctr->rec_sum, 0ull);   // (+ the records built in place)
             ap = stot[0][0] + stot[0][1] + stot[0][2] + stot[0][3];
             cand = stot[1][0] + stot[1][1] + stot[1][2] + stot[1][3];
             uint32_t *sm = (uint32_t *)p.summary;
@@ -501,7 +514,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
             // how long the launch took, on the device's own clock (its first workgroup's entry to here)
             const unsigned long long t0 = (unsigned long long)__hip_atomic_load(&p.ctr->t_start[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32 |
                                           __hip_atomic_load(&p.ctr->t_start[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t vals[9] = {n_hits_now, ovf, (uint32_t)rs, p.ctr->n_dap,
+            const uint32_t vals[9] = {placed + n_hits_now, ovf, (uint32_t)rs, p.ctr->n_dap,
                                       ap + p.ctr->n_dap, cand + p.ctr->n_cand_simple, (uint32_t)(rs >> 32), p.seq,
                                       (uint32_t)((unsigned long long)wall_clock64() - t0)};
             host_store32(sm + 9, summary_check(vals));

@@ -124,21 +124,25 @@ def test_ring_slots_copied_in_front_of_their_pass(hip_lib, oracle_mod, per_slot,
             assert [(s,) + key(m) for s, m in got] == want
 
 
-def test_address_taught_early_in_a_buffer_reaches_a_frame_late_in_it_and_not_the_reverse(hip_lib, oracle_mod):
-    """One buffer, one launch, 17 workgroups that finish in any order: a DF17 in the first tile and
-    address/parity frames for its address in the last tiles must decode (score 1000), the mirrored buffer
-    -- frames first, DF17 last -- must not; both a hundred times over, blocking and pipelined."""
+@pytest.mark.parametrize("n_buf", [1, 8])
+def test_address_taught_early_in_a_buffer_reaches_a_frame_late_in_it_and_not_the_reverse(hip_lib, oracle_mod, n_buf):
+    """One launch, 17 workgroups per buffer that finish in any order: a DF17 in one tile and address/parity
+    frames for its address in the tiles behind it must decode (score 1000), the mirrored buffer -- frames
+    first, DF17 last -- must not; both a hundred times over, blocking and pipelined.  (Eight buffers: 136
+    workgroups -- a multiple of eight, the grid shape the large passes place by XCD -- with the pair in the
+    last buffer, tiles next to each other included.)"""
     import torch
     from dump1090_rs_amd import Context
     icao = 0x3C6589
     df4 = ap_frame(bytes([0x20, 0x00, 0x05, 0x30]), icao)
     df21 = ap_frame(bytes([0xA8, 0x00, 0x05, 0x30, 9, 8, 7, 6, 5, 4, 3]), icao)
-    fwd = synth.noise_numpy(CHUNK, seed=77)
-    synth.add_bursts(fwd, [synth.Burst(5 * 700 + 2, 23000, 1, synth.df17_frame(icao, 1))] +
-                     [synth.Burst(5 * (100000 + 4000 * q) + q % 5, 21000, q, df4 if q % 2 else df21) for q in range(7)])
-    rev = synth.noise_numpy(CHUNK, seed=78)
-    synth.add_bursts(rev, [synth.Burst(5 * (1000 + 4000 * q) + q % 5, 21000, q, df4 if q % 2 else df21) for q in range(7)] +
-                     [synth.Burst(5 * 126000 + 2, 23000, 1, synth.df17_frame(icao, 1))])
+    base = 5 * (n_buf - 1) * CHUNK
+    fwd = synth.noise_numpy(n_buf * CHUNK, seed=77)
+    synth.add_bursts(fwd, [synth.Burst(base + 5 * 700 + 2, 23000, 1, synth.df17_frame(icao, 1))] +
+                     [synth.Burst(base + 5 * (9000 + 16000 * q) + q % 5, 21000, q, df4 if q % 2 else df21) for q in range(7)])
+    rev = synth.noise_numpy(n_buf * CHUNK, seed=78)
+    synth.add_bursts(rev, [synth.Burst(base + 5 * (1000 + 16000 * q) + q % 5, 21000, q, df4 if q % 2 else df21) for q in range(7)] +
+                     [synth.Burst(base + 5 * 126000 + 2, 23000, 1, synth.df17_frame(icao, 1))])
     orc = oracle_mod.Oracle()
     w_fwd, _ = orc.demod_iq(fwd)
     orc.icao_flush()
@@ -147,25 +151,27 @@ def test_address_taught_early_in_a_buffer_reaches_a_frame_late_in_it_and_not_the
     assert len(ap(w_fwd)) >= 7 and all(w["score"] == 1000 for w in ap(w_fwd)) and not ap(w_rev)
     d_fwd, d_rev = torch.from_numpy(fwd).cuda(), torch.from_numpy(rev).cuda()
     torch.cuda.synchronize()
-    with Context(0, 1) as c:
+    CHUNKS = n_buf * CHUNK
+    with Context(0, n_buf) as c:
         # polls = 0: no workgroup waits for the tiles before it (adsb_selftest_set_order_polls), so whenever the
         # pass learns an address its last workgroup looks at every list once more -- the fallback, on purpose
         for polls in (200, 0):
             assert c._L.adsb_selftest_set_order_polls(c._h, polls) == 0
             for rep in range(100):
                 c.icao_flush()
-                assert [key(m) for m in c.demod_iq_device(d_fwd.data_ptr(), CHUNK)] == [want_key(w) for w in w_fwd]
+                assert [key(m) for m in c.demod_iq_device(d_fwd.data_ptr(), CHUNKS)] == [want_key(w) for w in w_fwd]
                 c.icao_flush()
-                assert [key(m) for m in c.demod_iq_device(d_rev.data_ptr(), CHUNK)] == [want_key(w) for w in w_rev]
+                assert [key(m) for m in c.demod_iq_device(d_rev.data_ptr(), CHUNKS)] == [want_key(w) for w in w_rev]
             for rep in range(50):   # pipelined, a flush in front of each: four one-launch passes in flight
                 for d in (d_fwd, d_rev, d_fwd, d_rev):
                     c.icao_flush()
-                    c.submit_iq_device(d.data_ptr(), CHUNK)
+                    c.submit_iq_device(d.data_ptr(), CHUNKS)
                 for w in (w_fwd, w_rev, w_fwd, w_rev):
                     assert [key(m) for m in c.collect()] == [want_key(x) for x in w]
             # caller-supplied magnitudes take the same one-launch form (adsb_demodulate2400)
-            c.icao_flush()
-            assert [key(m) for m in c.demodulate2400(c.to_mag(fwd))] == [want_key(w) for w in w_fwd]
+            if n_buf == 1:
+                c.icao_flush()
+                assert [key(m) for m in c.demodulate2400(c.to_mag(fwd))] == [want_key(w) for w in w_fwd]
 
 
 @pytest.mark.parametrize("n_chunks,cut", [(1, 0), (1, 50000), (2, 131071), (5, 4321), (16, 0), (16, 99), (17, 0), (17, 5000)])
