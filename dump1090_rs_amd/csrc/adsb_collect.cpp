@@ -73,9 +73,20 @@ void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, ui
             order[i] = {replay_key(rec[i]), (uint32_t)i};
             all_or |= order[i].key;
         }
+        if (n <= 96) {
+            // a pass of a buffer or two (its workgroups write their records as they find them): by insertion,
+            // stable, nothing to allocate or to count
+            for (size_t a = 1; a < n; a++) {
+                const Ref r = order[a];
+                size_t b = a;
+                for (; b > 0 && order[b - 1].key > r.key; b--) order[b] = order[b - 1];
+                order[b] = r;
+            }
+            all_or = 0;   // (sorted: the passes below all skip)
+        }
         // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
         // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
-        std::vector<Ref> tmp(n);
+        std::vector<Ref> tmp(all_or ? n : 0);
         Ref *src = order.data(), *dst = tmp.data();
         for (int shift = 0; shift < 64; shift += 11) {
             if (((all_or >> shift) & 0x7FFu) == 0) continue;

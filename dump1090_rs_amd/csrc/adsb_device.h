@@ -247,6 +247,7 @@ struct ScanParams {
     // ... a host-pointer call copies its samples into pinned memory WHILE the launch is on its way: how many
     // samples of src are there so far (a word in mapped host memory the copying thread advances; null: all)
     const unsigned long long *src_ready;
+    uint32_t src_host;      // one-launch pass: `src` is host memory read in place over the link (its tiles trickle in)
     uint32_t order_polls;   // ... how often a workgroup polls for the tiles before its own before it gives up
                             // (200, ~0.2 ms; the self-test hook sets 0: every tile gives up, the second look decides)
 };

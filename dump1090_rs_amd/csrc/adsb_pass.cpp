@@ -160,6 +160,9 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.order_polls = c->order_polls;
     p.src_ready = fused && !from_mag ? c->next_src_ready : nullptr;
     c->next_src_ready = nullptr;
+    static const bool no_trickle = tuning_env("ADSB_NO_TRICKLE") != nullptr;
+    p.src_host = fused && !from_mag && c->next_src_host && !no_trickle ? 1u : 0u;
+    c->next_src_host = false;
     // the scan hands the bit fields of its self-validating hits to the record builder: where the record
     // builder's instructions matter (dense streams: it shares the vector pipes with the next scan) and in
     // one-launch passes; a sparse stream's scan stays the lean instantiation

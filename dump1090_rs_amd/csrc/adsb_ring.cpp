@@ -69,7 +69,12 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
         const bool can = one_launch_pass(c, n_chunks) && !c->carry_over;
         in_place = can && mode == 0;
     }
-    if (in_place) return submit(c, r.h_iq_dev, false, n_samples, false, input_ready_now());
+    if (in_place) {
+        c->next_src_host = true;
+        const int rc = submit(c, r.h_iq_dev, false, n_samples, false, input_ready_now());
+        c->next_src_host = false;
+        return rc;
+    }
     {
         HT(c, HT_RING_MEMCPY);
         HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, next_scan_stream(c, n_chunks)));

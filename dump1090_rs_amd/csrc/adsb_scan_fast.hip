@@ -446,6 +446,10 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFi
 // IQ of one tile, as each thread holds it between the load and the magnitude pass:
 // 8 aligned dwordx4 = 32 samples per thread, 8080 per workgroup.
 constexpr int kLoadsPerThread = (kAllocSlots / 4 + kThreads - 1) / kThreads;  // 8
+#ifndef ADSB_TRICKLE
+#define ADSB_TRICKLE 3
+#endif
+constexpr int kTrickle = ADSB_TRICKLE;   // loads in flight per thread while a tile is read in place from host memory
 
 struct TileRef {
     uint32_t chunk;
@@ -521,6 +525,18 @@ __device__ __forceinline__ void load_tile_iq(const ScanParams &p, const TileRef 
         pre[0].z |= v.z;
         pre[0].w |= v.w;
     }
+}
+
+// Load i of the eight alone (a tile read in place from host memory, no carry-over: k_scan_fast trickles those).
+__device__ __forceinline__ void load_tile_iq_one(const ScanParams &p, const TileRef &r, int tid, uint4 (&pre)[kLoadsPerThread], int i)
+{
+    const uint32_t *iq = (const uint32_t *)p.src + r.chunk * (uint64_t)kChunkSamples;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)iq, 0, r.len * 4, 0x00020000);
+    const int k0 = r.jbase - kPad - kLead;
+    int off = (k0 + 4 * (tid + i * kThreads)) * 4;
+    asm volatile("" : "+v"(off));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    pre[i] = make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // A lane writes its own matches (bits of m; the branch 0..4 of each from the three code planes)
@@ -759,7 +775,21 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
             __syncthreads();
         }
     }
-    if (t_first < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t_first), tid, pre);
+    // A tile read in place from host memory keeps kTrickle of its eight loads in flight, not all of them: every
+    // request waits its turn in the same L2 queues as everything else on the device, and four passes side by
+    // side with 512 KB each outstanding put ~36 us of link time in front of any other miss -- the tables of a
+    // pass that is just starting, the address bits and list entries of one that is matching (seen: 17 us for
+    // the tables instead of 2).  Two loads per thread in flight already fill the link (tools/pcie_read_probe.hip); three measured best.
+    bool trickle = false;
+    if constexpr (FUSED && !FROM_MAG) trickle = p.src_host != 0u && p.carry == nullptr;
+    if (t_first < t_end) {
+        if (trickle) {
+#pragma unroll
+            for (int i = 0; i < kTrickle; i++) load_tile_iq_one(p, tile_ref<FROM_MAG>(p, t_first), tid, pre, i);
+        } else {
+            load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t_first), tid, pre);
+        }
+    }
 
     // Workgroups that share a CU start a fraction of a tile period apart, so that the
     // VALU-dense phases of one overlap the latency-bound phases of the others instead of
@@ -792,6 +822,12 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
     // ---------------------------------------------------------------- P1 magnitudes
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; i++) {
+        if constexpr (FUSED && !FROM_MAG) {
+            if (trickle && i + kTrickle < kLoadsPerThread) {   // load i has arrived: the next one may go
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTrickle - 1) : "memory");
+                load_tile_iq_one(p, cur, tid, pre, i + kTrickle);
+            }
+        }
         const int g = tid + i * kThreads;
         if (g < kAllocSlots / 4) *(uint2 *)(s.mag + 4 * g) = FROM_MAG ? make_uint2(pre[i].x, pre[i].y) : mag4_of(pre[i]);
     }
