@@ -982,15 +982,33 @@ def run_config1(env: Env):
         ctx.ring_submit(len(iq))
         return ctx.collect()
 
+    # the two ABI calls alone, as a compiled caller makes them (no Python list of messages built per call)
+    import ctypes as C
+    from dump1090_rs_amd._lib import AdsbMsg
+    raw_out, raw_n, L, h = (AdsbMsg * 4096)(), C.c_size_t(), ctx._L, ctx._h
+    iq_ptr, dev_ptr = iq.ctypes.data, C.c_void_p(dev.data_ptr())
+
+    def abi_host():
+        L.adsb_icao_flush(h)
+        L.adsb_demod_iq(h, iq_ptr, len(iq), raw_out, 4096, C.byref(raw_n))
+
+    def abi_dev():
+        L.adsb_icao_flush(h)
+        L.adsb_demod_iq_device(h, dev_ptr, len(iq), raw_out, 4096, C.byref(raw_n))
+
     out = {"workload": "icao_flush + to_mag + demodulate2400 on test_1641427457780.iq, 131072 samples "
                        "(benches/demod_benchmark.rs:7-12; BASELINE config 1)",
            "ms_to_mag_plus_demodulate2400": round(timeit(ref_api), 4),
            "ms_fused_host_iq": round(timeit(fused_host), 4),
            "ms_fused_resident_iq": round(timeit(fused_dev), 4),
            "ms_ring_pinned_iq": round(timeit(ring_pinned), 4),
+           "ms_fused_host_iq_c_abi": round(timeit(abi_host), 4),
+           "ms_fused_resident_iq_c_abi": round(timeit(abi_dev), 4),
            "timing": "mean of back-to-back calls over >= 0.6 s after 0.25 s of warm-up, each through the Python mirror "
-                     "of the reference's API (dump1090_rs_amd.Context); a call of one buffer is ONE launch "
-                     "(k_scan_fast<FUSED>), host IQ is copied once into pinned memory and read in place",
+                     "of the reference's API (dump1090_rs_amd.Context: a list of message objects built per call); "
+                     "*_c_abi: adsb_icao_flush + the one ABI call, as a compiled caller makes them.  A call of one "
+                     "buffer is ONE launch (k_scan_fast<FUSED>), host IQ is copied once into pinned memory and read in "
+                     "place while the copy is still going",
            "frames": len(fx["frames"]), "parity_checked": bool(ok),
            "published_reference_ms": PUBLISHED_CONFIG1_MS,
            "published_reference_note": "README.md:107, Intel i7-7700K, 1 thread, the Rust binary (other hardware)"}

@@ -525,6 +525,6 @@ const char *adsb_strerror(int status)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.17 gfx950 scan=v8-gate-reads tail=v5-one-launch"; }
+const char *adsb_version(void) { return "adsb_hip 0.18 gfx950 scan=v8-gate-reads tail=v6-records-in-place"; }
 
 }  // extern "C"

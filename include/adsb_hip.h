@@ -185,9 +185,10 @@ int adsb_fetch_messages(adsb_ctx *ctx, adsb_msg *out, size_t cap, size_t *n_out)
 /* Streaming ring for a host that produces IQ (an SDR read loop, dump1090_rs/src/main.rs:
  * 154-167): adsb_max_in_flight() (4 or 8) pinned host buffers of `samples_per_slot` samples (4 bytes
  * each) with a device staging buffer each.  Fill the buffer adsb_ring_acquire hands out (e.g.
- * read the SDR straight into it), adsb_ring_submit(n) starts its host-to-device copy on a copy
- * stream and the pass behind it, adsb_collect returns the oldest pass's messages.  While one
- * slot's pass runs, the next slots' transfers are in flight.  samples_per_slot may not exceed the
+ * read the SDR straight into it), adsb_ring_submit(n) starts the slot's pass -- one launch that
+ * reads a slot of one or two buffers in place over the link; larger slots are copied first, on the
+ * pass's own stream --, adsb_collect returns the oldest pass's messages.  While one slot's pass
+ * runs, the next slots' transfers are in flight.  samples_per_slot may not exceed the
  * context's max_chunks buffers; adsb_ring_acquire returns ADSB_ERR_BUSY until the pass
  * that last used the slot has been collected. */
 int adsb_ring_create(adsb_ctx *ctx, size_t samples_per_slot);
