@@ -267,13 +267,18 @@ def main():
     ring_chunks = min(2, args.max_chunks)
     ctx.ring_create(ring_chunks * CHUNK)
     shard_ctx = [Context(0, args.max_chunks), Context(0, args.max_chunks)]
+    # a ring of larger slots: three buffers and more per slot are copied in front of their pass (on its own
+    # stream) when another pass is in flight, the first one of a burst is read in place (adsb_ring.cpp)
+    big_chunks = max(3, min(5, args.max_chunks))
+    ctx_big = Context(0, big_chunks)
+    ctx_big.ring_create(big_chunks * CHUNK)
     t0 = time.time()
     modes = {}
     for case in range(args.cases):
         iq, seed = make_case(rng, synth, args.max_chunks)
         n = len(iq)
         carry_mode = rng.random() < 0.35
-        api = str(rng.choice(["host", "device", "pipelined", "ring", "shards", "magbuf"]))
+        api = str(rng.choice(["host", "device", "pipelined", "ring", "ring", "shards", "magbuf"]))
         if carry_mode and api in ("shards", "magbuf"):
             api = "device"
         ncuts = int(rng.integers(1, 4))
@@ -314,8 +319,16 @@ def main():
                 gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
                 pend -= 1
         elif api == "ring":
-            # the ring takes at most ring_chunks buffers per slot: cut accordingly (oracle redone to match)
-            cuts = list(range(0, n, ring_chunks * CHUNK)) + [n]
+            # the ring takes at most ring_chunks buffers per slot: cut accordingly (oracle redone to match);
+            # every other time the ring of larger slots, a random slot length (3 .. 5 buffers, ragged), 2 .. 4 deep
+            rctx, per_slot, depth = ctx, ring_chunks * CHUNK, 2
+            if rng.random() < 0.5:
+                rctx, depth = ctx_big, int(rng.integers(2, 5))
+                per_slot = int(rng.integers(2 * CHUNK + 4, big_chunks * CHUNK + 1)) // 4 * 4
+                rctx.set_carry_over(carry_mode)
+                rctx.icao_flush()
+                modes[("ring:copied", carry_mode)] = modes.get(("ring:copied", carry_mode), 0) + 1
+            cuts = list(range(0, n, per_slot)) + [n]
             orc = binding.Oracle()
             carry = np.zeros((326, 2), np.int16)
             wants = []
@@ -324,15 +337,15 @@ def main():
                 wants.append([okey(x) for x in w])
             pend = 0
             for a, b in zip(cuts[:-1], cuts[1:]):
-                if pend == 2:
-                    gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
+                if pend == depth:
+                    gots.append([key(m) for m in rctx.collect(cap=1 << 20)])
                     pend -= 1
-                buf = ctx.ring_acquire()
+                buf = rctx.ring_acquire()
                 buf[: b - a] = iq[a:b]
-                ctx.ring_submit(b - a)
+                rctx.ring_submit(b - a)
                 pend += 1
             while pend:
-                gots.append([key(m) for m in ctx.collect(cap=1 << 20)])
+                gots.append([key(m) for m in rctx.collect(cap=1 << 20)])
                 pend -= 1
         elif api == "magbuf":
             # the reference's two-call shape, one 131072-sample buffer at a time (filter persists)
