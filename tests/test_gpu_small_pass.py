@@ -240,3 +240,36 @@ def test_one_launch_passes_between_long_passes_and_flushes(hip_lib, oracle_mod):
             while c.pending():
                 got.append([key(m) for m in c.collect()])
             assert got == want, (rep, [i for i, (g, w) in enumerate(zip(got, want)) if g != w])
+
+
+@pytest.mark.parametrize("n_buf", [1, 8])
+def test_a_buffer_packed_with_frames_takes_every_record_path(hip_lib, oracle_mod, n_buf):
+    """Frames back to back (one every 300 samples: ~25 a tile, each decoding at several positions and phases):
+    more hits in a tile than its staging holds (32: the rest goes through the hit list and the record
+    builder at the end, behind the records built in place), address/parity frames matched inline for
+    addresses taught a few frames earlier; eight such buffers overflow the pass's record capacity, and
+    the pass is redone buffer by buffer.  One-launch passes throughout, against the oracle."""
+    from dump1090_rs_amd import Context
+    n = n_buf * CHUNK
+    iq = synth.noise_numpy(n, seed=4242 + n_buf)
+    bursts = []
+    for k in range(n // 300 - 2):
+        icao = 0x400000 + (k % 37) * 0x101
+        kind = k % 4
+        frame = (synth.df17_frame(icao, k) if kind in (0, 1) else synth.df11_frame(icao) if kind == 2
+                 else ap_frame(bytes([0x20, 0x00, 0x05, 0x30]), icao))
+        bursts.append(synth.Burst(5 * (300 * k + 40) + k % 5, 18000 + 500 * (k % 9), k, frame))
+    synth.add_bursts(iq, bursts)
+    want, _ = oracle_mod.Oracle().demod_iq(iq, cap=1 << 20)
+    assert len(want) > 300 * n_buf
+    with Context(0, n_buf) as c:
+        for rep in range(3):
+            c.icao_flush()
+            got = c.demod_iq(iq, cap=1 << 20)
+            assert [key(m) for m in got] == [want_key(w) for w in want]
+            st = c.stats()
+            assert st["n_records"] >= len(want)
+            if n_buf == 1:
+                assert st["retries"] == 0 and st["n_records"] > 2 * 32 * 17   # ~94 hits a tile: staging holds 32
+            if n_buf == 8:
+                assert st["retries"] > 0       # (4096 + 8 * 1024 records do not hold this pass: the fallback ran)
