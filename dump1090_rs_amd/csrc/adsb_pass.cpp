@@ -199,6 +199,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         }
         if (ready) HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
     }
+    // (a ring slot's copy was queued on the stream adsb_ring_submit expected this pass to take -- the same rule as
+    // above, in next_scan_stream(); should the two ever disagree, the pass waits for that stream)
+    if (c->input_on_stream && c->input_on_stream != ss) {
+        HIP_TRY(c, hipEventRecord(c->lazy_ev, c->input_on_stream));
+        HIP_TRY(c, hipStreamWaitEvent(ss, c->lazy_ev, 0));
+    }
     // (0) the slot's lists and counters: a one-launch pass that used them last on another stream may still
     //     be zeroing them (the host goes by its summary, which it writes just before)
     if (sl.fused_q && sl.fused_q != ss) {

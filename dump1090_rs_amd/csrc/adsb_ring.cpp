@@ -75,11 +75,16 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
         c->next_src_host = false;
         return rc;
     }
+    hipStream_t q = next_scan_stream(c, n_chunks);
     {
         HT(c, HT_RING_MEMCPY);
-        HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, next_scan_stream(c, n_chunks)));
+        HIP_TRY(c, hipMemcpyAsync(r.d_iq, r.h_iq, n_samples * 4, hipMemcpyHostToDevice, q));
     }
-    return submit(c, r.d_iq, false, n_samples, false, input_ready_now());
+    // (enqueue_pass checks that the pass does land on q, and orders it behind q with an event if it ever does not)
+    c->input_on_stream = q;
+    const int rc = submit(c, r.d_iq, false, n_samples, false, input_ready_now());
+    c->input_on_stream = nullptr;
+    return rc;
 }
 
 }  // extern "C"

@@ -398,16 +398,26 @@ __device__ __forceinline__ void put_hit_fields(const ScanParams &p, size_t place
 // what the scan's vector pipes share their cycles with, and one-launch passes).  The sparse stream's
 // instantiation stays at 102 registers and 31.2 KB: two registers more and a fifth workgroup no longer
 // fits a CU while consecutive launches overlap (measured: +3 % on the pipelined step).
-template <bool FIELDS>
+// A one-launch pass (FUSED) stages kFusedExtraHits more per tile: its workgroups build the records of what is
+// staged themselves (emit_record), what is not goes through the hit list to ONE workgroup at the end -- a buffer
+// packed with frames (~94 hits a tile) took 0.22 ms that way.
+constexpr int kFusedExtraHits = 96;
+template <bool FIELDS, bool FUSED = false>
 struct HitFieldLds {
     uint32_t f[kHitCap][5];   // the five bit-class fields of each staged hit (ScanParams::hit_fields)
 };
 template <>
-struct HitFieldLds<false> {
+struct HitFieldLds<true, true> {
+    uint32_t f[kHitCap][5];
+    uint64_t xhit[kFusedExtraHits];      // staged hits kHitCap .. kHitCap + kFusedExtraHits - 1 of the tile
+    uint32_t xf[kFusedExtraHits][5];
+};
+template <bool FUSED>
+struct HitFieldLds<false, FUSED> {
 };
 
 template <bool FUSED, bool FIELDS>
-__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS> &hf, bool is_hit, uint64_t entry,
+__device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS, FUSED> &hf, bool is_hit, uint64_t entry,
                                           int lane, uint32_t par, const uint32_t (&f)[5])
 {
     const unsigned long long mh = __ballot(is_hit);
@@ -421,6 +431,12 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFi
             if constexpr (FIELDS) {
 #pragma unroll
                 for (int r = 0; r < 5; r++) hf.f[at][r] = f[r];
+            }
+        } else if (FUSED && FIELDS && at < (uint32_t)(kHitCap + kFusedExtraHits)) {
+            if constexpr (FUSED && FIELDS) {
+                hf.xhit[at - kHitCap] = entry;
+#pragma unroll
+                for (int r = 0; r < 5; r++) hf.xf[at - kHitCap][r] = f[r];
             }
         } else {  // more hits in one tile than the staging holds: one by one
             const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
@@ -584,7 +600,7 @@ __device__ __forceinline__ void gate_pass(const ScanParams &p, const FastLds &s,
 
 // One 64-lane pass of the trials: lane = (candidate entry ce, try_phase 4 + tpi).
 template <bool FUSED, bool FIELDS>
-__device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS> &hf, uint32_t ce, uint32_t tpi,
+__device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitFieldLds<FIELDS, FUSED> &hf, uint32_t ce, uint32_t tpi,
                                            bool live, int jbase, uint32_t chunk, uint64_t *seg, uint32_t seg_cap,
                                            uint32_t &ap_count, int lane, uint32_t par)
 {
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
 {
     __shared__ FastLds s;
     __shared__ FusedLds<FUSED> fs;
-    __shared__ HitFieldLds<FIELDS> hf;
+    __shared__ HitFieldLds<FIELDS, FUSED> hf;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t n_tiles = p.n_chunks * kTilesPerChunk;
@@ -1088,11 +1104,13 @@ tile_end:
     if constexpr (FUSED && FIELDS) {
         // one-launch pass: the staged hits' records are built here and now, a wave a hit (emit_record); only what
         // did not fit the staging went to the hit list (stage_hit), for the record builder at the end
-        for (uint32_t i = (uint32_t)(tid >> 6); i < nhit; i += (uint32_t)kWaves) {
-            const uint64_t me = s.hit[i];
+        const uint32_t nstaged = min(s.nhit[par], (uint32_t)(kHitCap + kFusedExtraHits));
+        for (uint32_t i = (uint32_t)(tid >> 6); i < nstaged; i += (uint32_t)kWaves) {
+            const bool extra = i >= (uint32_t)kHitCap;   // (wave-uniform)
+            const uint64_t me = extra ? hf.xhit[i - kHitCap] : s.hit[i];
             uint32_t ff[5];
 #pragma unroll
-            for (int r = 0; r < 5; r++) ff[r] = hf.f[i][r];
+            for (int r = 0; r < 5; r++) ff[r] = extra ? hf.xf[i - kHitCap][r] : hf.f[i][r];
             emit_record(p, s, ff, (uint32_t)((int)entry_j(me) - (jbase - kPad)), me, entry_value(me), lane);
         }
     } else
