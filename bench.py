@@ -996,6 +996,14 @@ def run_config1(env: Env):
         L.adsb_icao_flush(h)
         L.adsb_demod_iq_device(h, dev_ptr, len(iq), raw_out, 4096, C.byref(raw_n))
 
+    # the caller's own buffer registered once (adsb_host_register: main.rs reads the SDR into one Vec for ever)
+    own = iq.copy()
+    own_ptr = own.ctypes.data
+
+    def abi_registered():
+        L.adsb_icao_flush(h)
+        L.adsb_demod_iq(h, own_ptr, len(own), raw_out, 4096, C.byref(raw_n))
+
     out = {"workload": "icao_flush + to_mag + demodulate2400 on test_1641427457780.iq, 131072 samples "
                        "(benches/demod_benchmark.rs:7-12; BASELINE config 1)",
            "ms_to_mag_plus_demodulate2400": round(timeit(ref_api), 4),
@@ -1004,6 +1012,7 @@ def run_config1(env: Env):
            "ms_ring_pinned_iq": round(timeit(ring_pinned), 4),
            "ms_fused_host_iq_c_abi": round(timeit(abi_host), 4),
            "ms_fused_resident_iq_c_abi": round(timeit(abi_dev), 4),
+           "ms_fused_registered_host_iq_c_abi": None,
            "timing": "mean of back-to-back calls over >= 0.6 s after 0.25 s of warm-up, each through the Python mirror "
                      "of the reference's API (dump1090_rs_amd.Context: a list of message objects built per call); "
                      "*_c_abi: adsb_icao_flush + the one ABI call, as a compiled caller makes them.  A call of one "
@@ -1012,6 +1021,11 @@ def run_config1(env: Env):
            "frames": len(fx["frames"]), "parity_checked": bool(ok),
            "published_reference_ms": PUBLISHED_CONFIG1_MS,
            "published_reference_note": "README.md:107, Intel i7-7700K, 1 thread, the Rust binary (other hardware)"}
+    ctx.host_register(own)
+    ctx.icao_flush()
+    out["parity_checked"] = bool(out["parity_checked"] and [m.buffer().hex() for m in ctx.demod_iq(own)] == fx["frames"])
+    out["ms_fused_registered_host_iq_c_abi"] = round(timeit(abi_registered), 4)
+    ctx.host_unregister(own)
     orc = binding.Oracle()
     reps, t = 30, time.perf_counter()
     for _ in range(reps):

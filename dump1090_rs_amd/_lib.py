@@ -130,6 +130,10 @@ def lib() -> C.CDLL:
     L.adsb_selftest_crc_table.restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]
     L.adsb_host_replays.restype = C.c_uint64
+    L.adsb_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.adsb_host_register.restype = C.c_int
+    L.adsb_host_unregister.argtypes = [vp, C.c_void_p]
+    L.adsb_host_unregister.restype = C.c_int
     L.adsb_host_rematches.argtypes = [vp]
     L.adsb_host_rematches.restype = C.c_uint64
     L.adsb_host_sorts.argtypes = [vp]

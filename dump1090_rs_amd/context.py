@@ -262,6 +262,14 @@ class Context:
         self._check(st, "adsb_shard_finish")
         return rec[: n.value].copy()
 
+    # -- a buffer the caller keeps (main.rs:154-167 reads the SDR into one Vec for ever): pinned and mapped once,
+    #    demod_iq on samples inside it reads them in place
+    def host_register(self, a: np.ndarray) -> None:
+        self._check(self._L.adsb_host_register(self._h, a.ctypes.data, a.nbytes), "adsb_host_register")
+
+    def host_unregister(self, a: np.ndarray) -> None:
+        self._check(self._L.adsb_host_unregister(self._h, a.ctypes.data), "adsb_host_unregister")
+
     # -- streaming ring: pinned host buffers, H2D overlapped with the other slot's pass
     def ring_create(self, samples_per_slot: int) -> None:
         self._check(self._L.adsb_ring_create(self._h, samples_per_slot), "adsb_ring_create")

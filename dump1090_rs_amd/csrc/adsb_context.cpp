@@ -310,6 +310,7 @@ void adsb_destroy(adsb_ctx *c)
     if (c->fb.d_hits) (void)hipFree(c->fb.d_hits);
     if (c->fb.d_dap) (void)hipFree(c->fb.d_dap);
     if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
+    for (const auto &r : c->host_ranges) (void)hipHostUnregister(r.base);
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &r : c->ring) {
         if (r.h_iq) (void)hipHostFree(r.h_iq);

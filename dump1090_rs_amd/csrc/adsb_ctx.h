@@ -149,6 +149,13 @@ struct adsb_ctx {
     uint64_t rematches = 0;                 // one-launch passes redone because a pass in flight beside them did
     uint32_t order_polls = 200;             // ScanParams::order_polls (adsb_selftest_set_order_polls)
     const unsigned long long *next_src_ready = nullptr;  // ScanParams::src_ready of the next pass enqueued (adsb_demod_iq)
+    // adsb_host_register: the caller's buffers, pinned and mapped (adsb_demod_iq reads samples inside them in place)
+    struct HostRange {
+        char *base = nullptr;
+        size_t bytes = 0;
+        char *dev = nullptr;
+    };
+    std::vector<HostRange> host_ranges;
     hipStream_t input_on_stream = nullptr;   // the next pass's input is a copy queued on this stream (the ring): it must run behind it
     bool next_src_host = false;    // ... reads host memory in place (ScanParams::src_host)
     hipEvent_t input_ready[kScanStreams] = {};  // per scan stream: `stream` at submit (the caller's IQ is complete)

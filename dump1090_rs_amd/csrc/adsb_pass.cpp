@@ -573,6 +573,20 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
     // A call of a few buffers (the reference's own call shape, benches/demod_benchmark.rs:10-11: one
     // 131072-sample buffer) is one launch that reads the samples in place from pinned host memory: one
     // host copy into it instead of a copy command, its staging inside the runtime and an event.
+    // Samples inside a buffer the caller registered (adsb_host_register) are pinned and mapped already: one launch
+    // that reads them where they are, no host copy at all.
+    if (n_samples && n_samples <= std::min<size_t>(piece, (size_t)kInlineTailChunks * kChunkSamples) && !c->carry_over &&
+        ((uintptr_t)iq & 15u) == 0) {
+        const char *b = reinterpret_cast<const char *>(iq);
+        for (const auto &r : c->host_ranges)
+            if (b >= r.base && b + n_samples * 4 <= r.base + r.bytes) {
+                if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+                int rc = run_sync(c, r.dev + (b - r.base), false, n_samples, msgs, input_ready_now());
+                if (rc) return rc;
+                c->stats.n_samples = n_samples;
+                return deliver(c, msgs, out, cap, n_out);
+            }
+    }
     const bool in_place = n_samples <= (size_t)kInlineTailChunks * kChunkSamples && !c->carry_over;
     int rc = in_place ? ensure_host_stage(c, std::max<size_t>(n_samples, 1) * 4 + 512)   // (+ the progress word)
                       : ensure_stage(c, std::min(piece, std::max<size_t>(n_samples, 1)) * 4);

@@ -87,4 +87,39 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     return rc;
 }
 
+int adsb_host_register(adsb_ctx *c, void *host_ptr, size_t bytes)
+{
+    if (!c || !host_ptr || bytes == 0) return ADSB_ERR_INVALID;
+    char *b = static_cast<char *>(host_ptr);
+    for (const auto &r : c->host_ranges)
+        if (b < r.base + r.bytes && r.base < b + bytes) return ADSB_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipHostRegister(host_ptr, bytes, hipHostRegisterMapped));
+    void *dev = nullptr;
+    if (hipError_t e = hipHostGetDevicePointer(&dev, host_ptr, 0); e != hipSuccess) {
+        (void)hipHostUnregister(host_ptr);
+        return fail(c, e, "hipHostGetDevicePointer");
+    }
+    adsb_ctx::HostRange r;
+    r.base = b;
+    r.bytes = bytes;
+    r.dev = static_cast<char *>(dev);
+    c->host_ranges.push_back(r);
+    return ADSB_OK;
+}
+
+int adsb_host_unregister(adsb_ctx *c, void *host_ptr)
+{
+    if (!c || !host_ptr) return ADSB_ERR_INVALID;
+    if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
+    for (size_t k = 0; k < c->host_ranges.size(); k++)
+        if (c->host_ranges[k].base == static_cast<char *>(host_ptr)) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipHostUnregister(host_ptr));
+            c->host_ranges.erase(c->host_ranges.begin() + (long)k);
+            return ADSB_OK;
+        }
+    return ADSB_ERR_INVALID;
+}
+
 }  // extern "C"

@@ -195,6 +195,15 @@ int adsb_ring_create(adsb_ctx *ctx, size_t samples_per_slot);
 int adsb_ring_acquire(adsb_ctx *ctx, int16_t **host_iq_re_im, size_t *capacity_samples);
 int adsb_ring_submit(adsb_ctx *ctx, size_t n_samples);
 
+/* For a host that keeps its own sample buffer (the Vec the SDR reads land in, dump1090_rs/src/main.rs:
+ * 154-167, is allocated once): pin it and map it for the device, so that adsb_demod_iq on samples
+ * INSIDE it (16-byte aligned start, at most 16 buffers) reads them in place over the link -- one kernel
+ * launch, no copy of the samples on the host.  The memory stays the caller's; it must not be freed
+ * before adsb_host_unregister (adsb_destroy unregisters what is left).  Samples outside any registered
+ * range take the usual path.  ADSB_ERR_INVALID for a range that overlaps a registered one. */
+int adsb_host_register(adsb_ctx *ctx, void *host_ptr, size_t bytes);
+int adsb_host_unregister(adsb_ctx *ctx, void *host_ptr);
+
 /* src/utils.rs:23-40 read_test_data: file pairs are [im][re] little-endian;
  * writes in-memory {re, im}.  Returns samples read via *n_out. */
 int adsb_read_test_data(const char *path, int16_t *iq_re_im, size_t max_samples, size_t *n_out);

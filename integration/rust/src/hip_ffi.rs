@@ -97,6 +97,8 @@ unsafe extern "C" {
     pub fn adsb_get_stats(ctx: *const AdsbCtx, out: *mut AdsbStats) -> c_int;
     pub fn adsb_host_sorts(ctx: *const AdsbCtx) -> u64;
     pub fn adsb_host_replays(ctx: *const AdsbCtx) -> u64;
+    pub fn adsb_host_register(ctx: *mut AdsbCtx, host_ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn adsb_host_unregister(ctx: *mut AdsbCtx, host_ptr: *mut c_void) -> c_int;
     pub fn adsb_host_rematches(ctx: *const AdsbCtx) -> u64;
     pub fn adsb_strerror(status: c_int) -> *const c_char;
     pub fn adsb_last_error(ctx: *const AdsbCtx) -> *const c_char;

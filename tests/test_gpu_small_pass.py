@@ -273,3 +273,44 @@ def test_a_buffer_packed_with_frames_takes_every_record_path(hip_lib, oracle_mod
                 assert st["retries"] == 0 and st["n_records"] > 2 * 32 * 17   # ~94 hits a tile: staging holds 32
             if n_buf == 8:
                 assert st["retries"] > 0       # (4096 + 8 * 1024 records do not hold this pass: the fallback ran)
+
+
+def test_samples_in_a_registered_host_buffer_are_read_in_place(hip_lib, oracle_mod):
+    """adsb_host_register: the caller's own buffer (the reference's main loop reads the SDR into one Vec,
+    main.rs:154-167) pinned and mapped once; adsb_demod_iq on samples inside it is one launch that reads them
+    where they are -- whole, a window of it at a 16-byte aligned offset, rewritten between calls; a window at an
+    odd offset, samples outside it, and more buffers than one launch takes go the usual way.  Same frames."""
+    from dump1090_rs_amd import Context
+    n = 6 * CHUNK
+    big = np.zeros((n + 64, 2), dtype=np.int16)
+    iq = synth.make_iq(n, n_bursts=200, seed=6060, n_icao=12, df11_every=4)
+    other = synth.make_iq(2 * CHUNK, n_bursts=60, seed=6061, n_icao=12, df11_every=4)
+    big[:n] = iq
+    orc = oracle_mod.Oracle()
+    with Context(0, 6) as c:
+        c.host_register(big)
+        with pytest.raises(Exception):
+            c.host_register(big[100:200])                       # overlaps
+        for a, b in ((0, n), (4 * 1000, 4 * 1000 + 2 * CHUNK + 777), (3, CHUNK + 3), (8, 8 + CHUNK)):
+            orc.icao_flush()
+            c.icao_flush()
+            want = [want_key(w) for w in orc.demod_iq(big[a:b])[0]]
+            assert [key(m) for m in c.demod_iq(big[a:b])] == want
+            assert c.stats()["n_samples"] == b - a
+        # the host rewrites its buffer between calls, as an SDR read does
+        for rep in range(20):
+            src = other if rep % 2 else iq[CHUNK:3 * CHUNK]
+            big[:2 * CHUNK] = src
+            orc.icao_flush()
+            c.icao_flush()
+            assert [key(m) for m in c.demod_iq(big[:2 * CHUNK])] == [want_key(w) for w in orc.demod_iq(src)[0]]
+        # a buffer that is not registered, and the registered one after unregistering
+        orc.icao_flush()
+        c.icao_flush()
+        assert [key(m) for m in c.demod_iq(other)] == [want_key(w) for w in orc.demod_iq(other)[0]]
+        c.host_unregister(big)
+        with pytest.raises(Exception):
+            c.host_unregister(big)
+        orc.icao_flush()
+        c.icao_flush()
+        assert [key(m) for m in c.demod_iq(big[:n])] == [want_key(w) for w in orc.demod_iq(big[:n])[0]]
