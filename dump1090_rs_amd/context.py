@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import struct
 import os
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -49,8 +50,14 @@ class ModeSMessage:
         return self.msg[: self.msglen]
 
 
+_MSG_STRUCT = struct.Struct("<14sBBiIQd")   # adsb_msg (include/adsb_hip.h): msg, len, try_phase, score, j, chunk, signal_level
+assert _MSG_STRUCT.size == C.sizeof(AdsbMsg)
+
+
 def _as_iq(iq) -> np.ndarray:
     """Accept (N,2) int16 [re, im] rows, flat interleaved int16, or complex arrays of ints."""
+    if type(iq) is np.ndarray and iq.dtype == np.int16 and iq.ndim == 2 and iq.shape[1] == 2 and iq.flags.c_contiguous:
+        return iq
     a = np.asarray(iq)
     if np.iscomplexobj(a):
         a = np.stack([a.real, a.imag], axis=-1)
@@ -142,20 +149,21 @@ class Context:
         # a one-buffer pass takes)
         if getattr(self, "_out_cap", 0) != cap:
             self._out_buf, self._out_cap = (AdsbMsg * cap)(), cap
-        buf = self._out_buf
+            self._out_view = memoryview(self._out_buf).cast("B")
+        buf, view = self._out_buf, self._out_view
         n = C.c_size_t()
         st = call(buf, cap, C.byref(n))
         if st == _lib.ADSB_ERR_CAPACITY:
             # the pass is consumed (the filter has advanced): never repeat the call, fetch its list
             cap = n.value
             buf = (AdsbMsg * cap)()
+            view = memoryview(buf).cast("B")
             st = self._L.adsb_fetch_messages(self._h, buf, cap, C.byref(n))
         self._check(st, what)
-        return [
-            ModeSMessage(bytes(m.msg), int(m.len), float(m.signal_level), int(m.score),
-                         int(m.j), int(m.try_phase), int(m.chunk))
-            for m in buf[: n.value]
-        ]
+        # (adsb_msg unpacked in one go: field by field through ctypes a list of five messages cost 11 us, more
+        # than a quarter of the call that produced it)
+        return [ModeSMessage(m, ln, sig, score, j, tp, chunk)
+                for (m, ln, tp, score, j, chunk, sig) in _MSG_STRUCT.iter_unpack(view[: _MSG_STRUCT.size * n.value])]
 
     def demodulate2400(self, mag: MagnitudeBuffer, cap: int = 4096) -> List[ModeSMessage]:
         data = np.ascontiguousarray(mag.data, dtype=np.uint16)
@@ -171,8 +179,9 @@ class Context:
     def demod_iq(self, iq, cap: Optional[int] = None) -> List[ModeSMessage]:
         a = _as_iq(iq)
         cap = cap or max(4096, a.shape[0] // 256)
+        ptr = a.__array_interface__["data"][0]   # (a.ctypes.data builds an object per call: 1.8 us against 1.1)
         return self._collect(
-            lambda out, c, n: self._L.adsb_demod_iq(self._h, a.ctypes.data, a.shape[0], out, c, n),
+            lambda out, c, n: self._L.adsb_demod_iq(self._h, ptr, a.shape[0], out, c, n),
             "adsb_demod_iq", cap)
 
     def demod_iq_device(self, device_ptr: int, n_samples: int, cap: Optional[int] = None
