@@ -135,9 +135,11 @@ class Context:
 
     def to_mag(self, iq) -> MagnitudeBuffer:
         a = _as_iq(iq)
-        out = MagnitudeBuffer()
+        # (the library writes all 131398 entries, lead-in and tail zeros included: no need to zero them first)
+        out = MagnitudeBuffer(data=np.empty(MAG_DATA_LEN, dtype=np.uint16))
         n = C.c_size_t()
-        st = self._L.adsb_to_mag(self._h, a.ctypes.data, a.shape[0], out.data.ctypes.data, C.byref(n))
+        st = self._L.adsb_to_mag(self._h, a.__array_interface__["data"][0], a.shape[0],
+                                 out.data.__array_interface__["data"][0], C.byref(n))
         if st == _lib.ADSB_ERR_TOO_LONG:
             raise IndexError("to_mag: more than 131072 samples (the reference panics here)")
         self._check(st, "adsb_to_mag")
@@ -172,7 +174,7 @@ class Context:
         if mag.length > MODES_MAG_BUF_SAMPLES:
             raise IndexError("MagnitudeBuffer.length > 131072")
         return self._collect(
-            lambda out, c, n: self._L.adsb_demodulate2400(self._h, data.ctypes.data, mag.length, out, c, n),
+            lambda out, c, n: self._L.adsb_demodulate2400(self._h, data.__array_interface__["data"][0], mag.length, out, c, n),
             "adsb_demodulate2400", cap)
 
     # -- stream forms (to_mag + demodulate2400 per 131072-sample buffer)
