@@ -58,7 +58,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     subprocess.run(cmd, check=True)
     # the file/pipe -> "*hex;" feeder (host only, plain C++ over the C ABI); finds the library
     # next to itself
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", str(FEED_SRC), "-o", str(FEED),
+    cmd = ["g++", "-O3", "-std=c++17", "-Wall", "-Wextra", str(FEED_SRC), "-o", str(FEED),
            f"-L{PKG}", "-ladsb_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)

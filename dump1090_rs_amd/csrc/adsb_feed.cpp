@@ -269,12 +269,13 @@ int main(int argc, char **argv)
             short_passes++;
         }
         const size_t n = bytes / 4;
-        if (!mem_order)  // file pairs are [im][re]: swap into the in-memory {re, im} (utils.rs:29-31)
-            for (size_t k = 0; k < n; k++) {
-                const int16_t im = buf[2 * k];
-                buf[2 * k] = buf[2 * k + 1];
-                buf[2 * k + 1] = im;
-            }
+        if (!mem_order) {  // file pairs are [im][re]: swap into the in-memory {re, im} (utils.rs:29-31)
+            // (a 16-bit rotate of each pair as one word: the compiler vectorises it; pair by pair the swap was
+            // the slowest stage of the feed)
+            typedef uint32_t __attribute__((may_alias)) pair_word;
+            pair_word *w = reinterpret_cast<pair_word *>(buf);
+            for (size_t k = 0; k < n; k++) w[k] = (w[k] << 16) | (w[k] >> 16);
+        }
         if (n == 0) break;
         if ((st = adsb_ring_submit(ctx, n)) != ADSB_OK) return die(ctx, "adsb_ring_submit", st);
         total_samples += n;
