@@ -237,8 +237,8 @@ int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, st
         // intervals is what is being summed).  The frontier's events are intact for kScanEvRing - n_slots
         // passes back: the ring is that much longer than what can be in flight.
         float excl = ms;
-        bool advance = true;
-        if (c->last_stop && sl.scan_seq - c->last_scan_seq <= (uint64_t)(kScanEvRing - c->n_slots)) {
+        bool advance = !sl.redo;   // (a pass run again is blocking and on events of its own: no part of the frontier)
+        if (!sl.redo && c->last_stop && sl.scan_seq - c->last_scan_seq <= (uint64_t)(kScanEvRing - c->n_slots)) {
             float since = 0;
             if (hipEventElapsedTime(&since, c->last_stop, sl.ev[1]) == hipSuccess) {
                 if (since <= 0) {

@@ -53,6 +53,13 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     if (max_chunks > kMaxChunks) return ADSB_ERR_INVALID;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return ADSB_ERR_NO_DEVICE;
+    {
+        // the kernels are gfx950 code objects and nothing else: any other device is "no usable device" here, not a
+        // failed launch later (include/adsb_hip.h: ADSB_ERR_NO_DEVICE)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return ADSB_ERR_NO_DEVICE;
+    }
 
     adsb_ctx *c = new (std::nothrow) adsb_ctx;
     if (!c) return ADSB_ERR_NOMEM;
@@ -218,6 +225,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         for (auto &pair : c->scan_ev)
             for (auto &e : pair) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+        for (auto &e : c->redo_ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
         if (tuning_env("ADSB_TIMELINE")) {
             // 1: stamps of 8 blocks x 8 tiles; 2 (with ADSB_DEBUG_STOP=100): per-wave phase totals
             HIP_TRY(c, hipMalloc((void **)&c->d_timeline, kTimelineWords * sizeof(unsigned long long)));
@@ -269,6 +277,8 @@ void adsb_destroy(adsb_ctx *c)
     for (auto &pair : c->scan_ev)
         for (auto &e : pair)
             if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->redo_ev)
+        if (e) (void)hipEventDestroy(e);
     for (Slot &sl : c->slot) {
         for (int k = 2; k < 5; k++)
             if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
@@ -431,6 +441,9 @@ int adsb_set_stream(adsb_ctx *c, void *hip_stream)
 int adsb_set_profiling(adsb_ctx *c, int enabled)
 {
     if (!c) return ADSB_ERR_INVALID;
+    // (the level decides whether a pass of a few buffers is one launch or three, and the cross-stream edges of a
+    // pass are worked out from what the passes in flight are: like the other settings, only between passes)
+    if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return ADSB_OK;
 }

@@ -86,6 +86,8 @@ struct Slot {
     hipEvent_t done = nullptr;  // no timing, no system fence: results are written through
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int profiled = 0;  // profiling level the pass was enqueued with
+    bool redo = false;  // enqueued by collect_oldest (overflow fallback, rematch): keeps the pass's number, times itself with
+                        // the context's redo events, and stays out of ms_scan_exclusive's frontier
 };
 
 // Passes in flight: 4 and the device never waits for the host between large passes (3 do for sparse
@@ -176,6 +178,7 @@ struct adsb_ctx {
     // start / stop events of the scans, in a ring one longer than the passes in flight: when pass N
     // is collected the stop event of pass N-1 is still its own (ms_scan_exclusive)
     hipEvent_t scan_ev[kScanEvRing][2] = {};
+    hipEvent_t redo_ev[2] = {};      // start / stop of a pass collect_oldest runs again (blocking: one pair is enough)
     hipEvent_t last_stop = nullptr;  // stop event of the pass collected last, and its number
     uint64_t last_scan_seq = 0;
     uint64_t scan_counter = 0;
@@ -288,6 +291,10 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
                  bool inline_tail = false, bool lead_from_src = false, bool advance_carry = true,
                  bool force_simple = false, hipEvent_t input_done = nullptr, bool no_fuse = false);
 int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other);
+// The blocking entry points that launch on `stream` with slot 0's lists and counters without enqueue_pass (shard
+// phases, self-tests): behind the one-launch pass that used the slot last, whose summary reaches the host a
+// moment before its last workgroup has zeroed the counters (edge 0 of DESIGN.md section 5b).
+int order_behind_slot0(adsb_ctx *c);
 int resync_exact(adsb_ctx *c);
 int reseed_bitmap_from_filter(adsb_ctx *c);
 int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false,

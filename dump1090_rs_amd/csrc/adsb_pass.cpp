@@ -46,6 +46,17 @@ int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other)
     return ADSB_OK;
 }
 
+int order_behind_slot0(adsb_ctx *c)
+{
+    Slot &sl = c->slot[0];
+    if (sl.fused_q && sl.fused_q != c->stream) {
+        HIP_TRY(c, hipEventRecord(c->lazy_ev, sl.fused_q));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lazy_ev, 0));
+    }
+    sl.fused_q = nullptr;
+    return ADSB_OK;
+}
+
 // Enqueue one device pass over n_chunks chunks starting at d_src into `sl`:
 // reset -> scan -> dense -> match -> records -> D2H of the summary and the first records.
 // Whether a plain pass of n_chunks buffers submitted now goes out as one launch.
@@ -137,9 +148,18 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     const int prof = sl.profiled;
     sl.seq = c->next_seq++;
     if (c->next_seq == 0) c->next_seq = 1;
-    sl.scan_seq = ++c->scan_counter;
-    sl.ev[0] = c->scan_ev[sl.scan_seq % kScanEvRing][0];
-    sl.ev[1] = c->scan_ev[sl.scan_seq % kScanEvRing][1];
+    // A pass collect_oldest runs again (overflow fallback buffer by buffer, rematch: `advance_carry` is false for
+    // exactly those) keeps its number -- a fresh one per buffer would walk through the event ring under the
+    // passes still in flight and move last_new_insert_seq ahead of them -- and times itself with its own pair.
+    sl.redo = !advance_carry;
+    if (!sl.redo) {
+        sl.scan_seq = ++c->scan_counter;
+        sl.ev[0] = c->scan_ev[sl.scan_seq % kScanEvRing][0];
+        sl.ev[1] = c->scan_ev[sl.scan_seq % kScanEvRing][1];
+    } else {
+        sl.ev[0] = c->redo_ev[0];
+        sl.ev[1] = c->redo_ev[1];
+    }
     sl.h_sum->seq = 0;  // the records kernel overwrites it, last, with sl.seq
     p.seq = sl.seq;
     if (sl.device_scored) {
@@ -238,10 +258,11 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
             HIP_TRY(c, hipStreamWaitEvent(ss, c->prev_scanned, 0));
             other_stream_synced = true;   // (in stream order behind it: every earlier pass on that stream)
         }
-        if (!other_stream_synced)   // (every pass in flight whose scan is not in stream order before this launch)
-            for (Slot &other : c->slot)
-                if (&other != &sl && other.busy && other.scan_q != ss)
-                    sl.unsynced_from = sl.unsynced_from ? std::min(sl.unsynced_from, other.scan_seq) : other.scan_seq;
+        // (every pass in flight whose scan is not in stream order before this launch: not on this stream, and not
+        // on the stream of the three-launch pass just waited for -- that wait covers what ran on ITS stream only)
+        for (Slot &other : c->slot)
+            if (&other != &sl && other.busy && other.scan_q != ss && !(other_stream_synced && other.scan_q == c->prev_scan_stream))
+                sl.unsynced_from = sl.unsynced_from ? std::min(sl.unsynced_from, other.scan_seq) : other.scan_seq;
     }
     sl.scan_q = ss;
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));

@@ -15,21 +15,35 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
     if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
     if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    for (int k = 0; k < c->n_slots; k++) {
-        auto &r = c->ring[k];
-        // (mapped and coherent: slots of a few buffers are read in place by the pass itself)
-        HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(c, hipHostGetDevicePointer(&r.h_iq_dev, r.h_iq, 0));
-        HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
+    auto body = [&]() -> int {
+        for (int k = 0; k < c->n_slots; k++) {
+            auto &r = c->ring[k];
+            // (mapped and coherent: slots of a few buffers are read in place by the pass itself)
+            HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(c, hipHostGetDevicePointer(&r.h_iq_dev, r.h_iq, 0));
+            HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
+        }
+        // One small copy per slot now, on an idle stream.  The runtime sets something up on the first copy between a
+        // pair of buffers; left to the first pipelined submit (a ring that starts with its slots read in place) every
+        // later hipMemcpyAsync of the ring took 12-19 us of the submitting thread instead of 2-5 (measured: 16-buffer
+        // slots, eight in flight, 12.5 Gsample/s instead of 13.2; profiles/r4_ring_copy_ab.txt).
+        const size_t warm = std::min<size_t>(samples_per_slot * 4, 64 << 10);
+        for (int k = 0; k < c->n_slots; k++)
+            HIP_TRY(c, hipMemcpyAsync(c->ring[k].d_iq, c->ring[k].h_iq, warm, hipMemcpyHostToDevice, c->scan_stream[k % c->n_scan_streams]));
+        for (int k = 0; k < c->n_scan_streams; k++) HIP_TRY(c, hipStreamSynchronize(c->scan_stream[k]));
+        return (int)ADSB_OK;
+    };
+    const int rc = body();
+    if (rc != ADSB_OK) {
+        // nothing half-made stays behind: a retry starts from scratch instead of overwriting (and leaking) these
+        for (int k = 0; k < c->n_scan_streams; k++) (void)hipStreamSynchronize(c->scan_stream[k]);
+        for (auto &r : c->ring) {
+            if (r.h_iq) (void)hipHostFree(r.h_iq);
+            if (r.d_iq) (void)hipFree(r.d_iq);
+            r = adsb_ctx::RingSlot{};
+        }
+        return rc;
     }
-    // One small copy per slot now, on an idle stream.  The runtime sets something up on the first copy between a
-    // pair of buffers; left to the first pipelined submit (a ring that starts with its slots read in place) every
-    // later hipMemcpyAsync of the ring took 12-19 us of the submitting thread instead of 2-5 (measured: 16-buffer
-    // slots, eight in flight, 12.5 Gsample/s instead of 13.2; profiles/r4_ring_copy_ab.txt).
-    const size_t warm = std::min<size_t>(samples_per_slot * 4, 64 << 10);
-    for (int k = 0; k < c->n_slots; k++)
-        HIP_TRY(c, hipMemcpyAsync(c->ring[k].d_iq, c->ring[k].h_iq, warm, hipMemcpyHostToDevice, c->scan_stream[k % c->n_scan_streams]));
-    for (int k = 0; k < c->n_scan_streams; k++) HIP_TRY(c, hipStreamSynchronize(c->scan_stream[k]));
     c->ring_samples = samples_per_slot;
     return ADSB_OK;
 }

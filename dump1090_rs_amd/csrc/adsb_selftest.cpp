@@ -17,6 +17,7 @@ int selftest_pass(adsb_ctx *c, const void *d_iq, size_t n_samples, std::vector<u
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = order_behind_slot0(c)) return rc;
     Slot &sl = c->slot[0];
     const uint32_t dev_cap = (uint32_t)std::min<uint64_t>(n_samples, 1u << 26);  // a list entry per position at most
     uint64_t *d_cand = nullptr;

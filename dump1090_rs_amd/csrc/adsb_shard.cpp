@@ -81,6 +81,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     if ((uintptr_t)device_iq % 16) return ADSB_ERR_INVALID;
     // (the caller may be a worker thread whose current device is not this context's: sharding.ShardPipeline)
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = order_behind_slot0(c)) return rc;
     Slot &sl = c->slot[0];
     ScanParams p{};
     p.src = device_iq;

@@ -1,4 +1,6 @@
 #!/bin/bash
+cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
+trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 # A/B: run bench with alternative builds of the library (variants/lib_<tag>.so), alternating the
 # builds AB_REPS times (numbers are only comparable within one GPU session).  AB_ARGS="--sync"
 # makes launches not overlap, so that kernel_avg_ms is the kernel alone.

@@ -1,4 +1,6 @@
 #!/bin/bash
+cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
+trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 for rep in 1 2 3; do
 for t in base o5r2; do
   cp gpurun_lib_$t.so dump1090_rs_amd/libadsb_hip.so

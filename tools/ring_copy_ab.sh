@@ -4,6 +4,7 @@
 # launch (=0) / always copied (=2) / alternating (=3).  Needs the tuning build (tools/mkvariants.sh
 # tune="-DADSB_TUNING").
 cp dump1090_rs_amd/libadsb_hip.so /tmp/lib_prod.so
+trap 'cp /tmp/lib_prod.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 cp variants/lib_tune.so dump1090_rs_amd/libadsb_hip.so
 run() { # mode chunks depth
   echo -n "mode $1: "

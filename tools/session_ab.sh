@@ -2,6 +2,7 @@
 # A/B of library variants (variants/lib_<tag>.so) on the headline and the dense workload, alternating.
 T=${TAG:-s}; mkdir -p gpurun_out; O=gpurun_out/${T}_ab.log
 cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
+trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 for rep in 1 2 3; do
   for tag in "$@"; do
     cp variants/lib_$tag.so dump1090_rs_amd/libadsb_hip.so

@@ -1,6 +1,7 @@
 #!/bin/bash
 T=${TAG:-s}; mkdir -p gpurun_out; O=gpurun_out/${T}_ab.log
 cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
+trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 fmt='import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("ms/step",d["ms_per_step"],"median",d["ms_per_step_median"],"kernel_alone",d["roofline"]["kernel_avg_ms"],"device",d["roofline"]["sustained"]["device_ms_per_launch"])'
 for rep in 1 2 3; do

@@ -4,6 +4,7 @@
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/${TAG:-s}_tests.log
 cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
+trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 cp variants/lib_tune.so dump1090_rs_amd/libadsb_hip.so
 for depth in 3 1; do
   ADSB_HOST_TIMES=1 python tools/hosttime.py ring --chunks 1 --depth $depth >> gpurun_out/${TAG:-s}_hosttime.log 2>&1

@@ -8,6 +8,7 @@ if [ "${FULL:-0}" = "1" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/${T}_tests.log; tail -4 gpurun_out/${T}_tests.log
 fi
 cp dump1090_rs_amd/libadsb_hip.so /tmp/rel.so
+trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT   # whatever ends the script, the production library is back
 python tools/config1.py > gpurun_out/${T}_config1.log 2>&1
 H=gpurun_out/${T}_hosttime_rel.log
 for prof in 1 0; do for depth in 4 6 8; do
