@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
     L.adsb_selftest_set_order_polls.restype = C.c_int
     L.adsb_selftest_crc_table.argtypes = [vp]
     L.adsb_selftest_crc_table.restype = C.c_int
+    L.adsb_selftest_learned_union.argtypes = [vp, sz, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_selftest_learned_union.restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]
     L.adsb_host_replays.restype = C.c_uint64
     L.adsb_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]

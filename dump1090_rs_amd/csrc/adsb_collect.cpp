@@ -6,14 +6,6 @@ using namespace adsb::host;
 
 namespace {
 
-// Ordered replay (src/demod_2400.rs:149-207 with mode_s scoring): records sorted by
-// (chunk, j, try_phase); per (chunk, j) the best trial by strictly-greater score
-// starting from -2 wins and is emitted when its score is >= 0.
-inline uint64_t replay_key(const TrialRecord &r)
-{
-    return (uint64_t)r.chunk << 32 | (uint64_t)(r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24);
-}
-
 // The pass's messages as the device scored them, when they can be taken as they are: scored in the
 // current epoch, whole (checksum), and with the filter nowhere near full -- the one situation whose
 // reference behaviour (icao_filter_add gives up on a full table, src/icao_filter.rs:46-62) the parallel
@@ -51,90 +43,6 @@ bool take_device_result(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, std::vecto
 
 namespace adsb {
 namespace host {
-
-void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
-            std::vector<adsb_msg> &out, uint64_t *host_sorts)
-{
-    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
-    // else is put in order here -- the records stay where they are (they may sit in mapped host
-    // memory), only 16-byte (key, index) pairs are sorted.
-    struct Ref {
-        uint64_t key;
-        uint32_t idx;
-    };
-    bool sorted = true;
-    for (size_t i = 1; i < n && sorted; i++) sorted = replay_key(rec[i - 1]) <= replay_key(rec[i]);
-    std::vector<Ref> order;
-    if (!sorted) {
-        if (host_sorts) ++*host_sorts;
-        order.resize(n);
-        uint64_t all_or = 0;
-        for (size_t i = 0; i < n; i++) {
-            order[i] = {replay_key(rec[i]), (uint32_t)i};
-            all_or |= order[i].key;
-        }
-        if (n <= 96) {
-            // a pass of a buffer or two (its workgroups write their records as they find them): by insertion,
-            // stable, nothing to allocate or to count
-            for (size_t a = 1; a < n; a++) {
-                const Ref r = order[a];
-                size_t b = a;
-                for (; b > 0 && order[b - 1].key > r.key; b--) order[b] = order[b - 1];
-                order[b] = r;
-            }
-            all_or = 0;   // (sorted: the passes below all skip)
-        }
-        // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
-        // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
-        std::vector<Ref> tmp(all_or ? n : 0);
-        Ref *src = order.data(), *dst = tmp.data();
-        for (int shift = 0; shift < 64; shift += 11) {
-            if (((all_or >> shift) & 0x7FFu) == 0) continue;
-            uint32_t count[2048] = {0};
-            for (size_t i = 0; i < n; i++) count[(src[i].key >> shift) & 0x7FFu]++;
-            uint32_t at = 0;
-            for (uint32_t &c : count) {
-                const uint32_t k = c;
-                c = at;
-                at += k;
-            }
-            for (size_t i = 0; i < n; i++) dst[count[(src[i].key >> shift) & 0x7FFu]++] = src[i];
-            std::swap(src, dst);
-        }
-        if (src != order.data()) order.swap(tmp);
-    }
-    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i].idx]; };
-    size_t i = 0;
-    while (i < n) {
-        const uint64_t pos = replay_key(at(i)) >> 8;  // (chunk, j)
-        const TrialRecord *best = nullptr;
-        Score best_score{false, (int)ADSB_MODES_SHORT_MSG_BYTES, -2};
-        for (; i < n; i++) {
-            const TrialRecord &r = at(i);
-            if ((replay_key(r) >> 8) != pos) break;
-            // records built on the device bring the CRC residual along (pad bit 0) and the filter
-            // hash of the value their DF asks about (pad bit 1, hash in bits 4..15)
-            const Score s = (r.pad & 1) ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg,
-                                                              (r.pad & 2) ? (int)(r.pad >> 4) : -1)
-                                        : score_modes_message(filter, crc, r.msg);
-            if (!s.some || s.value <= best_score.value) continue;
-            best = &r;
-            best_score = s;
-        }
-        if (!best || best_score.value < 0) continue;
-        adsb_msg m{};
-        std::memcpy(m.msg, best->msg, 14);
-        m.len = (uint8_t)best_score.len;
-        m.score = best_score.value;
-        m.try_phase = (uint8_t)(best->j_tp >> 24);
-        // demod_2400.rs:191-198: signal_len = 14*12/5 = 33 (the same three divisions, in this order)
-        const double signal_power = (double)(best->power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
-        m.signal_level = signal_power / 33.0;
-        m.j = (uint32_t)(pos & 0xFFFFFFu);
-        m.chunk = chunk_offset + (pos >> 24);
-        out.push_back(m);
-    }
-}
 
 // The records and the summary travel to host memory as separate posted writes; the summary's
 // sequence word says the pass is done, this says every one of its records has landed whole: the
@@ -447,22 +355,6 @@ int adsb_fetch_messages(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
     if (n) std::memcpy(out, c->undelivered.data(), n * sizeof(adsb_msg));
     if (n_out) *n_out = c->undelivered.size();
     return c->undelivered.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
-
-int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
-                        size_t cap, size_t *n_out)
-{
-    if (!filter_table || (!records && n) || (!out && cap)) return ADSB_ERR_INVALID;
-    static const Crc24 crc;
-    IcaoFilter filter;
-    filter.load(filter_table);
-    std::vector<adsb_msg> msgs;
-    replay(filter, crc, reinterpret_cast<TrialRecord *>(records), n, 0, msgs);
-    filter.store(filter_table);
-    const size_t k = std::min(cap, msgs.size());
-    if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
-    if (n_out) *n_out = msgs.size();
-    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
 }
 
 }  // extern "C"

@@ -473,43 +473,6 @@ int adsb_icao_flush(adsb_ctx *c)
     return ADSB_OK;
 }
 
-int adsb_read_test_data(const char *path, int16_t *iq, size_t max_samples, size_t *n_out)
-{
-    if (!path || !iq) return ADSB_ERR_INVALID;
-    FILE *fp = std::fopen(path, "rb");
-    if (!fp) return ADSB_ERR_INVALID;
-    size_t k = 0;
-    unsigned char b[4];
-    while (k < max_samples && std::fread(b, 1, 4, fp) == 4) {
-        // file: [im lo][im hi][re lo][re hi]  (src/utils.rs:29-31) -> memory {re, im}
-        iq[2 * k] = (int16_t)(b[2] | (b[3] << 8));
-        iq[2 * k + 1] = (int16_t)(b[0] | (b[1] << 8));
-        k++;
-    }
-    std::fclose(fp);
-    if (n_out) *n_out = k;
-    return ADSB_OK;
-}
-
-int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
-{
-    if (!m || !out || (m->len != ADSB_MODES_SHORT_MSG_BYTES && m->len != ADSB_MODES_LONG_MSG_BYTES))
-        return ADSB_ERR_INVALID;
-    const size_t need = 2u * m->len + 3u;  // '*', hex, ';', '\n'
-    if (out_size < need + 1) return ADSB_ERR_CAPACITY;
-    static const char digits[] = "0123456789abcdef";  // hex::encode is lowercase
-    char *w = out;
-    *w++ = '*';
-    for (int i = 0; i < m->len; i++) {
-        *w++ = digits[m->msg[i] >> 4];
-        *w++ = digits[m->msg[i] & 15];
-    }
-    *w++ = ';';
-    *w++ = '\n';
-    *w = 0;
-    return (int)need;
-}
-
 uint64_t adsb_host_sorts(const adsb_ctx *c) { return c ? c->host_sorts : 0; }
 uint64_t adsb_host_replays(const adsb_ctx *c) { return c ? c->host_replays : 0; }
 uint64_t adsb_host_rematches(const adsb_ctx *c) { return c ? c->rematches : 0; }
@@ -520,21 +483,6 @@ int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
     if (!c || !out) return ADSB_ERR_INVALID;
     *out = c->stats;
     return ADSB_OK;
-}
-
-const char *adsb_strerror(int status)
-{
-    switch (status) {
-    case ADSB_OK: return "ok";
-    case ADSB_ERR_INVALID: return "invalid argument";
-    case ADSB_ERR_NO_DEVICE: return "no usable HIP device (libadsb_hip has no CPU fallback)";
-    case ADSB_ERR_HIP: return "HIP runtime error";
-    case ADSB_ERR_TOO_LONG: return "more than 131072 samples for a single MagnitudeBuffer";
-    case ADSB_ERR_CAPACITY: return "output array too small";
-    case ADSB_ERR_NOMEM: return "out of memory";
-    case ADSB_ERR_BUSY: return "submissions are pending (collect them first) or too many are in flight";
-    default: return "unknown status";
-    }
 }
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }

@@ -4,7 +4,8 @@
 //   adsb_context.cpp   create / destroy, the stream pool, settings, diagnostics
 //   adsb_pass.cpp      one device pass: what is enqueued on which stream, and every cross-stream edge
 //                      (DESIGN.md section 5b lists them), submit, the blocking entry points
-//   adsb_collect.cpp   waiting for a pass, checksums, the ordered host replay, the overflow fallback
+//   adsb_collect.cpp   waiting for a pass, checksums, the overflow fallback
+//   adsb_replay_host.cpp  the ordered host replay and the other host-only entry points (no HIP: also built by g++ under sanitizers)
 //   adsb_ring.cpp      the pinned streaming ring
 //   adsb_shard.cpp     the two-phase shard calls
 //   adsb_selftest.cpp  stage lists and digests for the tests
@@ -24,6 +25,7 @@
 #include "../../include/adsb_hip.h"
 #include "adsb_device.h"
 #include "adsb_scan_geometry.h"
+#include "adsb_replay_host.h"
 #include "adsb_tables.h"
 #include "mode_s_host.hpp"
 
@@ -306,8 +308,6 @@ int ensure_stage(adsb_ctx *c, size_t bytes);
 int ensure_host_stage(adsb_ctx *c, size_t bytes);
 
 // adsb_collect.cpp
-void replay(IcaoFilter &filter, const Crc24 &crc, TrialRecord *rec, size_t n, uint64_t chunk_offset,
-            std::vector<adsb_msg> &out, uint64_t *host_sorts = nullptr);
 int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size_t n);
 int finish_pass(adsb_ctx *c, Slot &sl, uint64_t chunk_offset, adsb_stats &st, std::vector<adsb_msg> &out);
 int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out);

@@ -21,6 +21,8 @@
 
 #include <cstdlib>
 
+#include "adsb_record.h"
+
 // Measurement switches (tools/*.sh: ADSB_DEBUG_STOP, ADSB_STAGGER, ADSB_SCAN_BLOCKS_PER_CU,
 // ADSB_STREAM_PRIO, ADSB_NO_EXT_EVENTS, ADSB_ONE_SCAN_STREAM, ADSB_DONE_FENCE, ADSB_TIMELINE) exist
 // only in a library built with -DADSB_TUNING (-DADSB_KERNEL_ACCT implies it): the release build
@@ -71,17 +73,6 @@ __host__ __device__ inline uint32_t entry_j(uint64_t e) { return (uint32_t)(e >>
 __host__ __device__ inline uint64_t entry_chunk(uint64_t e) { return e >> 45; }
 constexpr uint64_t kMaxChunks = 1ull << 19;  // per device pass (256 GiB of IQ)
 
-// One trial message handed to the host replay (32 bytes).
-struct TrialRecord {
-    uint64_t power;     // bits 0..39: sum of the 33 squared magnitudes from j+19 (demod_2400.rs:
-                        // 191-196; < 2^38).  With pad bit 0, bits 40..63: the CRC residual of msg
-    uint32_t chunk;
-    uint32_t j_tp;      // j | try_phase << 24
-    uint8_t msg[14];
-    uint16_t pad;       // bit 0: `power` carries the residual (records built on the device); bit 1: bits 4..15 are
-                        // icao_hash of the value the DF asks the filter about (residual or address)
-};
-static_assert(sizeof(TrialRecord) == 32, "TrialRecord layout");
 
 // The AP list of the fast scan is split into kApWaveSegs equal segments: every wave of
 // every persistent workgroup owns one outright, so appending needs no atomic and no shared

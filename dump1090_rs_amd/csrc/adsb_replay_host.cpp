@@ -1,0 +1,245 @@
+// adsb_replay_host.cpp -- the host-only half of libadsb_hip.so: the ordered replay (src/demod_2400.rs:149-207 with
+// src/mode_s/mod.rs:34-139 scoring against src/icao_filter.rs:11-97 and src/crc.rs:263-282), the address union of the
+// sharded capture, and the ABI's host-only entry points (adsb_replay_records, adsb_format_raw, adsb_read_test_data,
+// adsb_selftest_crc_table, adsb_strerror).  No HIP in this unit: besides the library build it is compiled by plain
+// g++ with -fsanitize=address,undefined and fed every trial the CPU checker slices plus adversarial records
+// (tests/test_host_sanitizers.py) -- the GPU pool offers no device sanitizer, the host side needs none.
+#include "adsb_replay_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <iterator>
+
+using namespace adsb;
+
+namespace {
+
+// Ordered replay (src/demod_2400.rs:149-207 with mode_s scoring): records sorted by
+// (chunk, j, try_phase); per (chunk, j) the best trial by strictly-greater score
+// starting from -2 wins and is emitted when its score is >= 0.
+inline uint64_t replay_key(const TrialRecord &r)
+{
+    return (uint64_t)r.chunk << 32 | (uint64_t)(r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24);
+}
+
+}  // namespace
+
+namespace adsb {
+namespace host {
+
+void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out, uint64_t *host_sorts)
+{
+    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
+    // else is put in order here -- the records stay where they are (they may sit in mapped host
+    // memory), only 16-byte (key, index) pairs are sorted.
+    struct Ref {
+        uint64_t key;
+        uint32_t idx;
+    };
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i++) sorted = replay_key(rec[i - 1]) <= replay_key(rec[i]);
+    std::vector<Ref> order;
+    if (!sorted) {
+        if (host_sorts) ++*host_sorts;
+        order.resize(n);
+        uint64_t all_or = 0;
+        for (size_t i = 0; i < n; i++) {
+            order[i] = {replay_key(rec[i]), (uint32_t)i};
+            all_or |= order[i].key;
+        }
+        if (n <= 96) {
+            // a pass of a buffer or two (its workgroups write their records as they find them): by insertion,
+            // stable, nothing to allocate or to count
+            for (size_t a = 1; a < n; a++) {
+                const Ref r = order[a];
+                size_t b = a;
+                for (; b > 0 && order[b - 1].key > r.key; b--) order[b] = order[b - 1];
+                order[b] = r;
+            }
+            all_or = 0;   // (sorted: the passes below all skip)
+        }
+        // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
+        // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
+        std::vector<Ref> tmp(all_or ? n : 0);
+        Ref *src = order.data(), *dst = tmp.data();
+        for (int shift = 0; shift < 64; shift += 11) {
+            if (((all_or >> shift) & 0x7FFu) == 0) continue;
+            uint32_t count[2048] = {0};
+            for (size_t i = 0; i < n; i++) count[(src[i].key >> shift) & 0x7FFu]++;
+            uint32_t at = 0;
+            for (uint32_t &c : count) {
+                const uint32_t k = c;
+                c = at;
+                at += k;
+            }
+            for (size_t i = 0; i < n; i++) dst[count[(src[i].key >> shift) & 0x7FFu]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != order.data()) order.swap(tmp);
+    }
+    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i].idx]; };
+    size_t i = 0;
+    while (i < n) {
+        const uint64_t pos = replay_key(at(i)) >> 8;  // (chunk, j)
+        const TrialRecord *best = nullptr;
+        Score best_score{false, (int)ADSB_MODES_SHORT_MSG_BYTES, -2};
+        for (; i < n; i++) {
+            const TrialRecord &r = at(i);
+            if ((replay_key(r) >> 8) != pos) break;
+            // records built on the device bring the CRC residual along (pad bit 0) and the filter
+            // hash of the value their DF asks about (pad bit 1, hash in bits 4..15)
+            const Score s = (r.pad & 1) ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg,
+                                                              (r.pad & 2) ? (int)(r.pad >> 4) : -1)
+                                        : score_modes_message(filter, crc, r.msg);
+            if (!s.some || s.value <= best_score.value) continue;
+            best = &r;
+            best_score = s;
+        }
+        if (!best || best_score.value < 0) continue;
+        adsb_msg m{};
+        std::memcpy(m.msg, best->msg, 14);
+        m.len = (uint8_t)best_score.len;
+        m.score = best_score.value;
+        m.try_phase = (uint8_t)(best->j_tp >> 24);
+        // demod_2400.rs:191-198: signal_len = 14*12/5 = 33 (the same three divisions, in this order)
+        const double signal_power = (double)(best->power & ((1ull << 40) - 1)) / 65535.0 / 65535.0;
+        m.signal_level = signal_power / 33.0;
+        m.j = (uint32_t)(pos & 0xFFFFFFu);
+        m.chunk = chunk_offset + (pos >> 24);
+        out.push_back(m);
+    }
+}
+
+// mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17): the addresses the replay will add
+void learned_addresses(const Crc24 &crc, const TrialRecord *rec, size_t n, std::vector<uint32_t> &addrs)
+{
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *m = rec[i].msg;
+        const uint32_t df = m[0] >> 3;
+        const bool adds = df == 17 || (df == 11 && crc.residual(m, 7) == 0);
+        if (adds) addrs.push_back(uint32_t(m[1]) << 16 | uint32_t(m[2]) << 8 | m[3]);
+    }
+}
+
+void union_sorted(const std::vector<const std::vector<uint32_t> *> &lists, const std::vector<uint32_t> &known,
+                  std::vector<uint32_t> &out)
+{
+    out.clear();
+    for (const auto *l : lists)
+        if (l) out.insert(out.end(), l->begin(), l->end());
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    if (!known.empty()) {
+        std::vector<uint32_t> fresh;
+        std::set_difference(out.begin(), out.end(), known.begin(), known.end(), std::back_inserter(fresh));
+        out.swap(fresh);
+    }
+}
+
+}  // namespace host
+}  // namespace adsb
+
+using namespace adsb;
+using namespace adsb::host;
+
+extern "C" {
+
+static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors TrialRecord");
+
+int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
+                        size_t cap, size_t *n_out)
+{
+    if (!filter_table || (!records && n) || (!out && cap)) return ADSB_ERR_INVALID;
+    static const Crc24 crc;
+    IcaoFilter filter;
+    filter.load(filter_table);
+    std::vector<adsb_msg> msgs;
+    replay(filter, crc, reinterpret_cast<const TrialRecord *>(records), n, 0, msgs);
+    filter.store(filter_table);
+    const size_t k = std::min(cap, msgs.size());
+    if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
+    if (n_out) *n_out = msgs.size();
+    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int adsb_read_test_data(const char *path, int16_t *iq, size_t max_samples, size_t *n_out)
+{
+    if (!path || !iq) return ADSB_ERR_INVALID;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return ADSB_ERR_INVALID;
+    size_t k = 0;
+    unsigned char b[4];
+    while (k < max_samples && std::fread(b, 1, 4, fp) == 4) {
+        // file: [im lo][im hi][re lo][re hi]  (src/utils.rs:29-31) -> memory {re, im}
+        iq[2 * k] = (int16_t)(b[2] | (b[3] << 8));
+        iq[2 * k + 1] = (int16_t)(b[0] | (b[1] << 8));
+        k++;
+    }
+    std::fclose(fp);
+    if (n_out) *n_out = k;
+    return ADSB_OK;
+}
+
+int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
+{
+    if (!m || !out || (m->len != ADSB_MODES_SHORT_MSG_BYTES && m->len != ADSB_MODES_LONG_MSG_BYTES))
+        return ADSB_ERR_INVALID;
+    const size_t need = 2u * m->len + 3u;  // '*', hex, ';', '\n'
+    if (out_size < need + 1) return ADSB_ERR_CAPACITY;
+    static const char digits[] = "0123456789abcdef";  // hex::encode is lowercase
+    char *w = out;
+    *w++ = '*';
+    for (int i = 0; i < m->len; i++) {
+        *w++ = digits[m->msg[i] >> 4];
+        *w++ = digits[m->msg[i] & 15];
+    }
+    *w++ = ';';
+    *w++ = '\n';
+    *w = 0;
+    return (int)need;
+}
+
+int adsb_selftest_learned_union(const adsb_trial *records, size_t n, const uint32_t *known, size_t n_known, uint32_t *out,
+                                 size_t cap, size_t *n_out)
+{
+    if ((!records && n) || (!known && n_known) || (!out && cap)) return ADSB_ERR_INVALID;
+    static const Crc24 crc;
+    std::vector<uint32_t> learned, kn(known, known + n_known), fresh;
+    learned_addresses(crc, reinterpret_cast<const TrialRecord *>(records), n, learned);
+    std::sort(learned.begin(), learned.end());
+    learned.erase(std::unique(learned.begin(), learned.end()), learned.end());
+    std::sort(kn.begin(), kn.end());
+    kn.erase(std::unique(kn.begin(), kn.end()), kn.end());
+    union_sorted({&learned}, kn, fresh);
+    if (n_out) *n_out = fresh.size();
+    const size_t k = std::min(cap, fresh.size());
+    if (k) std::memcpy(out, fresh.data(), k * sizeof(uint32_t));
+    return fresh.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int adsb_selftest_crc_table(uint32_t *out256)
+{
+    if (!out256) return ADSB_ERR_INVALID;
+    static const Crc24 crc;  // the table the host replay scores with (mode_s_host.hpp)
+    std::memcpy(out256, crc.t, sizeof(crc.t));
+    return ADSB_OK;
+}
+
+const char *adsb_strerror(int status)
+{
+    switch (status) {
+    case ADSB_OK: return "ok";
+    case ADSB_ERR_INVALID: return "invalid argument";
+    case ADSB_ERR_NO_DEVICE: return "no usable HIP device (libadsb_hip has no CPU fallback)";
+    case ADSB_ERR_HIP: return "HIP runtime error";
+    case ADSB_ERR_TOO_LONG: return "more than 131072 samples for a single MagnitudeBuffer";
+    case ADSB_ERR_CAPACITY: return "output array too small";
+    case ADSB_ERR_NOMEM: return "out of memory";
+    case ADSB_ERR_BUSY: return "submissions are pending (collect them first) or too many are in flight";
+    default: return "unknown status";
+    }
+}
+
+}  // extern "C"

@@ -176,12 +176,4 @@ int adsb_selftest_set_order_polls(adsb_ctx *c, uint32_t polls)
     return ADSB_OK;
 }
 
-int adsb_selftest_crc_table(uint32_t *out256)
-{
-    if (!out256) return ADSB_ERR_INVALID;
-    static const Crc24 crc;  // the table the host replay scores with (mode_s_host.hpp)
-    std::memcpy(out256, crc.t, sizeof(crc.t));
-    return ADSB_OK;
-}
-
 }  // extern "C"

@@ -53,17 +53,6 @@ int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, ui
     return verify_records(c, sl.h_sum, c->fb.h_rec, *n_out);
 }
 
-// mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17): the addresses the replay will add
-void learned_addresses(const adsb_ctx *c, const TrialRecord *rec, size_t n, std::vector<uint32_t> &addrs)
-{
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t *m = rec[i].msg;
-        const uint32_t df = m[0] >> 3;
-        const bool adds = df == 17 || (df == 11 && c->crc.residual(m, 7) == 0);
-        if (adds) addrs.push_back(uint32_t(m[1]) << 16 | uint32_t(m[2]) << 8 | m[3]);
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -143,10 +132,10 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
         for (uint64_t ch = 0; ch < n_chunks; ch++) {
             size_t k = 0;
             if (int rc = shard_chunk_pass(c, p, ch, false, nullptr, &k)) return rc;
-            learned_addresses(c, c->fb.h_rec, k, addrs);
+            learned_addresses(c->crc, c->fb.h_rec, k, addrs);
         }
     } else {
-        learned_addresses(c, sl.h_rec, n_hits, addrs);
+        learned_addresses(c->crc, sl.h_rec, n_hits, addrs);
     }
     c->shard_by_chunk = by_chunk;
     std::sort(addrs.begin(), addrs.end());

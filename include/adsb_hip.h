@@ -310,6 +310,13 @@ int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
  * pins it against the reference's constants.  Host only, no context. */
 int adsb_selftest_crc_table(uint32_t *out256);
 
+/* Host only, no context: the address exchange of a sharded capture as the library does it -- the 24-bit
+ * addresses the replay of `records` can add to the filter (clean DF11 with IID 0, DF17: src/mode_s/mod.rs:80-84,
+ * 97-99), sorted, without duplicates and without those in `known` (any order).  For the tests that run the
+ * host-only code under sanitizers. */
+int adsb_selftest_learned_union(const adsb_trial *records, size_t n, const uint32_t *known, size_t n_known,
+                                uint32_t *out, size_t cap, size_t *n_out);
+
 int adsb_get_stats(const adsb_ctx *ctx, adsb_stats *out);
 /* Diagnostic: how many collected passes handed the host their trial records out of
  * (buffer, j, try_phase) order, so that the host replay had to sort them first.  Passes of more

@@ -94,6 +94,7 @@ unsafe extern "C" {
     pub fn adsb_selftest_gate_stages(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, preamble: *mut u64, preamble_cap: usize, n_preamble: *mut usize, snr: *mut u64, snr_cap: usize, n_snr: *mut usize) -> c_int;
     pub fn adsb_selftest_set_order_polls(ctx: *mut AdsbCtx, polls: u32) -> c_int;
     pub fn adsb_selftest_crc_table(out256: *mut u32) -> c_int;
+    pub fn adsb_selftest_learned_union(records: *const AdsbTrial, n: usize, known: *const u32, n_known: usize, out: *mut u32, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_get_stats(ctx: *const AdsbCtx, out: *mut AdsbStats) -> c_int;
     pub fn adsb_host_sorts(ctx: *const AdsbCtx) -> u64;
     pub fn adsb_host_replays(ctx: *const AdsbCtx) -> u64;
