@@ -58,6 +58,29 @@ class AdsbTrial(C.Structure):
     ]
 
 
+class AdsbMultiStats(C.Structure):
+    """adsb_multi_stats (include/adsb_hip.h): the capture an adsb_multi collected last."""
+    _fields_ = [
+        ("n_samples", C.c_uint64),
+        ("n_chunks", C.c_uint64),
+        ("n_candidates", C.c_uint64),
+        ("n_ap_entries", C.c_uint64),
+        ("n_records", C.c_uint64),
+        ("n_messages", C.c_uint64),
+        ("n_addrs_exchanged", C.c_uint64),
+        ("n_devices", C.c_uint32),
+        ("retries", C.c_uint32),
+        ("ms_wall", C.c_float),
+        ("ms_phase1_max", C.c_float),
+        ("ms_phase2_max", C.c_float),
+        ("ms_phase1_span", C.c_float),
+        ("ms_phase2_span", C.c_float),
+        ("ms_exchange", C.c_float),
+        ("ms_replay", C.c_float),
+        ("reserved", C.c_float),
+    ]
+
+
 class AdsbError(RuntimeError):
     def __init__(self, status: int, what: str, detail: str = ""):
         self.status = status
@@ -130,6 +153,29 @@ def lib() -> C.CDLL:
     L.adsb_selftest_crc_table.restype = C.c_int
     L.adsb_selftest_learned_union.argtypes = [vp, sz, vp, sz, vp, sz, C.POINTER(sz)]
     L.adsb_selftest_learned_union.restype = C.c_int
+    ip = C.POINTER(C.c_int)
+    L.adsb_multi_create.argtypes = [C.POINTER(vp), ip, C.c_int, sz]
+    L.adsb_multi_destroy.argtypes = [vp]
+    L.adsb_multi_destroy.restype = None
+    L.adsb_multi_device_count.argtypes = [vp]
+    L.adsb_multi_max_in_flight.argtypes = [vp]
+    L.adsb_multi_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    L.adsb_multi_icao_flush.argtypes = [vp]
+    L.adsb_multi_demod_iq.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.adsb_multi_demod_iq_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.POINTER(sz)]
+    L.adsb_multi_submit_iq_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.adsb_multi_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.adsb_multi_pending.argtypes = [vp]
+    L.adsb_multi_fetch_messages.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.adsb_multi_get_stats.argtypes = [vp, C.POINTER(AdsbMultiStats)]
+    L.adsb_multi_filter_table.argtypes = [vp, vp]
+    L.adsb_multi_last_error.argtypes = [vp]
+    L.adsb_multi_last_error.restype = C.c_char_p
+    for name in ("adsb_multi_create", "adsb_multi_device_count", "adsb_multi_max_in_flight", "adsb_multi_shard_range",
+                 "adsb_multi_icao_flush", "adsb_multi_demod_iq", "adsb_multi_demod_iq_device", "adsb_multi_submit_iq_device",
+                 "adsb_multi_collect", "adsb_multi_pending", "adsb_multi_fetch_messages", "adsb_multi_get_stats",
+                 "adsb_multi_filter_table"):
+        getattr(L, name).restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]
     L.adsb_host_replays.restype = C.c_uint64
     L.adsb_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]

@@ -20,7 +20,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libadsb_hip.so"
 SOURCES = [CSRC / "adsb_scan_fast.hip", CSRC / "adsb_scan_simple.hip", CSRC / "adsb_aux.hip",
            *(CSRC / f for f in ("adsb_context.cpp", "adsb_pass.cpp", "adsb_collect.cpp", "adsb_ring.cpp",
-                                "adsb_shard.cpp", "adsb_selftest.cpp", "adsb_replay_host.cpp"))]
+                                "adsb_shard.cpp", "adsb_multi.cpp", "adsb_selftest.cpp", "adsb_replay_host.cpp"))]
 HEADERS = [CSRC / "adsb_ctx.h", CSRC / "adsb_device.h", CSRC / "adsb_dev_common.h", CSRC / "adsb_scan_geometry.h",
            CSRC / "adsb_tables.h", CSRC / "adsb_tail_dev.h", CSRC / "adsb_record.h", CSRC / "adsb_replay_host.h", CSRC / "mode_s_host.hpp", PKG.parent / "include" / "adsb_hip.h"]
 FLAGS = [

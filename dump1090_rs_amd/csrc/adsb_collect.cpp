@@ -66,7 +66,7 @@ int verify_records(adsb_ctx *c, const Summary *sum, const TrialRecord *rec, size
 // The summary is ten separate posted writes with the sequence word issued last; a host that polls for it
 // takes the summary only when its own checksum covers what it reads (a word that overtook its neighbours
 // on the way would otherwise pair this pass's sequence number with the previous pass's counts).
-static bool summary_landed(const Summary *s, uint32_t seq)
+bool summary_landed(const Summary *s, uint32_t seq)
 {
     if (__atomic_load_n(&s->seq, __ATOMIC_ACQUIRE) != seq) return false;
     uint32_t w[10];

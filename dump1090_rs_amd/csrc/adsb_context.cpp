@@ -327,6 +327,8 @@ void adsb_destroy(adsb_ctx *c)
         if (r.d_iq) (void)hipFree(r.d_iq);
     }
     if (c->d_addrs) (void)hipFree(c->d_addrs);
+    for (auto &j : c->shard)
+        if (j.h_addrs) (void)hipHostFree(j.h_addrs);
     if (c->d_carry_next) (void)hipFree(c->d_carry_next);
     if (c->d_timeline && tuning_env("ADSB_TIMELINE") && std::atoi(tuning_env("ADSB_TIMELINE")) == 3) {
         // profiling aid: the stamps of the last one-launch pass (100 MHz wall clock)

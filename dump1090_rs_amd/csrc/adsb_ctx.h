@@ -205,10 +205,23 @@ struct adsb_ctx {
     bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
     uint32_t *d_carry_next = nullptr;  // the end of the latest submission's input: the next one's lead-in
 
-    // sharded capture (adsb_shard_scan / adsb_shard_finish): the pass parked between its two phases
+    // sharded capture: adsb_shard_scan / adsb_shard_finish park one shard (in slot 0) between its two phases;
+    // the multi-GPU entry points (adsb_multi.cpp) keep up to n_slots shards of consecutive captures in flight,
+    // one per slot (adsb_shard.cpp: shard_begin ... shard_records)
     bool shard_active = false;
-    bool shard_by_chunk = false;  // the shard overflowed the fast scan's lists: both phases go chunk by chunk
-    ScanParams shard_params{};
+    struct ShardJob {
+        bool active = false;      // phase 1 enqueued, phase 2 not collected yet
+        bool by_chunk = false;    // the shard overflowed the fast scan's lists: both phases go buffer by buffer
+        bool waiting = false;     // a phase's launches are out and its summary has not been seen yet
+        ScanParams p{};
+        uint32_t *retired = nullptr;   // the bitmap an icao_flush in front of this shard retired (phase 2 cleans it)
+        std::vector<TrialRecord> chunk_records;   // by_chunk: the second phase's records
+        uint64_t n_cand = 0, n_ap = 0;
+        hipStream_t scan_q = nullptr;
+        uint32_t *h_addrs = nullptr, *h_addrs_dev = nullptr;   // the other shards' addresses, in mapped host memory
+                                                               // (k_set_addresses reads them in place: no copy command)
+    } shard[kSlots];
+    uint64_t shard_jobs = 0;      // shards begun (their scans alternate between the first two scan streams)
     uint32_t *d_addrs = nullptr;
     size_t addrs_cap = 0;
 
@@ -296,7 +309,8 @@ int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other);
 // The blocking entry points that launch on `stream` with slot 0's lists and counters without enqueue_pass (shard
 // phases, self-tests): behind the one-launch pass that used the slot last, whose summary reaches the host a
 // moment before its last workgroup has zeroed the counters (edge 0 of DESIGN.md section 5b).
-int order_behind_slot0(adsb_ctx *c);
+int order_behind_fused(adsb_ctx *c, Slot &sl, hipStream_t waiter);
+inline int order_behind_slot0(adsb_ctx *c) { return order_behind_fused(c, c->slot[0], c->stream); }
 int resync_exact(adsb_ctx *c);
 int reseed_bitmap_from_filter(adsb_ctx *c);
 int submit(adsb_ctx *c, const void *d_src, bool from_mag, uint64_t n_samples, bool inline_tail = false,
@@ -314,6 +328,18 @@ int collect_oldest(adsb_ctx *c, std::vector<adsb_msg> &out);
 int park_pending(adsb_ctx *c);
 int collect_next(adsb_ctx *c, std::vector<adsb_msg> &out);
 int deliver(adsb_ctx *c, std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap, size_t *n_out);
+bool summary_landed(const Summary *s, uint32_t seq);
+
+// adsb_shard.cpp: one shard of a capture in slot k, phase by phase, nothing blocking but shard_phase_wait
+// (and the buffer-by-buffer fallback of a shard that overflows the lists).  Order of calls per slot:
+// shard_begin -> [landed] -> shard_learned -> shard_match -> [landed] -> shard_records.
+constexpr size_t kShardAddrCap = 16384;   // addresses per launch of k_set_addresses from mapped memory
+int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples);
+bool shard_phase_landed(adsb_ctx *c, int k);
+int shard_phase_wait(adsb_ctx *c, int k);
+int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs);
+int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra);
+int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n);
 
 }  // namespace host
 }  // namespace adsb

@@ -46,12 +46,11 @@ int wait_for_tail_of(adsb_ctx *c, hipStream_t waiter, Slot &other)
     return ADSB_OK;
 }
 
-int order_behind_slot0(adsb_ctx *c)
+int order_behind_fused(adsb_ctx *c, Slot &sl, hipStream_t waiter)
 {
-    Slot &sl = c->slot[0];
-    if (sl.fused_q && sl.fused_q != c->stream) {
+    if (sl.fused_q && sl.fused_q != waiter) {
         HIP_TRY(c, hipEventRecord(c->lazy_ev, sl.fused_q));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lazy_ev, 0));
+        HIP_TRY(c, hipStreamWaitEvent(waiter, c->lazy_ev, 0));
     }
     sl.fused_q = nullptr;
     return ADSB_OK;

@@ -41,6 +41,7 @@
 // its matches and candidates in its own small LDS regions and drains them in rounds
 // (P3..P5 below), so exactness never depends on how dense the signal is.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1291,28 +1292,29 @@ inline void hip_clear() { (void)hipGetLastError(); }
 
 }  // namespace
 
-// persistent grid = what is resident at once (occupancy API x CUs), found once
+// persistent grid = what is resident at once (occupancy API x CUs) on the CURRENT device, found once per device
 int scan_resident_blocks()
 {
-    // (a function-local static: initialised once, also when two threads create contexts at once)
-    static const int resident = [] {
-        int dev = 0, per_cu = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast<false>, kThreads, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            per_cu <= 0 || cus <= 0) {
-            per_cu = 2;
-            cus = 256;
-        }
-        int r = per_cu * cus;
-        if (const char *e = tuning_env("ADSB_SCAN_BLOCKS_PER_CU")) r = std::atoi(e) * cus;
-        if (r > kApSegments) r = kApSegments;  // four private AP segments (one per wave) each
-        if (r < 1) r = 1;
-        if (tuning_env("ADSB_TIMELINE"))
-            std::fprintf(stderr, "k_scan_fast: occupancy %d blocks/CU x %d CUs\n", per_cu, cus);
-        return r;
-    }();
-    return resident;
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> cached[kMaxDevices];   // (zero-initialised: 0 = not asked yet; two threads asking at once
+                                                   // compute the same number)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (const int r = cached[dev].load(std::memory_order_relaxed)) return r;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_fast<false>, kThreads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0 || cus <= 0) {
+        per_cu = 2;
+        cus = 256;
+    }
+    int r = per_cu * cus;
+    if (const char *e = tuning_env("ADSB_SCAN_BLOCKS_PER_CU")) r = std::atoi(e) * cus;
+    if (r > kApSegments) r = kApSegments;  // four private AP segments (one per wave) each
+    if (r < 1) r = 1;
+    if (tuning_env("ADSB_TIMELINE"))
+        std::fprintf(stderr, "k_scan_fast: device %d: occupancy %d blocks/CU x %d CUs\n", dev, per_cu, cus);
+    cached[dev].store(r, std::memory_order_relaxed);
+    return r;
 }
 
 int launch_pass_fused(const ScanParams &p, bool from_mag, void *stream)

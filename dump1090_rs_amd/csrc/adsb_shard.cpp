@@ -1,16 +1,25 @@
 // adsb_shard.cpp -- sharded capture.
 // ---------------------------------------------------------------------------------
-// Sharded capture: one capture cut into contiguous ranges of buffers, one
-// range per GPU.  The only thing that couples the shards is the order-dependent ICAO
-// filter, so a shard runs in two phases around a tiny host-side exchange:
-//   adsb_shard_scan    scan the shard; return the addresses its self-validating frames
-//                      will add to the filter (DF11 with IID 0, DF17)
-//   (exchange)         every shard receives the union of all shards' addresses
-//   adsb_shard_finish  add them to the shard's superset bitmap, match the address/parity
-//                      trials against it, return the raw trial records
-// and whoever holds all records replays them once, in global (chunk, j, try_phase) order,
-// through one filter (adsb_replay_records).  The union is a superset in time of what the
-// filter can hold at any point of the capture, so the result is the single-stream one.
+// One capture cut into contiguous ranges of buffers, one range per GPU.  The only thing that
+// couples the shards is the order-dependent ICAO filter (the reference is one loop with one
+// process-global filter: dump1090_rs/src/main.rs:154-167, src/icao_filter.rs:8-9), so a shard runs
+// in two phases around a tiny host-side exchange:
+//   phase 1   scan the shard; return the addresses its self-validating frames will add to the
+//             filter (DF11 with IID 0, DF17: src/mode_s/mod.rs:80-84, 97-99)
+//   exchange  every shard receives the union of all shards' addresses
+//   phase 2   add them to the shard's superset bitmap, match the address/parity trials against it,
+//             return the raw trial records
+// and whoever holds all records replays them once, in global (chunk, j, try_phase) order, through
+// one filter.  The union is a superset in time of what the filter can hold at any point of the
+// capture, so the result is the single-stream one.
+//
+// The phases are written per slot and do not block: shard_begin enqueues phase 1 of a shard into
+// slot k (scan on one of the two scan streams, the records of its self-validating hits on the tail
+// stream) and returns; the host sees the phase finish by its summary landing in mapped memory
+// (shard_phase_landed); shard_match enqueues phase 2 on the tail stream.  Shards of consecutive
+// captures sit in consecutive slots, so the scan of capture i + 1 runs while capture i is being
+// exchanged and matched -- that is what adsb_multi.cpp (one process, N GPUs, a thread per device)
+// is built on.  adsb_shard_scan / adsb_shard_finish are the same phases, blocking, in slot 0.
 // ---------------------------------------------------------------------------------
 #include "adsb_ctx.h"
 
@@ -18,13 +27,18 @@ using namespace adsb::host;
 
 namespace {
 
+uint32_t next_seq(adsb_ctx *c)
+{
+    const uint32_t s = c->next_seq++;
+    if (c->next_seq == 0) c->next_seq = 1;
+    return s;
+}
+
 // One 131072-sample buffer of a parked shard through the reference-shaped kernel, whose lists
 // hold the worst case of a buffer: scan (+ match) + records, synchronously.  The records land
 // in the fallback's host buffer (c->fb.h_rec) with chunk = 0; *n_out = how many.
-int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, uint32_t *clean, size_t *n_out)
+int shard_chunk_pass(adsb_ctx *c, Slot &sl, ScanParams p, uint64_t ch, bool with_match, uint32_t *clean, size_t *n_out)
 {
-    HIP_TRY(c, hipSetDevice(c->device));
-    Slot &sl = c->slot[0];
     if (int rc = ensure_fallback(c)) return rc;
     const uint64_t off = ch * kChunkSamples;
     p.src = (const uint32_t *)p.src + off;
@@ -36,8 +50,7 @@ int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, ui
     p.hits_cap = kWorstPerChunk;
     p.dap = c->fb.d_dap;
     p.dap_cap = kWorstPerChunk;
-    sl.seq = c->next_seq++;
-    if (c->next_seq == 0) c->next_seq = 1;
+    sl.seq = next_seq(c);
     sl.h_sum->seq = 0;
     p.seq = sl.seq;
     if (int e = launch_scan_simple(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan_simple");
@@ -53,39 +66,45 @@ int shard_chunk_pass(adsb_ctx *c, ScanParams p, uint64_t ch, bool with_match, ui
     return verify_records(c, sl.h_sum, c->fb.h_rec, *n_out);
 }
 
+// the rare, blocking path starts from idle streams (the slot's own launches are done by then; what other
+// slots still have on the tail stream may be matching against the bitmap this path is about to clean)
+int drain_for_chunk_path(adsb_ctx *c, const adsb_ctx::ShardJob &job)
+{
+    if (job.scan_q) HIP_TRY(c, hipStreamSynchronize(job.scan_q));
+    HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+    return ADSB_OK;
+}
+
 }  // namespace
 
-extern "C" {
+namespace adsb {
+namespace host {
 
-static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors TrialRecord");
-
-int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32_t *addrs_out, size_t cap,
-                    size_t *n_addrs)
+int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
 {
-    if (!c || (!device_iq && n_samples) || (!addrs_out && cap)) return ADSB_ERR_INVALID;
-    if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
-    if (n_addrs) *n_addrs = 0;
+    Slot &sl = c->slot[k];
+    adsb_ctx::ShardJob &job = c->shard[k];
+    if (job.active || sl.busy || sl.parked) return ADSB_ERR_BUSY;
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
-    if ((uintptr_t)device_iq % 16) return ADSB_ERR_INVALID;
-    // (the caller may be a worker thread whose current device is not this context's: sharding.ShardPipeline)
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (int rc = order_behind_slot0(c)) return rc;
-    Slot &sl = c->slot[0];
+    if (!job.h_addrs) {
+        HIP_TRY(c, hipHostMalloc((void **)&job.h_addrs, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_addrs_dev, job.h_addrs, 0));
+    }
     ScanParams p{};
-    p.src = device_iq;
+    p.src = d_iq;
     p.n_samples = n_samples;
     p.n_chunks = (uint32_t)n_chunks;
     p.clean_bitmap = nullptr;
-    uint32_t *retired = nullptr;
+    job.retired = nullptr;
     if (c->flush_pending) {
-        retired = c->d_bitmap[c->cur_bitmap];
+        job.retired = c->d_bitmap[c->cur_bitmap];
         c->cur_bitmap = (c->cur_bitmap + 1) % c->n_bitmaps;
         c->filter.flush();
         c->flush_pending = false;
         // the device-side copy of the filter (exact bitmap, k_score) still holds the addresses from
         // before the flush and was not rotated here: it is rebuilt from the (now empty) host table
-        // before the next device-scored pass -- the context is idle, nothing in flight to disown
+        // before the next device-scored pass
         c->exact_valid = false;
         ++c->score_epoch;
     }
@@ -101,47 +120,229 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     p.ctr = sl.d_ctr;
     p.summary = sl.h_sum_dev;
     p.keep_counters = 1;
-    sl.seq = c->next_seq++;
-    if (c->next_seq == 0) c->next_seq = 1;
+    sl.seq = next_seq(c);
     sl.h_sum->seq = 0;
     p.seq = sl.seq;
-    size_t n_hits = 0;
-    bool by_chunk = false;
-    if (n_chunks) {
-        if (int e = launch_scan(p, false, c->stream)) return fail(c, (hipError_t)e, "launch_scan");
-        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
-            c->last_error = "shard scan completed without publishing its summary";
-            return ADSB_ERR_HIP;
-        }
-        by_chunk = sl.h_sum->overflow != 0;
-        n_hits = sl.h_sum->n_hits;
-        if (!by_chunk)
-            if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n_hits)) return rc;
+    job.p = p;
+    job.by_chunk = false;
+    job.chunk_records.clear();
+    job.n_cand = job.n_ap = 0;
+    job.scan_q = nullptr;
+    job.waiting = false;
+    job.active = true;
+    if (!n_chunks) return ADSB_OK;   // (an empty shard: nothing to wait for, nothing learned)
+    // consecutive shards' scans alternate between the first two scan streams, like consecutive passes
+    hipStream_t ss = c->scan_stream[c->shard_jobs++ % 2], ts = c->tail_stream;
+    job.scan_q = ss;
+    // the caller's samples are complete where `stream` stands now (nothing to wait for on the context's own,
+    // idle stream: see enqueue_pass)
+    if (!(c->stream == c->own_stream && !c->own_stream_dirty)) {
+        hipEvent_t ready = c->input_ready[ss == c->scan_stream[0] ? 0 : 1];
+        HIP_TRY(c, hipEventRecord(ready, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(ss, ready, 0));
+        c->own_stream_dirty = false;
     }
-    std::vector<uint32_t> addrs;
-    if (by_chunk) {
+    if (int rc = order_behind_fused(c, sl, ss)) return rc;
+    if (int e = launch_scan(p, false, ss)) return fail(c, (hipError_t)e, "launch_scan");
+    HIP_TRY(c, hipEventRecord(sl.scanned, ss));
+    HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
+    if (int e = launch_records(p, false, sl.h_rec_dev, ts)) return fail(c, (hipError_t)e, "launch_records");
+    job.waiting = true;
+    return ADSB_OK;
+}
+
+bool shard_phase_landed(adsb_ctx *c, int k)
+{
+    adsb_ctx::ShardJob &job = c->shard[k];
+    if (!job.waiting) return true;
+    if (!summary_landed(c->slot[k].h_sum, c->slot[k].seq)) return false;
+    job.waiting = false;
+    return true;
+}
+
+int shard_phase_wait(adsb_ctx *c, int k)
+{
+    adsb_ctx::ShardJob &job = c->shard[k];
+    if (!job.waiting) return ADSB_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
+        if (shard_phase_landed(c, k)) return ADSB_OK;
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+    for (int attempt = 0; attempt < 200; attempt++) {
+        if (shard_phase_landed(c, k)) return ADSB_OK;
+        for (volatile int spin = 0; spin < 2000; spin++) {}
+    }
+    c->last_error = "shard phase completed without publishing a whole summary";
+    return ADSB_ERR_HIP;
+}
+
+// after phase 1 has landed: the addresses this shard's replay can add, sorted, no duplicates
+int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
+{
+    Slot &sl = c->slot[k];
+    adsb_ctx::ShardJob &job = c->shard[k];
+    addrs.clear();
+    if (!job.active || job.waiting) return ADSB_ERR_INVALID;
+    const ScanParams &p = job.p;
+    if (!p.n_chunks) return ADSB_OK;
+    job.by_chunk = sl.h_sum->overflow != 0;
+    const size_t n_hits = sl.h_sum->n_hits;
+    if (!job.by_chunk) {
+        if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n_hits)) return rc;
+        learned_addresses(c->crc, sl.h_rec, n_hits, addrs);
+    } else {
         // Far denser than the fast scan's lists are sized for: zero this pass's counters (the
         // records kernel does that on its way out), then both phases go buffer by buffer
         // through the reference-shaped kernel, whose lists hold a buffer's worst case.
+        if (int rc = drain_for_chunk_path(c, job)) return rc;
         ScanParams q = p;
         q.keep_counters = 0;
         if (int e = launch_records(q, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (uint64_t ch = 0; ch < n_chunks; ch++) {
-            size_t k = 0;
-            if (int rc = shard_chunk_pass(c, p, ch, false, nullptr, &k)) return rc;
-            learned_addresses(c->crc, c->fb.h_rec, k, addrs);
+        for (uint64_t ch = 0; ch < p.n_chunks; ch++) {
+            size_t n = 0;
+            if (int rc = shard_chunk_pass(c, sl, p, ch, false, nullptr, &n)) return rc;
+            learned_addresses(c->crc, c->fb.h_rec, n, addrs);
         }
-    } else {
-        learned_addresses(c->crc, sl.h_rec, n_hits, addrs);
     }
-    c->shard_by_chunk = by_chunk;
     std::sort(addrs.begin(), addrs.end());
     addrs.erase(std::unique(addrs.begin(), addrs.end()), addrs.end());
-    p.clean_bitmap = retired;
-    c->shard_params = p;
+    return ADSB_OK;
+}
+
+int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
+{
+    Slot &sl = c->slot[k];
+    adsb_ctx::ShardJob &job = c->shard[k];
+    if (!job.active || job.waiting) return ADSB_ERR_INVALID;
+    ScanParams &p = job.p;
+    hipStream_t ts = c->tail_stream;
+    p.keep_counters = 0;
+    p.clean_bitmap = job.retired;
+    // the other shards' addresses join this shard's superset: read by the kernel from the slot's mapped host
+    // buffer, no copy command (a capture teaches a few hundred at most; the buffer is the slot's own, free again
+    // when the shard has been collected)
+    if (n_extra && n_extra <= kShardAddrCap) {
+        std::memcpy(job.h_addrs, extra, n_extra * sizeof(uint32_t));
+        if (int e = launch_set_addresses(job.h_addrs_dev, (uint32_t)n_extra, p.bitmap, ts))
+            return fail(c, (hipError_t)e, "launch_set_addresses");
+    } else if (n_extra) {
+        // (more than a capture can teach: a caller's own union through adsb_shard_finish -- a device buffer, blocking)
+        if (n_extra > c->addrs_cap) {
+            if (c->d_addrs) (void)hipFree(c->d_addrs);
+            c->d_addrs = nullptr;
+            c->addrs_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_addrs, n_extra * sizeof(uint32_t)));
+            c->addrs_cap = n_extra;
+        }
+        HIP_TRY(c, hipStreamSynchronize(ts));   // (d_addrs may still be read by an earlier shard's launch)
+        HIP_TRY(c, hipMemcpy(c->d_addrs, extra, n_extra * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, ts))
+            return fail(c, (hipError_t)e, "launch_set_addresses");
+    }
+    if (!p.n_chunks) {
+        // an empty shard has no records kernel to clean the bitmap a flush retired
+        if (job.retired)
+            if (int e = launch_reset(sl.d_ctr, job.retired, ts)) return fail(c, (hipError_t)e, "launch_reset");
+        if (n_extra || job.retired) HIP_TRY(c, hipStreamSynchronize(ts));   // (h_addrs is free again; nothing else to wait for)
+        return ADSB_OK;
+    }
+    if (!job.by_chunk) {
+        sl.seq = next_seq(c);
+        sl.h_sum->seq = 0;
+        p.seq = sl.seq;
+        if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
+        if (int e = launch_records(p, false, sl.h_rec_dev, ts)) return fail(c, (hipError_t)e, "launch_records");
+        job.waiting = true;
+    }
+    return ADSB_OK;
+}
+
+// after phase 2 has landed: the shard's raw trial records (chunk = buffer index within the shard); they stay
+// valid until the slot's next shard_begin
+int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
+{
+    Slot &sl = c->slot[k];
+    adsb_ctx::ShardJob &job = c->shard[k];
+    *rec = nullptr;
+    *n_out = 0;
+    if (!job.active || job.waiting) return ADSB_ERR_INVALID;
+    ScanParams &p = job.p;
+    job.active = false;
+    adsb_stats st{};
+    st.n_samples = p.n_samples;
+    st.n_chunks = p.n_chunks;
+    if (!p.n_chunks) {
+        c->stats = st;
+        return ADSB_OK;
+    }
+    if (!job.by_chunk) {
+        // the matched address/parity trials did not fit the hit list (a large union of addresses
+        // over a dense shard): buffer by buffer, like a shard whose scan overflowed.  (The
+        // records kernel has zeroed the counters and cleaned the retired bitmap on its way out.)
+        if (sl.h_sum->overflow) {
+            job.by_chunk = true;
+            p.clean_bitmap = nullptr;
+        } else {
+            const size_t n = sl.h_sum->n_hits;
+            if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+            st.n_candidates = sl.h_sum->n_cand_total;
+            st.n_ap_entries = sl.h_sum->n_ap_total;
+            st.n_records = n;
+            c->stats = st;
+            *rec = sl.h_rec;
+            *n_out = n;
+            return ADSB_OK;
+        }
+    }
+    if (int rc = drain_for_chunk_path(c, job)) return rc;
+    std::vector<TrialRecord> &all = job.chunk_records;
+    all.clear();
+    for (uint64_t ch = 0; ch < p.n_chunks; ch++) {
+        size_t n = 0;
+        uint32_t *clean = ch + 1 == p.n_chunks ? p.clean_bitmap : nullptr;
+        if (int rc = shard_chunk_pass(c, sl, p, ch, true, clean, &n)) return rc;
+        for (size_t i = 0; i < n; i++) {
+            TrialRecord r = c->fb.h_rec[i];
+            r.chunk = (uint32_t)ch;
+            all.push_back(r);
+        }
+        st.n_candidates += sl.h_sum->n_cand_total;
+        st.n_ap_entries += sl.h_sum->n_ap_total;
+    }
+    st.n_records = all.size();
+    st.retries = 1;
+    c->stats = st;
+    *rec = all.data();
+    *n_out = all.size();
+    return ADSB_OK;
+}
+
+}  // namespace host
+}  // namespace adsb
+
+extern "C" {
+
+int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32_t *addrs_out, size_t cap,
+                    size_t *n_addrs)
+{
+    if (!c || (!device_iq && n_samples) || (!addrs_out && cap)) return ADSB_ERR_INVALID;
+    if (c->submitted != c->delivered || c->shard_active || c->shard[0].active) return ADSB_ERR_BUSY;
+    if (n_addrs) *n_addrs = 0;
+    if ((uintptr_t)device_iq % 16) return ADSB_ERR_INVALID;
+    // (the caller may be a worker thread whose current device is not this context's: sharding.ShardPipeline)
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = shard_begin(c, 0, device_iq, n_samples)) return rc;
+    std::vector<uint32_t> addrs;
+    int rc = shard_phase_wait(c, 0);
+    if (rc == ADSB_OK) rc = shard_learned(c, 0, addrs);
+    if (rc != ADSB_OK) {
+        c->shard[0].active = c->shard[0].waiting = false;
+        return rc;
+    }
     c->shard_active = true;
     if (n_addrs) *n_addrs = addrs.size();
     const size_t k = std::min(cap, addrs.size());
@@ -156,88 +357,20 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
     if (!c->shard_active) return ADSB_ERR_INVALID;
     if (n_records) *n_records = 0;
     HIP_TRY(c, hipSetDevice(c->device));
-    Slot &sl = c->slot[0];
-    ScanParams p = c->shard_params;
-    p.keep_counters = 0;
     c->shard_active = false;
-    if (n_extra) {
-        if (n_extra > c->addrs_cap) {
-            if (c->d_addrs) (void)hipFree(c->d_addrs);
-            c->d_addrs = nullptr;
-            c->addrs_cap = 0;
-            HIP_TRY(c, hipMalloc((void **)&c->d_addrs, n_extra * sizeof(uint32_t)));
-            c->addrs_cap = n_extra;
-        }
-        HIP_TRY(c, hipMemcpyAsync(c->d_addrs, extra_addrs, n_extra * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                  c->stream));
-        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, c->stream))
-            return fail(c, (hipError_t)e, "launch_set_addresses");
-    }
-    bool by_chunk = c->shard_by_chunk;
-    c->shard_by_chunk = false;
+    const TrialRecord *rec = nullptr;
     size_t n = 0;
-    if (!by_chunk && p.n_chunks) {
-        sl.seq = c->next_seq++;
-        if (c->next_seq == 0) c->next_seq = 1;
-        sl.h_sum->seq = 0;
-        p.seq = sl.seq;
-        if (int e = launch_match(p, c->stream)) return fail(c, (hipError_t)e, "launch_match");
-        if (int e = launch_records(p, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (__atomic_load_n(&sl.h_sum->seq, __ATOMIC_ACQUIRE) != sl.seq) {
-            c->last_error = "shard finish completed without publishing its summary";
-            return ADSB_ERR_HIP;
-        }
-        // the matched address/parity trials did not fit the hit list (a large union of addresses
-        // over a dense shard): buffer by buffer, like a shard whose scan overflowed.  (The
-        // records kernel has zeroed the counters and cleaned the retired bitmap on its way out.)
-        if (sl.h_sum->overflow) {
-            by_chunk = true;
-            p.clean_bitmap = nullptr;
-        }
-        n = sl.h_sum->n_hits;
-        if (!by_chunk)
-            if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    int rc = shard_match(c, 0, extra_addrs, n_extra);
+    if (rc == ADSB_OK) rc = shard_phase_wait(c, 0);
+    if (rc == ADSB_OK) rc = shard_records(c, 0, &rec, &n);
+    if (rc != ADSB_OK) {
+        c->shard[0].active = c->shard[0].waiting = false;
+        return rc;
     }
-    if (by_chunk) {
-        std::vector<TrialRecord> all;
-        uint64_t cand = 0, ap = 0;
-        for (uint64_t ch = 0; ch < p.n_chunks; ch++) {
-            size_t k = 0;
-            uint32_t *clean = ch + 1 == p.n_chunks ? p.clean_bitmap : nullptr;
-            if (int rc = shard_chunk_pass(c, p, ch, true, clean, &k)) return rc;
-            for (size_t i = 0; i < k; i++) {
-                TrialRecord r = c->fb.h_rec[i];
-                r.chunk = (uint32_t)ch;
-                all.push_back(r);
-            }
-            cand += sl.h_sum->n_cand_total;
-            ap += sl.h_sum->n_ap_total;
-        }
-        adsb_stats st{};
-        st.n_samples = p.n_samples;
-        st.n_chunks = p.n_chunks;
-        st.n_candidates = cand;
-        st.n_ap_entries = ap;
-        st.n_records = all.size();
-        st.retries = 1;
-        c->stats = st;
-        if (n_records) *n_records = all.size();
-        const size_t k = std::min(cap, all.size());
-        if (k) std::memcpy(records_out, all.data(), k * sizeof(adsb_trial));
-        return all.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-    }
-    adsb_stats st{};
-    st.n_samples = p.n_samples;
-    st.n_chunks = p.n_chunks;
-    st.n_candidates = p.n_chunks ? sl.h_sum->n_cand_total : 0;
-    st.n_ap_entries = p.n_chunks ? sl.h_sum->n_ap_total : 0;
-    st.n_records = n;
-    c->stats = st;
     if (n_records) *n_records = n;
     const size_t k = std::min(cap, n);
     static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "record layout is the ABI's");
-    if (k) std::memcpy(records_out, sl.h_rec, k * sizeof(adsb_trial));
+    if (k) std::memcpy(records_out, rec, k * sizeof(adsb_trial));
     return n > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
 }
 

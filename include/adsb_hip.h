@@ -262,6 +262,75 @@ int adsb_shard_scan(adsb_ctx *ctx, const void *device_iq, size_t n_samples, uint
 int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra,
                       adsb_trial *records_out, size_t cap, size_t *n_records);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * One capture over several GPUs from ONE process (BASELINE config 4).  The reference is one process with
+ * one loop and one process-global filter (dump1090_rs/src/main.rs:154-167, src/icao_filter.rs:8-9); an
+ * adsb_multi keeps that shape for its caller -- one handle, one ICAO filter, one message list in the
+ * reference's order -- over N devices: the capture is cut into contiguous ranges of 131072-sample buffers,
+ * one per device; inside, a context and a host thread per device run the two shard phases above, the
+ * learned addresses are united in memory between them, and the caller's thread replays all shards' trial
+ * records once, in global (buffer, j, try_phase) order, through the one filter.  No process group, no
+ * collective, nothing outside this library.  The result is the single-stream one, bit for bit.
+ *
+ *   adsb_multi_create        a context on each of devices[0..n) (a device may appear more than once: then
+ *                            its shards share it), each for up to max_chunks_per_device buffers per capture
+ *   adsb_multi_icao_flush    == icao_flush() for the ONE filter; applies to the captures submitted after it
+ *   adsb_multi_demod_iq      a host capture of any length: cut, copied to the devices, demodulated (blocking)
+ *   adsb_multi_demod_iq_device  the shards already resident: device_iq[k] / n_samples[k] = device k's range
+ *                            (16-byte aligned; whole buffers except the capture's last non-empty shard;
+ *                            adsb_multi_shard_range gives the even split), blocking
+ *   adsb_multi_submit_iq_device / adsb_multi_collect   the same, asynchronously: up to
+ *                            adsb_multi_max_in_flight (4) captures in flight, results in submission order;
+ *                            the scans of capture i + 1 run while capture i is exchanged, matched and
+ *                            replayed.  The samples must be complete (their producer synchronised) before
+ *                            the call and unchanged until the capture is collected.
+ * adsb_msg.chunk is the buffer's index in the whole capture.  Errors and ADSB_ERR_CAPACITY behave as for
+ * the one-device calls (adsb_multi_fetch_messages hands out the whole list of a capture whose `out` was too
+ * small).  One adsb_multi is driven by one host thread at a time. */
+typedef struct adsb_multi adsb_multi;
+typedef struct {
+    uint64_t n_samples;
+    uint64_t n_chunks;
+    uint64_t n_candidates;
+    uint64_t n_ap_entries;
+    uint64_t n_records;          /* trial records replayed on the host */
+    uint64_t n_messages;
+    uint64_t n_addrs_exchanged;  /* learned addresses handed to every device between the phases */
+    uint32_t n_devices;
+    uint32_t retries;            /* shards that went buffer by buffer (list overflow) */
+    float ms_wall;               /* submit -> the last device's records on the host (host clock) */
+    float ms_phase1_max;         /* slowest device: phase 1 issued -> its summary seen (scan + records of learned frames) */
+    float ms_phase2_max;         /* slowest device: phase 2 issued -> its summary seen (set addresses, match, records) */
+    float ms_phase1_span;        /* first device's phase-1 issue -> last device's phase-1 summary */
+    float ms_phase2_span;        /* ... the same for phase 2: ms_wall - the two spans = what the orchestration adds */
+    float ms_exchange;           /* the union of the learned addresses + handing phase 2 to every device thread */
+    float ms_replay;             /* the ordered replay in adsb_multi_collect */
+    float reserved;
+} adsb_multi_stats;
+
+int adsb_multi_create(adsb_multi **out, const int *devices, int n_devices, size_t max_chunks_per_device);
+void adsb_multi_destroy(adsb_multi *m);
+int adsb_multi_device_count(const adsb_multi *m);
+int adsb_multi_max_in_flight(const adsb_multi *m);
+/* Device k's contiguous share of a capture of n_samples cut n_devices ways: whole buffers, sizes that differ by at
+ * most one buffer, the ragged end with whoever holds the last buffer.  Host only. */
+int adsb_multi_shard_range(size_t n_samples, int n_devices, int k, size_t *first_sample, size_t *n_samples_k);
+int adsb_multi_icao_flush(adsb_multi *m);
+int adsb_multi_demod_iq(adsb_multi *m, const int16_t *iq_re_im, size_t n_samples, adsb_msg *out, size_t cap,
+                        size_t *n_out);
+int adsb_multi_demod_iq_device(adsb_multi *m, const void *const *device_iq, const size_t *n_samples, adsb_msg *out,
+                               size_t cap, size_t *n_out);
+int adsb_multi_submit_iq_device(adsb_multi *m, const void *const *device_iq, const size_t *n_samples);
+int adsb_multi_collect(adsb_multi *m, adsb_msg *out, size_t cap, size_t *n_out);
+int adsb_multi_pending(const adsb_multi *m);
+int adsb_multi_fetch_messages(adsb_multi *m, adsb_msg *out, size_t cap, size_t *n_out);
+/* Counters and host-clock timings of the capture collected last. */
+int adsb_multi_get_stats(const adsb_multi *m, adsb_multi_stats *out);
+/* Table A of the one filter (4096 u32, src/icao_filter.rs:8), for inspection.  ADSB_ERR_BUSY while captures are
+ * in flight. */
+int adsb_multi_filter_table(const adsb_multi *m, uint32_t *out4096);
+const char *adsb_multi_last_error(const adsb_multi *m);
+
 /* Host only, no device needed: the ordered replay every demod call ends with
  * (score_modes_message src/mode_s/mod.rs:34-139 + best-of-5 selection
  * src/demod_2400.rs:149-207 + icao_filter src/icao_filter.rs), exposed so the

@@ -58,8 +58,37 @@ pub struct AdsbStats {
     pub ms_scan_exclusive: f32,
 }
 
+/// `adsb_multi_stats`: counters and host-clock timings of the capture an `adsb_multi` collected last.  96 bytes.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct AdsbMultiStats {
+    pub n_samples: u64,
+    pub n_chunks: u64,
+    pub n_candidates: u64,
+    pub n_ap_entries: u64,
+    pub n_records: u64,
+    pub n_messages: u64,
+    pub n_addrs_exchanged: u64,
+    pub n_devices: u32,
+    pub retries: u32,
+    pub ms_wall: f32,
+    pub ms_phase1_max: f32,
+    pub ms_phase2_max: f32,
+    pub ms_phase1_span: f32,
+    pub ms_phase2_span: f32,
+    pub ms_exchange: f32,
+    pub ms_replay: f32,
+    pub reserved: f32,
+}
+
 #[repr(C)]
 pub struct AdsbCtx {
+    _private: [u8; 0],
+}
+
+/// One capture over several GPUs from one process: one handle, one filter (`adsb_multi_*`).
+#[repr(C)]
+pub struct AdsbMulti {
     _private: [u8; 0],
 }
 
@@ -86,6 +115,21 @@ unsafe extern "C" {
     pub fn adsb_ring_submit(ctx: *mut AdsbCtx, n_samples: usize) -> c_int;
     pub fn adsb_shard_scan(ctx: *mut AdsbCtx, device_iq: *const c_void, n_samples: usize, addrs_out: *mut u32, cap: usize, n_addrs: *mut usize) -> c_int;
     pub fn adsb_shard_finish(ctx: *mut AdsbCtx, extra_addrs: *const u32, n_extra: usize, records_out: *mut AdsbTrial, cap: usize, n_records: *mut usize) -> c_int;
+    pub fn adsb_multi_create(out: *mut *mut AdsbMulti, devices: *const c_int, n_devices: c_int, max_chunks_per_device: usize) -> c_int;
+    pub fn adsb_multi_destroy(m: *mut AdsbMulti);
+    pub fn adsb_multi_device_count(m: *const AdsbMulti) -> c_int;
+    pub fn adsb_multi_max_in_flight(m: *const AdsbMulti) -> c_int;
+    pub fn adsb_multi_shard_range(n_samples: usize, n_devices: c_int, k: c_int, first_sample: *mut usize, n_samples_k: *mut usize) -> c_int;
+    pub fn adsb_multi_icao_flush(m: *mut AdsbMulti) -> c_int;
+    pub fn adsb_multi_demod_iq(m: *mut AdsbMulti, iq_re_im: *const i16, n_samples: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_multi_demod_iq_device(m: *mut AdsbMulti, device_iq: *const *const c_void, n_samples: *const usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_multi_submit_iq_device(m: *mut AdsbMulti, device_iq: *const *const c_void, n_samples: *const usize) -> c_int;
+    pub fn adsb_multi_collect(m: *mut AdsbMulti, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_multi_pending(m: *const AdsbMulti) -> c_int;
+    pub fn adsb_multi_fetch_messages(m: *mut AdsbMulti, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn adsb_multi_get_stats(m: *const AdsbMulti, out: *mut AdsbMultiStats) -> c_int;
+    pub fn adsb_multi_filter_table(m: *const AdsbMulti, out4096: *mut u32) -> c_int;
+    pub fn adsb_multi_last_error(m: *const AdsbMulti) -> *const c_char;
     pub fn adsb_replay_records(filter_table: *mut u32, records: *mut AdsbTrial, n: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_format_raw(msg: *const AdsbMsg, out: *mut c_char, out_size: usize) -> c_int;
     pub fn adsb_read_test_data(path: *const c_char, iq_re_im: *mut i16, max_samples: usize, n_out: *mut usize) -> c_int;

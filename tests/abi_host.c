@@ -38,16 +38,85 @@ _Static_assert(offsetof(adsb_trial, power) == 0 && offsetof(adsb_trial, chunk) =
 _Static_assert(sizeof(adsb_stats) == 72, "adsb_stats is 72 bytes");
 _Static_assert(offsetof(adsb_stats, n_messages) == 40 && offsetof(adsb_stats, ms_scan) == 48 &&
                offsetof(adsb_stats, retries) == 64 && offsetof(adsb_stats, ms_scan_exclusive) == 68, "adsb_stats field offsets");
+_Static_assert(sizeof(adsb_multi_stats) == 96, "adsb_multi_stats is 96 bytes");
+_Static_assert(offsetof(adsb_multi_stats, n_addrs_exchanged) == 48 && offsetof(adsb_multi_stats, n_devices) == 56 &&
+               offsetof(adsb_multi_stats, retries) == 60 && offsetof(adsb_multi_stats, ms_wall) == 64 &&
+               offsetof(adsb_multi_stats, ms_replay) == 88, "adsb_multi_stats field offsets");
 _Static_assert(ADSB_OK == 0 && ADSB_ERR_INVALID == -1 && ADSB_ERR_NO_DEVICE == -2 && ADSB_ERR_HIP == -3 && ADSB_ERR_TOO_LONG == -4 &&
                ADSB_ERR_CAPACITY == -5 && ADSB_ERR_NOMEM == -6 && ADSB_ERR_BUSY == -7, "status codes");
 _Static_assert(ADSB_MAG_DATA_LEN == 131398 && ADSB_MAX_IN_FLIGHT == 4 && ADSB_MAX_IN_FLIGHT_SMALL == 8, "buffer geometry");
 
+static int check_frames(const adsb_msg *msgs, size_t n, int n_want, char **want_hex)
+{
+    int rc = (n == (size_t)n_want) ? 0 : 1;
+    for (size_t i = 0; i < n; i++) {
+        char hex[2 * ADSB_MODES_LONG_MSG_BYTES + 1];
+        for (unsigned k = 0; k < msgs[i].len; k++) sprintf(hex + 2 * k, "%02x", msgs[i].msg[k]);  /* buffer() */
+        const char *want = i < (size_t)n_want ? want_hex[i] : "(none)";
+        const int same = strcmp(hex, want) == 0;
+        printf("%s %s\n", hex, same ? "ok" : want);
+        if (!same) rc = 1;
+    }
+    if (n != (size_t)n_want) fprintf(stderr, "%zu frames, %d expected\n", n, n_want);
+    return rc;
+}
+
+/* abi_host --multi N <capture.iq> frames...: the same capture as ONE capture over N contexts on device 0 through
+ * adsb_multi_* -- the single-process multi-GPU entry points from a compiled host, no Python, no process group:
+ * each of the N shards holds a contiguous share of the 131072 samples... of a capture made of N copies of the
+ * file, so every shard has whole buffers: the frames of the file come out N times, buffer after buffer. */
+static int run_multi(int n_dev, int argc, char **argv)
+{
+    int devices[64];
+    if (n_dev < 1 || n_dev > 64 || argc < 1) return 2;
+    for (int k = 0; k < n_dev; k++) devices[k] = 0;
+    adsb_multi *m = NULL;
+    int st = adsb_multi_create(&m, devices, n_dev, 2);
+    if (st != ADSB_OK) {
+        fprintf(stderr, "adsb_multi_create: %s\n", adsb_strerror(st));
+        return 3;
+    }
+    const size_t per = ADSB_MODES_MAG_BUF_SAMPLES;
+    int16_t *iq = malloc(per * 2 * sizeof(int16_t) * (size_t)n_dev);
+    adsb_msg *msgs = malloc(sizeof(adsb_msg) * 256 * (size_t)n_dev);
+    size_t n_iq = 0, n = 0;
+    int rc = 1;
+    if (!iq || !msgs) goto out;
+    st = adsb_read_test_data(argv[0], iq, per, &n_iq);
+    if (st != ADSB_OK || n_iq != per) goto out;
+    for (int k = 1; k < n_dev; k++) memcpy(iq + 2 * per * (size_t)k, iq, per * 2 * sizeof(int16_t));
+    st = adsb_multi_icao_flush(m);
+    if (st == ADSB_OK) st = adsb_multi_demod_iq(m, iq, per * (size_t)n_dev, msgs, 256 * (size_t)n_dev, &n);
+    if (st != ADSB_OK) {
+        fprintf(stderr, "%s (%s)\n", adsb_strerror(st), adsb_multi_last_error(m));
+        goto out;
+    }
+    /* the first copy of the file: exactly the reference's frames (tests/test.rs), in buffer 0 */
+    size_t n0 = 0;
+    while (n0 < n && msgs[n0].chunk == 0) n0++;
+    rc = check_frames(msgs, n0, argc - 1, argv + 1);
+    /* every later copy is scored by a filter that already knows the capture's aircraft: at least as many frames,
+     * in ascending buffer order */
+    for (size_t i = 1; i < n; i++)
+        if (msgs[i].chunk < msgs[i - 1].chunk || msgs[i].chunk >= (uint64_t)n_dev) rc = 1;
+    adsb_multi_stats ms;
+    if (adsb_multi_get_stats(m, &ms) != ADSB_OK || ms.n_devices != (uint32_t)n_dev || ms.n_messages != n) rc = 1;
+    printf("multi: %d devices, %zu frames, %llu records, %llu addresses exchanged\n", n_dev, n,
+           (unsigned long long)ms.n_records, (unsigned long long)ms.n_addrs_exchanged);
+out:
+    free(iq);
+    free(msgs);
+    adsb_multi_destroy(m);
+    return rc;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <capture.iq> [expected hex frames...]\n", argv[0]);
+        fprintf(stderr, "usage: %s [--multi N] <capture.iq> [expected hex frames...]\n", argv[0]);
         return 2;
     }
+    if (strcmp(argv[1], "--multi") == 0) return argc < 4 ? 2 : run_multi(atoi(argv[2]), argc - 3, argv + 3);
     adsb_ctx *ctx = NULL;
     int st = adsb_create(&ctx, 0, 1);
     if (st != ADSB_OK) {
@@ -69,16 +138,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s (%s)\n", adsb_strerror(st), adsb_last_error(ctx));
         goto out;
     }
-    rc = (n == (size_t)(argc - 2)) ? 0 : 1;
-    for (size_t i = 0; i < n; i++) {
-        char hex[2 * ADSB_MODES_LONG_MSG_BYTES + 1];
-        for (unsigned k = 0; k < msgs[i].len; k++) sprintf(hex + 2 * k, "%02x", msgs[i].msg[k]);  /* buffer() */
-        const char *want = i + 2 < (size_t)argc ? argv[i + 2] : "(none)";
-        const int same = strcmp(hex, want) == 0;
-        printf("%s %s\n", hex, same ? "ok" : want);
-        if (!same) rc = 1;
-    }
-    if (n != (size_t)(argc - 2)) fprintf(stderr, "%zu frames, %d expected\n", n, argc - 2);
+    rc = check_frames(msgs, n, argc - 2, argv + 2);
 out:
     free(iq);
     free(data);

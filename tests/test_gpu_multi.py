@@ -1,0 +1,314 @@
+"""adsb_multi_*: ONE process, N GPUs, one filter -- BASELINE config 4 behind the C ABI.
+
+The reference is one loop with one process-global ICAO filter (dump1090_rs/src/main.rs:154-167,
+src/icao_filter.rs:8-9).  An adsb_multi cuts a capture into contiguous ranges of 131072-sample buffers, one per
+device, runs the two shard phases on a thread per device, unites the learned addresses in memory and replays all
+shards' trial records once through ONE filter.  On the one-GPU test box `devices = [0] * 8` (eight contexts,
+eight threads, one device) stands in for eight GPUs; wherever the box has several devices the same tests run over
+`range(device_count)` as well.  Every result is compared with the CPU oracle over the whole capture AND with the
+single-stream GPU result.
+"""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+
+from dump1090_rs_amd import synth
+from tests.conftest import GOLDEN, ROOT
+from tests.test_gpu_shard8 import (CHUNK, DF4_A, DF4_B, DF20_C, ICAO_A, ICAO_B, ICAO_C, N_SAMPLES, coupled_capture8, key,
+                                   preface_capture, want_key)
+
+pytestmark = pytest.mark.gpu
+
+
+def device_sets():
+    """[0] * 8 and [0] * 3 always; every real device once, and twice round, when the box has more than one."""
+    import torch
+    sets = [[0] * 8, [0] * 3, [0]]
+    n = torch.cuda.device_count()
+    if n >= 2:
+        sets += [list(range(n)), [k % n for k in range(2 * n)], list(range(n - 1, -1, -1))]
+    return sets
+
+
+def to_devices(iq, multi, torch):
+    """The capture's contiguous ranges, each resident on its device: (tensors, pointers, sample counts)."""
+    tensors, ptrs, ns = [], [], []
+    for dev, (a, n) in zip(multi.devices, multi.shard_ranges(len(iq))):
+        t = torch.from_numpy(np.ascontiguousarray(iq[a:a + n])).to(f"cuda:{dev}") if n else None
+        tensors.append(t)
+        ptrs.append(t.data_ptr() if n else 0)
+        ns.append(n)
+    for dev in set(multi.devices):
+        torch.cuda.synchronize(dev)
+    return tensors, ptrs, ns
+
+
+@pytest.mark.parametrize("which", range(6))
+def test_one_capture_over_n_devices_with_a_preloaded_filter_equals_single_stream_and_oracle(hip_lib, oracle_mod, which):
+    """The coupled capture of tests/test_gpu_shard8.py (38 buffers, the last ragged; an address taught in one shard
+    that frames in three others need; a DF11-taught address for a 112-bit DF20 three shards on; a filter that is NOT
+    empty when the capture starts) through adsb_multi_demod_iq (host capture) and adsb_multi_demod_iq_device
+    (resident shards): equal to the oracle and to one context demodulating the capture alone."""
+    import torch
+    from dump1090_rs_amd import Context
+    from dump1090_rs_amd.multi import MultiContext
+    sets = device_sets()
+    if which >= len(sets):
+        pytest.skip("one HIP device: the [0] * n forms cover the code, more devices add the placement")
+    devices = sets[which]
+    iq, pre = coupled_capture8(), preface_capture()
+    orc = oracle_mod.Oracle()
+    want_pre, _ = orc.demod_iq(pre)
+    want, _ = orc.demod_iq(iq)                       # the filter persists from the preface
+    cold_want, _ = oracle_mod.Oracle().demod_iq(iq)
+
+    with Context(devices[0], 8) as solo:
+        solo.icao_flush()
+        solo.demod_iq(pre)
+        single = solo.demod_iq(iq)
+    assert [key(m) for m in single] == [want_key(w) for w in want]
+
+    per = -(-38 // len(devices))
+    with MultiContext(devices, per) as multi:
+        assert multi.shard_ranges(N_SAMPLES)[0][0] == 0 and sum(n for _, n in multi.shard_ranges(N_SAMPLES)) == N_SAMPLES
+        if len(devices) == 8:
+            assert [-(-n // CHUNK) for _, n in multi.shard_ranges(N_SAMPLES)] == [5, 5, 5, 5, 5, 5, 4, 4]
+        # host capture
+        multi.icao_flush()
+        assert [key(m) for m in multi.demod_iq(pre)] == [want_key(w) for w in want_pre]
+        assert ICAO_B in multi.filter_table().tolist() and np.count_nonzero(multi.filter_table()) == 1
+        got = multi.demod_iq(iq)
+        assert [key(m) for m in got] == [want_key(w) for w in want]
+        assert [key(m) for m in got] == [key(m) for m in single]
+        st = multi.stats()
+        assert st["n_devices"] == len(devices) and st["n_messages"] == len(want) and st["n_samples"] == N_SAMPLES
+        assert st["n_chunks"] == 38 and st["retries"] == 0 and st["n_records"] >= len(want)
+        if len(devices) > 1:
+            assert st["n_addrs_exchanged"] >= 2        # A and C at least travelled between shards
+        # the couplings really are in the capture
+        chunks_of = lambda frame: sorted({m.chunk for m in got if m.buffer() == frame})
+        assert chunks_of(DF4_A) == [8, 31, 37]          # not 2: A is not known yet
+        assert chunks_of(DF4_B) == [0, 27]              # only because the filter held B already
+        assert chunks_of(DF20_C) == [22]                # not 12
+        table = multi.filter_table().tolist()
+        assert ICAO_A in table and ICAO_B in table and ICAO_C in table
+        # resident shards, behind a flush: no preface, so B's frames are gone
+        tensors, ptrs, ns = to_devices(iq, multi, torch)
+        multi.icao_flush()
+        cold = multi.demod_iq_device(ptrs, ns)
+        assert [key(m) for m in cold] == [want_key(w) for w in cold_want]
+        assert not [m for m in cold if m.buffer() == DF4_B]
+        # ... and again without a flush: the filter is warm, on both sides
+        orc2 = oracle_mod.Oracle()
+        orc2.demod_iq(iq)
+        warm_want, _ = orc2.demod_iq(iq)
+        assert [key(m) for m in multi.demod_iq_device(ptrs, ns)] == [want_key(w) for w in warm_want]
+        del tensors
+
+
+def test_captures_in_flight_four_deep_with_flushes_between_some(hip_lib, oracle_mod):
+    """adsb_multi_submit_iq_device / adsb_multi_collect: ten captures over eight contexts, four in flight, an
+    icao_flush in front of some: results in submission order, each equal to ONE oracle stream that flushes at the
+    same points -- the scans of capture i + 1 run while capture i is exchanged, matched and replayed, and the
+    address a capture learns must reach the next one's match although that was scanned before the replay."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    seeds = [4108, 4109, 4110, 4111, 4112, 4113, 4114, 4115, 4116, 4117]
+    flush_before = {0, 3, 4, 8}
+    caps = []
+    for i, s in enumerate(seeds):
+        iq = coupled_capture8(s)
+        if i % 3 == 1:
+            iq = iq[: 21 * CHUNK + 555]              # a shorter capture: other ranges, some shards nearly empty
+        if i == 6:
+            iq = iq[: 3 * CHUNK]                     # three buffers over eight devices: five empty shards
+        caps.append(np.ascontiguousarray(iq))
+    orc = oracle_mod.Oracle()
+    wants = []
+    for i, iq in enumerate(caps):
+        if i in flush_before:
+            orc.icao_flush()
+        wants.append(orc.demod_iq(iq)[0])
+    # (capture 1 follows capture 0 without a flush: the DF4 for A in its buffer 2 is found now)
+    assert sum(w["buffer"] == DF4_A and w["chunk"] == 2 for w in wants[1]) == 1
+    assert sum(w["buffer"] == DF4_A and w["chunk"] == 2 for w in wants[0]) == 0
+    with MultiContext([0] * 8, 5) as multi:
+        depth = multi.max_in_flight()
+        assert depth == 4
+        resident = [to_devices(iq, multi, torch) for iq in caps]
+        gots, refused = [], 0
+        for i in range(len(caps)):
+            if multi.pending() == depth:
+                with pytest.raises(Exception):           # a fifth capture in flight is refused, not queued
+                    multi.submit_iq_device(resident[i][1], resident[i][2])
+                refused += 1
+                assert multi.pending() == depth
+                gots.append(multi.collect())
+            if i in flush_before:
+                multi.icao_flush()
+            multi.submit_iq_device(resident[i][1], resident[i][2])
+        assert refused == len(caps) - depth
+        while multi.pending():
+            gots.append(multi.collect())
+        assert len(gots) == len(caps)
+        for i, (g, w) in enumerate(zip(gots, wants)):
+            assert [key(m) for m in g] == [want_key(x) for x in w], f"capture {i}"
+
+
+def test_small_ragged_and_empty_captures(hip_lib, oracle_mod):
+    """Fewer buffers than devices, a capture shorter than one buffer, an empty capture: shards without samples
+    still take part in the exchange (their superset must learn what the others taught)."""
+    from dump1090_rs_amd.multi import MultiContext
+    icao = 0x3C6589
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    a = synth.make_iq(2 * CHUNK, n_bursts=10, seed=321, n_icao=3)
+    synth.add_bursts(a, [synth.Burst(5 * 50000 + 2, 22000, 3, synth.df17_frame(icao, 9))])
+    b = synth.make_iq(7 * CHUNK + 99, n_bursts=20, seed=322, n_icao=3)
+    synth.add_bursts(b, [synth.Burst(5 * (k * CHUNK + 4000 + 17 * k) + k % 5, 21000, k, df4) for k in range(7)])
+    c = synth.make_iq(4321, n_bursts=0, seed=323)
+    orc = oracle_mod.Oracle()
+    want = [orc.demod_iq(x)[0] for x in (a, b, c, a[:0], b)]
+    assert sum(w["buffer"] == df4 for w in want[1]) == 7
+    with MultiContext([0] * 8, 2) as multi:
+        multi.icao_flush()
+        for iq, w in zip((a, b, c, a[:0], b), want):
+            # (b is 8 buffers over 8 devices; a leaves six devices without samples, yet b's DF4s on THEIR devices
+            # need the address a's DF17 taught)
+            assert [key(m) for m in multi.demod_iq(iq)] == [want_key(x) for x in w]
+        # a capture longer than the contexts hold together goes in pieces through the same filter
+        long_iq = np.concatenate([b, a, b])
+        orc3 = oracle_mod.Oracle()
+        multi.icao_flush()
+        assert [key(m) for m in multi.demod_iq(long_iq)] == [want_key(x) for x in orc3.demod_iq(long_iq)[0]]
+
+
+def test_a_shard_denser_than_the_lists_goes_buffer_by_buffer_and_stays_exact(hip_lib, oracle_mod):
+    """One shard of the capture overflows the fast scan's lists (a one-buffer context given a periodic stretch
+    that passes every gate at a quarter of all positions): that shard takes both phases buffer by buffer through
+    the worst-case lists while the others go the usual way; the merged result is still the oracle's."""
+    from dump1090_rs_amd.multi import MultiContext
+    from tests.test_gpu_parity import ADVERSARIAL_PERIODS
+    icao = 0x3C6589
+    body = bytes([0x20, 0x00, 0x05, 0x30])
+    df4 = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+    iq = synth.make_iq(4 * CHUNK, n_bursts=0, seed=900)
+    synth.add_bursts(iq, [synth.Burst(5 * (30000 * k + 777) + k, 21000, k, synth.df17_frame(icao, k)) for k in range(1, 4)])
+    a, b = CHUNK + 40000, CHUNK + 125000                     # inside buffer 1 = shard 1
+    per = np.array(ADVERSARIAL_PERIODS[1], dtype=np.int16)
+    iq[a:b, 0] = np.tile(per, (b - a) // len(per) + 1)[: b - a]
+    iq[a:b, 1] = 0
+    synth.add_bursts(iq, [synth.Burst(5 * (CHUNK * k + 9000 + 333 * k) + k, 21000, k, df4) for k in range(1, 4)])
+    want, _ = oracle_mod.Oracle().demod_iq(iq, cap=1 << 18)
+    assert sum(w["buffer"] == df4 for w in want) >= 3
+    with MultiContext([0] * 4, 1) as multi:
+        multi.icao_flush()
+        got = multi.demod_iq(iq, cap=1 << 18)
+        assert multi.stats()["retries"] >= 1                 # the scenario really went through the fallback
+        assert [key(m) for m in got] == [want_key(w) for w in want]
+        # and the handle is as good as new afterwards
+        multi.icao_flush()
+        assert [key(m) for m in multi.demod_iq(iq, cap=1 << 18)] == [want_key(w) for w in want]
+
+
+def test_output_array_too_small_and_misuse(hip_lib, oracle_mod):
+    """ADSB_ERR_CAPACITY hands out the first `cap` messages and keeps the list (the capture is consumed: the
+    filter has moved on); bad arguments are refused, never crash."""
+    import torch
+    from dump1090_rs_amd import _lib
+    from dump1090_rs_amd._lib import AdsbMsg
+    from dump1090_rs_amd.multi import MultiContext
+    L = hip_lib
+    iq = coupled_capture8()
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    with MultiContext([0] * 3, 13) as multi:
+        multi.icao_flush()
+        out, n = (AdsbMsg * 4)(), C.c_size_t()
+        st = L.adsb_multi_demod_iq(multi._h, iq.ctypes.data, len(iq), out, 4, C.byref(n))
+        assert st == _lib.ADSB_ERR_CAPACITY and n.value == len(want) > 4
+        assert [bytes(m.msg) for m in out] == [w["msg"] for w in want[:4]]
+        full = (AdsbMsg * n.value)()
+        assert L.adsb_multi_fetch_messages(multi._h, full, n.value, C.byref(n)) == 0
+        assert [(m.chunk, m.j, m.score) for m in full] == [(w["chunk"], w["j"], w["score"]) for w in want]
+        # the Python mirror fetches by itself
+        multi.icao_flush()
+        assert [key(m) for m in multi.demod_iq(iq, cap=2)] == [want_key(w) for w in want]
+        # misuse
+        tensors, ptrs, ns = to_devices(iq, multi, torch)
+        bad = list(ns)
+        bad[0] -= 5                                           # a ragged shard in the middle of the capture
+        with pytest.raises(Exception):
+            multi.demod_iq_device(ptrs, bad)
+        with pytest.raises(Exception):
+            multi.demod_iq_device([p + 4 for p in ptrs], ns)  # not 16-byte aligned
+        with pytest.raises(Exception):
+            multi.demod_iq_device(ptrs, [14 * CHUNK, 0, 0])   # more than the context was created for
+        assert L.adsb_multi_collect(multi._h, None, 0, None) == _lib.ADSB_ERR_INVALID      # nothing in flight
+        assert L.adsb_multi_fetch_messages(multi._h, None, 0, None) == _lib.ADSB_ERR_INVALID
+        assert [key(m) for m in multi.demod_iq_device(ptrs, ns)] is not None                 # still usable
+    h = C.c_void_p()
+    assert L.adsb_multi_create(C.byref(h), None, 2, 1) == _lib.ADSB_ERR_INVALID
+    assert L.adsb_multi_create(C.byref(h), (C.c_int * 1)(0), 0, 1) == _lib.ADSB_ERR_INVALID
+    assert L.adsb_multi_create(C.byref(h), (C.c_int * 2)(0, 99), 2, 1) == _lib.ADSB_ERR_NO_DEVICE and not h.value
+    assert L.adsb_multi_create(C.byref(h), (C.c_int * 1)(-1), 1, 1) == _lib.ADSB_ERR_NO_DEVICE
+    assert L.adsb_multi_shard_range(10, 0, 0, None, None) == _lib.ADSB_ERR_INVALID
+    assert L.adsb_multi_shard_range(10, 2, 2, None, None) == _lib.ADSB_ERR_INVALID
+    L.adsb_multi_destroy(None)
+
+
+def test_shard_ranges_are_the_even_contiguous_split():
+    """adsb_multi_shard_range == sharding.sample_range (whole buffers, sizes that differ by at most one)."""
+    from dump1090_rs_amd import _lib, sharding
+    L = _lib.lib()
+    for n_samples in (0, 1, CHUNK - 1, CHUNK, CHUNK + 1, 38 * CHUNK - 4321, 4096 * CHUNK):
+        for world in (1, 2, 3, 8, 64):
+            for k in range(world):
+                a, n = C.c_size_t(), C.c_size_t()
+                assert L.adsb_multi_shard_range(n_samples, world, k, C.byref(a), C.byref(n)) == 0
+                lo, hi = sharding.sample_range(n_samples, world, k)
+                assert (a.value, a.value + n.value) == (lo, hi)
+
+
+def test_compiled_c_host_drives_the_multi_entry_points(hip_lib, golden):
+    """tests/abi_host.c --multi N: a plain C program over include/adsb_hip.h, no Python and no process group, puts
+    N copies of a reference capture through adsb_multi_demod_iq as ONE capture over N contexts; the first buffer's
+    frames are exactly the reference's (tests/test.rs:22-28)."""
+    exe = ROOT / "tests" / "abi_host"
+    assert exe.exists(), "tests/abi_host was not built (dump1090_rs_amd.build.build_abi_host)"
+    fx = golden["fixtures"][0]
+    for n in (1, 3, 8):
+        r = subprocess.run([str(exe), "--multi", str(n), str(GOLDEN / fx["file"]), *fx["frames"]], capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = r.stdout.splitlines()
+        assert [ln.split()[0] for ln in lines[:-1]] == fx["frames"] and lines[-1].startswith(f"multi: {n} devices")
+    assert subprocess.run([str(exe), "--multi", "3", str(GOLDEN / fx["file"]), *fx["frames"][:-1]], capture_output=True).returncode == 1
+
+
+def test_two_gib_capture_through_one_device_and_through_eight_contexts(hip_lib, oracle_mod):
+    """BASELINE config 4's capture size once through the entry points (2 GiB = 4096 buffers would take the oracle
+    a minute: 512 buffers = 256 MiB here, the bench runs the 2 GiB one): one device holding everything, then eight
+    contexts of 64 buffers -- both equal to the oracle."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    n = 512 * CHUNK
+    dev = synth.make_iq_torch(n, n_bursts=400, seed=77001, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    want, _ = oracle_mod.Oracle().demod_iq(dev.cpu().numpy(), cap=1 << 18, threads=8)
+    for devices, per in (([0], 512), ([0] * 8, 64)):
+        with MultiContext(devices, per) as multi:
+            ranges = multi.shard_ranges(n)
+            ptrs = [dev.data_ptr() + 4 * a for a, _ in ranges]
+            ns = [k for _, k in ranges]
+            multi.icao_flush()
+            assert [key(m) for m in multi.demod_iq_device(ptrs, ns, cap=1 << 18)] == [want_key(w) for w in want]
+            # pipelined, a flush in front of each: the same list every time
+            for _ in range(6):
+                if multi.pending() == multi.max_in_flight():
+                    assert [key(m) for m in multi.collect(cap=1 << 18)] == [want_key(w) for w in want]
+                multi.icao_flush()
+                multi.submit_iq_device(ptrs, ns)
+            while multi.pending():
+                assert [key(m) for m in multi.collect(cap=1 << 18)] == [want_key(w) for w in want]

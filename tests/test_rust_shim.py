@@ -3,7 +3,7 @@
 The shim cannot be compiled in this image (no rustc / cargo), so nothing would notice if a prototype
 in the header changed and the `unsafe extern "C"` block did not.  This test parses both files and
 compares them mechanically: every function (name, arity, each argument's type, the return type), the
-status constants, and the three structs (field order, types, offsets, sizes -- also against the
+status constants, and the four structs (field order, types, offsets, sizes -- also against the
 ctypes structs the Python host uses).  tests/abi_host.c pins the same layouts from the C side with
 _Static_assert.
 """
@@ -23,6 +23,7 @@ BASE = {
     "int": "c_int", "void": "c_void", "char": "c_char", "size_t": "usize", "double": "f64", "float": "f32",
     "int16_t": "i16", "uint16_t": "u16", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8",
     "adsb_ctx": "AdsbCtx", "adsb_msg": "AdsbMsg", "adsb_trial": "AdsbTrial", "adsb_stats": "AdsbStats",
+    "adsb_multi": "AdsbMulti", "adsb_multi_stats": "AdsbMultiStats",
 }
 RUST_SIZE = {"u8": 1, "i16": 2, "u16": 2, "i32": 4, "u32": 4, "f32": 4, "u64": 8, "f64": 8}
 
@@ -35,15 +36,22 @@ def strip_comments(text: str) -> str:
 def c_type_to_rust(ctype: str) -> str:
     """`const adsb_ctx *` -> `*const AdsbCtx`, `int16_t **` -> `*mut *mut i16`, `size_t` -> `usize`."""
     toks = ctype.replace("*", " * ").split()
-    const = toks and toks[0] == "const"
+    const = bool(toks) and toks[0] == "const"
     if const:
         toks = toks[1:]
-    base, stars = toks[0], toks.count("*")
+    base = toks[0]
     assert base in BASE, f"unknown C type {ctype!r}"
     out = BASE[base]
-    for level in range(stars):
-        # the innermost pointer carries the const of the pointee; outer levels are plain `*mut`
-        out = ("*const " if (const and level == 0) else "*mut ") + out
+    # every `*` points at what stands to its left: the base type (const or not), or a pointer that is itself
+    # const when a `const` follows its star (`const void *const *` = `*const *const c_void`)
+    pointee_const, rest = const, toks[1:]
+    while rest:
+        assert rest[0] == "*", ctype
+        out = ("*const " if pointee_const else "*mut ") + out
+        rest = rest[1:]
+        pointee_const = bool(rest) and rest[0] == "const"
+        if pointee_const:
+            rest = rest[1:]
     return out
 
 
@@ -162,8 +170,9 @@ def test_status_constants_match_the_header():
 def test_struct_layouts_match_header_and_ctypes():
     from dump1090_rs_amd import _lib
     hdr, ffi = header_structs(), rust_structs()
-    ctypes_of = {"AdsbMsg": _lib.AdsbMsg, "AdsbTrial": _lib.AdsbTrial, "AdsbStats": _lib.AdsbStats}
-    want_size = {"AdsbMsg": 40, "AdsbTrial": 32, "AdsbStats": 72}
+    ctypes_of = {"AdsbMsg": _lib.AdsbMsg, "AdsbTrial": _lib.AdsbTrial, "AdsbStats": _lib.AdsbStats,
+                 "AdsbMultiStats": _lib.AdsbMultiStats}
+    want_size = {"AdsbMsg": 40, "AdsbTrial": 32, "AdsbStats": 72, "AdsbMultiStats": 96}
     for name, ct in ctypes_of.items():
         assert ffi[name] == hdr[name], f"{name}: field order / types differ between hip_ffi.rs and the header"
         offsets, size = layout(ffi[name])
@@ -171,6 +180,7 @@ def test_struct_layouts_match_header_and_ctypes():
         assert [f[0] for f in ct._fields_] == [f[0] for f in ffi[name]]
         assert offsets == [getattr(ct, f[0]).offset for f in ct._fields_]
     assert ffi["AdsbCtx"] == [("_private", "[u8; 0]")]          # opaque
+    assert ffi["AdsbMulti"] == [("_private", "[u8; 0]")]
 
 
 def test_build_script_is_inert_without_the_hip_feature():
