@@ -94,6 +94,13 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test (no GPU, no measurement): the ranks rendezvous over gloo, "
                          "barrier, and rank 0 prints a line that says so")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--workload shard: ONE process drives all devices through adsb_multi_* (a context and a host "
+                         "thread per device inside the library, the address exchange in memory, one replay) instead "
+                         "of one rank per GPU; --contexts picks how many shards")
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="--single-process: shards of the capture (default: every visible device once); more shards than "
+                         "devices wrap around (8 on a one-GPU box = eight contexts sharing the GPU)")
     ap.add_argument("--sync", action="store_true",
                     help="one blocking adsb_demod_iq_device call per step instead of the "
                          "submit/collect pipeline")
@@ -919,6 +926,126 @@ def run_shard(env: Env, args):
     return result
 
 
+def run_shard_single_process(env: Env, args):
+    """BASELINE config 4 from ONE process: adsb_multi_* (include/adsb_hip.h) -- the capture's contiguous ranges
+    resident on their devices, a context and a host thread per device inside the library, the learned addresses
+    united in memory between the two shard phases, one ordered replay through one filter.  A step = icao_flush +
+    the whole capture; steps are pipelined four deep (submit / collect) like the single-GPU headline, and timed
+    blocking as well for the orchestration figures (adsb_multi_stats: host-clock spans of the two phases)."""
+    torch = env.torch
+    from dump1090_rs_amd import Context, sharding, synth, _lib
+    from dump1090_rs_amd._lib import AdsbMsg
+    from dump1090_rs_amd.multi import MultiContext
+    import ctypes as C
+
+    n_dev = torch.cuda.device_count()
+    shards = args.contexts or n_dev
+    devices = [k % n_dev for k in range(shards)]
+    total_chunks = max(shards, args.capture_chunks)
+    ranges = [sharding.chunk_range(total_chunks, shards, r) for r in range(shards)]
+    per = max(b - a for a, b in ranges)
+
+    def shard_iq(r):
+        k = ranges[r][1] - ranges[r][0]
+        return synth.make_iq_torch(k * CHUNK, n_bursts=max(1, 64 * k // 512), seed=synth.SEED_DEFAULT + 31 * r,
+                                   device=torch.device("cuda", devices[r]))
+
+    parts = [shard_iq(r) for r in range(shards)]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    multi = MultiContext(devices, per)
+    ptrs = (C.c_void_p * shards)(*[C.c_void_p(t.data_ptr()) for t in parts])
+    ns = (C.c_size_t * shards)(*[t.shape[0] for t in parts])
+    cap = 1 << 20
+    out = (AdsbMsg * cap)()
+    depth = multi.max_in_flight()
+    keys = ("ms_wall", "ms_phase1_max", "ms_phase2_max", "ms_phase1_span", "ms_phase2_span", "ms_exchange", "ms_replay")
+
+    def run_steps(count, blocking, acc=None):
+        frames, done = 0, 0
+        for i in range(count):
+            multi.icao_flush()
+            multi.submit_raw(ptrs, ns)
+            if blocking or i - done >= depth - 1:
+                frames += multi.collect_raw(out, cap)
+                done += 1
+                if acc is not None:
+                    st = multi.stats()
+                    for k in keys:
+                        acc[k] += st[k]
+        while done < count:
+            frames += multi.collect_raw(out, cap)
+            done += 1
+        return frames
+
+    gc.collect()
+    gc.disable()
+    ramp = clock_ramp(env, args, lambda first, count: run_steps(count, False))
+    run_steps(max(2, args.warmup), False)
+    env.fence()
+    t0 = time.perf_counter()
+    frames = run_steps(args.steps, False)
+    env.fence()
+    elapsed = time.perf_counter() - t0
+    blocks = []
+    for _ in range(max(0, args.blocks)):
+        env.fence()
+        tb = time.perf_counter()
+        run_steps(args.steps, False)
+        env.fence()
+        blocks.append((time.perf_counter() - tb) / args.steps * 1e3)
+    # one capture at a time: what a step costs from submit to its last record, and what of it is orchestration
+    run_steps(5, True)
+    acc = {k: 0.0 for k in keys}
+    env.fence()
+    t0 = time.perf_counter()
+    run_steps(args.steps, True, acc)
+    env.fence()
+    blocking_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    gc.enable()
+    orch = {k: round(v / args.steps, 4) for k, v in acc.items()}
+    orch["ms_overhead"] = round(orch["ms_wall"] - orch["ms_phase1_span"] - orch["ms_phase2_span"], 4)
+    orch["is"] = ("blocking steps, host clock, mean per step: ms_wall = submit -> the last device's records on the host; "
+                  "ms_phase*_span = first device's issue of the phase -> last device's summary of it; ms_overhead = ms_wall "
+                  "minus the two spans = hand-over to the device threads + the address union + hand-over of phase 2 + "
+                  "noticing the end; ms_replay is the caller's ordered replay after that")
+    # checked: the merged list of one more step == the single-stream answer of one context over the whole capture
+    multi.icao_flush()
+    merged = multi.demod_iq_device([t.data_ptr() for t in parts], [t.shape[0] for t in parts], cap=cap)
+    whole = torch.cat([t.to(env.dev) for t in parts]) if shards > 1 else parts[0]
+    with Context(device=env.local_rank, max_chunks=min(512, total_chunks)) as solo:
+        solo.icao_flush()
+        want = solo.demod_iq_device(whole.data_ptr(), total_chunks * CHUNK, cap=cap)
+    key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
+    same = [key(m) for m in merged] == [key(m) for m in want]
+    del whole
+    n = total_chunks * CHUNK
+    result = {
+        "metric": "IQ Msamples/s demodulated", "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step_blocking": round(blocking_ms, 4),
+        "ms_per_step_blocks": None if not blocks else {"min": round(min(blocks), 4), "median": round(_median(blocks), 4),
+                                                       "max": round(max(blocks), 4), "all": [round(x, 4) for x in blocks]},
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "frames_per_s": round(frames / elapsed, 1), "single_process": True, "shards": shards, "devices": devices,
+        "orchestration": orch,
+        "config": {"workload": f"one capture of {total_chunks} buffers = {n * 4 // (1 << 20)} MiB cut into {shards} contiguous "
+                               f"ranges ({', '.join(str(b - a) for a, b in ranges)} buffers) resident on devices {devices} "
+                               "(BASELINE config 4), ONE process: a step = adsb_multi_icao_flush + the capture through "
+                               "adsb_multi_submit_iq_device / adsb_multi_collect",
+                   "per_shard_samples_per_step": [(b - a) * CHUNK for a, b in ranges],
+                   "sharding": "contiguous buffer ranges, the IQ never moves; one context and one host thread per device inside "
+                               "libadsb_hip.so; learned addresses united in memory between the two shard phases; one ordered "
+                               "replay through one filter on the caller's thread; no process group, no collective",
+                   "host_api": f"adsb_multi_submit_iq_device / adsb_multi_collect, {depth} captures in flight",
+                   "library": _lib.lib().adsb_version().decode(), "host_affinity": env.affinity_summary(), "clock_ramp": ramp},
+        "shard_merge_equals_single_stream": bool(same), "parity_frames": len(want),
+    }
+    multi.close()
+    return result
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE config 1: the reference's `cargo bench` case
 # ------------------------------------------------------------------------------------------------
@@ -1082,6 +1209,8 @@ def main():
         if env.rank == 0:
             result["live_receiver"] = live_leg(env, args)
             result["parity_checked"] = bool(s["parity"]) and result["live_receiver"]["parity_checked"]
+    elif args.workload == "shard" and args.single_process:
+        result = run_shard_single_process(env, args)
     elif args.workload == "shard":
         result = run_shard(env, args)
     else:

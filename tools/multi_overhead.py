@@ -1,0 +1,36 @@
+"""The kernels of the LAST cluster of a rocprofv3 kernel trace (tools/multi_steps.py puts its timed steps between
+two pauses): the union of their intervals = what the device was busy for; per kernel the count and mean duration.
+usage: python tools/multi_overhead.py <kernel_trace.csv> <steps.json>"""
+import csv, json, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = json.loads([l for l in open(sys.argv[2]).read().splitlines() if l.startswith("{")][-1])
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda x: x[0])
+clusters, cur = [], [ks[0]]
+for k in ks[1:]:
+    if k[0] - max(e for _, e, _ in cur) > 30_000_000:   # a pause of more than 30 ms
+        clusters.append(cur)
+        cur = []
+    cur.append(k)
+clusters.append(cur)
+timed = max((c for c in clusters[-3:]), key=len) if len(clusters) >= 3 else clusters[-1]
+busy, end = 0, 0
+for s, e, _ in timed:
+    if e > end:
+        busy += e - max(s, end)
+        end = e
+span = max(e for _, e, _ in timed) - timed[0][0]
+per = {}
+for s, e, name in timed:
+    short = name.split("(")[0].replace("void adsb::(anonymous namespace)::", "")
+    per.setdefault(short, []).append(e - s)
+n = steps["steps"]
+out = {"steps": n, "contexts": steps["contexts"], "pipelined": steps["pipelined"],
+       "ms_per_step_wall": steps["ms_per_step_wall"],
+       "ms_per_step_device_busy": round(busy / n / 1e6, 4),
+       "ms_per_step_first_kernel_to_last": round(span / n / 1e6, 4),
+       "ms_overhead": round(steps["ms_per_step_wall"] - busy / n / 1e6, 4),
+       "is": "device busy = union of the intervals of every kernel of the timed steps (rocprofv3 --kernel-trace); overhead = "
+             "wall time per step minus that: launch latencies, the exchange between the phases, hand-overs between threads",
+       "host_clock_stats": steps["stats_mean"],
+       "kernels_per_step": {k: {"launches": round(len(v) / n, 2), "mean_us": round(sum(v) / len(v) / 1e3, 2)} for k, v in sorted(per.items())}}
+print(json.dumps(out, indent=1))
