@@ -534,8 +534,11 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
     // this kernel, whatever the grid), and four or eight blocks per buffer are two and four
     // times slower (more rounds of the fixed per-block latencies).  What it does depend on is the
     // instruction count per hit: see the hit loop.
+    // (every block ends with one atomic on the same counter, ~90 of them a microsecond on this chip: a pass of
+    // 4096 buffers with a block per buffer spent 126 us in a kernel that writes a few hundred records --
+    // profiles/r5_multi_overhead.txt; beyond 1024 blocks the runs per block simply get longer)
     uint32_t blocks = p.n_chunks + 8u;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 1024) blocks = 1024;
     if (from_mag)  // (one caller-supplied buffer: never device-ordered)
         hipLaunchKernelGGL((k_records<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, d_rec);
     else if (p.order_cnt)  // device-ordered: dynamic LDS for the bucket being sorted

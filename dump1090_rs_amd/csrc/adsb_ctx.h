@@ -213,6 +213,7 @@ struct adsb_ctx {
         bool active = false;      // phase 1 enqueued, phase 2 not collected yet
         bool by_chunk = false;    // the shard overflowed the fast scan's lists: both phases go buffer by buffer
         bool waiting = false;     // a phase's launches are out and its summary has not been seen yet
+        bool ran = false;         // Slot::recorded has been recorded behind a second phase of this slot
         ScanParams p{};
         uint32_t *retired = nullptr;   // the bitmap an icao_flush in front of this shard retired (phase 2 cleans it)
         std::vector<TrialRecord> chunk_records;   // by_chunk: the second phase's records

@@ -14,8 +14,8 @@
 // capture, so the result is the single-stream one.
 //
 // The phases are written per slot and do not block: shard_begin enqueues phase 1 of a shard into
-// slot k (scan on one of the two scan streams, the records of its self-validating hits on the tail
-// stream) and returns; the host sees the phase finish by its summary landing in mapped memory
+// slot k (scan and the records of its self-validating hits on one of the two scan streams) and
+// returns; the host sees the phase finish by its summary landing in mapped memory
 // (shard_phase_landed); shard_match enqueues phase 2 on the tail stream.  Shards of consecutive
 // captures sit in consecutive slots, so the scan of capture i + 1 runs while capture i is being
 // exchanged and matched -- that is what adsb_multi.cpp (one process, N GPUs, a thread per device)
@@ -132,7 +132,7 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
     job.active = true;
     if (!n_chunks) return ADSB_OK;   // (an empty shard: nothing to wait for, nothing learned)
     // consecutive shards' scans alternate between the first two scan streams, like consecutive passes
-    hipStream_t ss = c->scan_stream[c->shard_jobs++ % 2], ts = c->tail_stream;
+    hipStream_t ss = c->scan_stream[c->shard_jobs++ % 2];
     job.scan_q = ss;
     // the caller's samples are complete where `stream` stands now (nothing to wait for on the context's own,
     // idle stream: see enqueue_pass)
@@ -143,10 +143,17 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
         c->own_stream_dirty = false;
     }
     if (int rc = order_behind_fused(c, sl, ss)) return rc;
+    // Phase 1 stays on its scan stream, no event: the tail stream is in order, and the first-phase records of the
+    // NEXT shards (enqueued microseconds after this one's, each waiting for its own scan) would sit in front of
+    // this shard's second phase there -- which the host only enqueues when this phase has landed -- so that every
+    // capture's match waited for the scans of the three captures behind it and the pipeline ran in bursts of four
+    // (measured: 0.99 ms per 2 GiB capture against 0.76 of scan; profiles/r5_multi_overhead.txt).
+    // (the slot's previous shard: its second phase ran on the tail stream, and its summary reached the host a
+    // moment before that launch retired -- it was still zeroing the counters this scan is about to fill)
+    if (job.ran) HIP_TRY(c, hipStreamWaitEvent(ss, sl.recorded, 0));
     if (int e = launch_scan(p, false, ss)) return fail(c, (hipError_t)e, "launch_scan");
-    HIP_TRY(c, hipEventRecord(sl.scanned, ss));
-    HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
-    if (int e = launch_records(p, false, sl.h_rec_dev, ts)) return fail(c, (hipError_t)e, "launch_records");
+    if (int e = launch_records(p, false, sl.h_rec_dev, ss)) return fail(c, (hipError_t)e, "launch_records");
+    HIP_TRY(c, hipEventRecord(sl.scanned, ss));   // (the second phase, on the tail stream, orders itself behind this launch)
     job.waiting = true;
     return ADSB_OK;
 }
@@ -170,6 +177,7 @@ int shard_phase_wait(adsb_ctx *c, int k)
         __builtin_ia32_pause();
         if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
+    if (job.scan_q) HIP_TRY(c, hipStreamSynchronize(job.scan_q));
     HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
     for (int attempt = 0; attempt < 200; attempt++) {
         if (shard_phase_landed(c, k)) return ADSB_OK;
@@ -254,8 +262,13 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
         sl.seq = next_seq(c);
         sl.h_sum->seq = 0;
         p.seq = sl.seq;
+        // (the first phase's records kernel published its summary a moment before it retired: it resets the
+        // block counter this phase's records kernel counts in)
+        HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
         if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
         if (int e = launch_records(p, false, sl.h_rec_dev, ts)) return fail(c, (hipError_t)e, "launch_records");
+        HIP_TRY(c, hipEventRecord(sl.recorded, ts));
+        job.ran = true;
         job.waiting = true;
     }
     return ADSB_OK;

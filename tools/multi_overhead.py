@@ -12,7 +12,12 @@ for k in ks[1:]:
         cur = []
     cur.append(k)
 clusters.append(cur)
-timed = max((c for c in clusters[-3:]), key=len) if len(clusters) >= 3 else clusters[-1]
+import re
+def short(name):
+    m = re.search(r"\b(k_\w+)(<[^(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name.split("(")[0][:60]
+want_scans = steps["steps"] * steps["contexts"]
+timed = next((c for c in reversed(clusters) if sum("k_scan_fast" in k[2] for k in c) == want_scans), clusters[-1])
 busy, end = 0, 0
 for s, e, _ in timed:
     if e > end:
@@ -21,8 +26,7 @@ for s, e, _ in timed:
 span = max(e for _, e, _ in timed) - timed[0][0]
 per = {}
 for s, e, name in timed:
-    short = name.split("(")[0].replace("void adsb::(anonymous namespace)::", "")
-    per.setdefault(short, []).append(e - s)
+    per.setdefault(short(name), []).append(e - s)
 n = steps["steps"]
 out = {"steps": n, "contexts": steps["contexts"], "pipelined": steps["pipelined"],
        "ms_per_step_wall": steps["ms_per_step_wall"],
