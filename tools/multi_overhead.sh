@@ -6,7 +6,7 @@ for mode in "" "--pipelined"; do
   tag=${T}_n${N}_c${CH}${mode:+_pipe}
   rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/mo_$tag -o t -- python3 $R/tools/multi_steps.py --contexts $N --chunks $CH --steps 40 $mode > $R/gpurun_out/mo_$tag.json 2> $R/gpurun_out/mo_$tag.err
   f=$(find $R/gpurun_out/mo_$tag -name "t_kernel_trace.csv" | head -1)
-  python3 $R/tools/multi_overhead.py $f $R/gpurun_out/mo_$tag.json > $R/gpurun_out/multi_overhead_$tag.json 2>> $R/gpurun_out/mo_$tag.err
+  python3 $R/tools/multi_overhead.py $f $R/gpurun_out/mo_$tag.json $R/gpurun_out/mo_$tag.trace.csv > $R/gpurun_out/multi_overhead_$tag.json 2>> $R/gpurun_out/mo_$tag.err
   cat $R/gpurun_out/multi_overhead_$tag.json
   rm -rf $R/gpurun_out/mo_$tag
 done
