@@ -33,13 +33,10 @@ import sys
 import time
 from pathlib import Path
 
-# The HIP runtime gives streams hardware queues from pools of GPU_MAX_HW_QUEUES (4 by default) per priority;
-# streams beyond that share a queue, i.e. run one after the other.  This process runs a 512-buffer context
-# (two high-priority scan streams) AND contexts for one-buffer passes (four) side by side -- the `also` legs --,
-# six in all: with the default two of them share (the one-buffer ring: 6.9 instead of 8.8-9.0 Gsample/s;
-# dump1090_rs_amd/csrc/adsb_context.cpp).  A process with one kind of context needs nothing.  Must be in the
-# environment before the runtime starts (torch is imported later); a value already set is left alone.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (No GPU_MAX_HW_QUEUES here any more: the library keeps every context's streams within four per priority and device --
+# dump1090_rs_amd/csrc/adsb_context.cpp: DeviceStreams -- so a process that mixes a large context with contexts for
+# passes of a few buffers, as this one does in its `also` legs, needs nothing in its environment.  A value the caller
+# has set is left alone and reported under config.runtime_env.)
 
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:

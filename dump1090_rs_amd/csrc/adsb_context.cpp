@@ -9,41 +9,56 @@ using namespace adsb::host;
 
 extern "C" {
 
-// The internal streams of destroyed contexts, kept for the next context on the same device.  The
-// runtime gives every new stream of a priority a new hardware queue until it has four of that priority
-// and never gives one back, so a process that creates, destroys and re-creates contexts ends up with its
-// streams spread over a different set of queues each time -- measured: a dense stream in the second
-// context alternates 88 / 270 us per pass (0.175 ms mean) where the first one holds 0.13.  Re-using the
-// same streams keeps every context of a process on the queues the first one got.
-struct StreamSet {
+// Streams.  The runtime multiplexes streams onto hardware queues: GPU_MAX_HW_QUEUES (4 by default) per priority, gives
+// every new stream of a priority a new queue until it has four of that priority, never gives one back, and streams
+// beyond that SHARE queues, i.e. run one after the other.  Measured in earlier rounds: a process that creates, destroys
+// and re-creates contexts ends up with its streams on a different set of queues each time (a dense stream in the second
+// context alternated 88 / 270 us per pass); a process with a large context (two scan streams) AND contexts for passes of
+// a few buffers (four) held six high-priority streams, two of which shared a queue -- the one-buffer ring ran at 6.8
+// instead of 8.8 Gsample/s, or the large stream at 0.129 instead of 0.097 ms per step, depending on who came first --
+// unless the process set GPU_MAX_HW_QUEUES=8 before the runtime started.
+// So the library never holds more than four streams of a priority per device, whatever its users create: per device,
+// for the life of the process, FOUR highest-priority streams (created in a row, the first time a context is made on the
+// device: streams added to a set later did not behave like four created together) that every context's scans run on --
+// a context for passes of a few buffers uses all four, a large context one of the two pairs, contexts side by side take
+// the pairs in turn -- and four lowest-priority ones that the contexts' tail and score chains share the same way.  Two
+// contexts on one stream are simply two in-order users of it (every wait is for an event recorded before: no cycle).
+// No environment variable is needed by anybody.
+struct DeviceStreams {
     int device = -1;
-    int n_scan = 2;   // sets of contexts for passes of a few buffers (four scan streams) and of large contexts
-                      // (two) are kept apart: a large context's set extended by two streams created later did not
-                      // behave like four created in a row (the one-buffer ring: 6.9 instead of 8.8 Gsample/s)
-    hipStream_t own = nullptr, scan[kScanStreams] = {}, tail = nullptr, score = nullptr;
+    hipStream_t scan[kScanStreams] = {};   // highest priority
+    hipStream_t low[4] = {};               // lowest priority: tail and score chains
+    unsigned next_pair = 0, next_low = 0;
+    std::vector<hipStream_t> free_own;     // normal priority: a context's own stream (input order, host-pointer copies)
 };
-std::mutex g_stream_pool_mu;
-std::vector<StreamSet> g_stream_pool;
+std::mutex g_streams_mu;
+std::vector<DeviceStreams *> g_device_streams;   // (never freed: the streams live as long as the process)
 
-bool take_stream_set(int device, int n_scan, StreamSet &out)
+// under g_streams_mu, the device current
+int device_streams(adsb_ctx *c, int device, DeviceStreams **out)
 {
-    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-    for (size_t i = 0; i < g_stream_pool.size(); i++)
-        if (g_stream_pool[i].device == device && g_stream_pool[i].n_scan == n_scan) {
-            out = g_stream_pool[i];
-            g_stream_pool.erase(g_stream_pool.begin() + (long)i);
-            return true;
+    for (DeviceStreams *d : g_device_streams)
+        if (d->device == device) {
+            *out = d;
+            return ADSB_OK;
         }
-    return false;
+    DeviceStreams *d = new (std::nothrow) DeviceStreams;
+    if (!d) return ADSB_ERR_NOMEM;
+    d->device = device;
+    int least = 0, greatest = 0;
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // The scan streams all take the highest priority: that pool holds nothing else of this process (the null stream,
+    // torch's and the caller's streams are of normal priority), so each gets a queue and consecutive scans overlap.
+    // They must have the SAME priority: with different ones, whenever two scans are pending at once the higher one
+    // starts first, its successor on that stream is then free earlier too, and the stream settles into finishing
+    // passes in the order 2, 1, 4, 3, ... for thousands of passes, 8-10 % slower (measured over 22 000 passes).
+    for (auto &q : d->scan) HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, greatest));
+    for (auto &q : d->low) HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, least));
+    g_device_streams.push_back(d);
+    *out = d;
+    return ADSB_OK;
 }
 
-// The runtime multiplexes streams onto hardware queues: GPU_MAX_HW_QUEUES (4 by default) per priority, and
-// streams beyond that SHARE queues, i.e. run one after the other.  A process with one kind of context stays
-// within four high-priority streams (two scan streams, or four).  A process that mixes a large context with
-// contexts for passes of a few buffers has six, and two of them share: measured (tools/ring_history_probe.py),
-// the one-buffer ring then runs at 6.8 instead of 8.8 Gsample/s when the large context's streams were used
-// first, and the large stream at 0.129 instead of 0.097 ms per step when the small ones were.  Such a
-// process sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts (bench.py does): then nothing shares.
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
 {
     if (!out) return ADSB_ERR_INVALID;
@@ -88,46 +103,46 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     int rc = ADSB_OK;
     auto body = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
-        StreamSet pooled;
-        const bool reuse = !tuning_env("ADSB_STREAM_PRIO") && !tuning_env("ADSB_SCORE_PRIO") && take_stream_set(device, c->n_scan_streams, pooled);
-        if (reuse) {
-            c->own_stream = pooled.own;
-            for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = pooled.scan[k];
-            c->tail_stream = pooled.tail;
-            c->score_stream = pooled.score;
-        } else {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-        }
-        c->stream = c->own_stream;
-        if (!reuse) {
-            // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
-            // default, per priority) and two streams on one queue run strictly one after the other.
-            // Both scan streams take the highest priority: that pool holds nothing else of this
-            // process (the null stream, torch's and the caller's streams are of normal priority), so
-            // the two get a queue each and consecutive scans can overlap.  They must have the SAME
-            // priority: with different ones, whenever two scans are pending at once (after any hiccup
-            // of the host) the higher one's starts first, its successor on that stream is then free
-            // earlier too, and the stream settles into finishing passes in the order 2, 1, 4, 3, ...
-            // for thousands of passes, 8-10 % slower (passes are collected in order), until another
-            // hiccup flips it back; measured over 22 000 passes: (mid, high) spends a third of the
-            // time in that mode, (high, high) and (mid, mid) none.
+        if (tuning_env("ADSB_STREAM_PRIO") || tuning_env("ADSB_SCORE_PRIO")) {
+            // measurement aid (tuning builds): streams of this context's own, "tail,scan0,scan1" as 0 (least) .. 2
             int least = 0, greatest = 0;
             HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            int pt = least, p0 = greatest, p1 = greatest;
-            if (const char *e = tuning_env("ADSB_STREAM_PRIO")) {  // measurement aid: "tail,scan0,scan1" as 0 (least) .. 2
+            int pt = least, p0 = greatest, p1 = greatest, ps = least;
+            if (const char *e = tuning_env("ADSB_STREAM_PRIO")) {
                 int a = 0, b = 1, d = 2;
                 if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
                     const int lv[3] = {least, (least + greatest) / 2, greatest};
                     pt = lv[a % 3], p0 = lv[b % 3], p1 = lv[d % 3];
                 }
             }
+            if (const char *e = tuning_env("ADSB_SCORE_PRIO")) ps = std::atoi(e) == 2 ? greatest : (std::atoi(e) == 1 ? (least + greatest) / 2 : least);
+            c->private_streams = true;
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
             HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, pt));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[0], hipStreamNonBlocking, p0));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[1], hipStreamNonBlocking, p1));
-            for (int k = 2; k < c->n_scan_streams; k++)
+            for (int k = 0; k < c->n_scan_streams; k++)
                 HIP_TRY(c, hipStreamCreateWithPriority(&c->scan_stream[k], hipStreamNonBlocking, k & 1 ? p1 : p0));
-            if (tuning_env("ADSB_TIMELINE")) std::fprintf(stderr, "stream priorities: least %d greatest %d\n", least, greatest);
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->score_stream, hipStreamNonBlocking, ps));
+        } else {
+            std::lock_guard<std::mutex> lk(g_streams_mu);
+            DeviceStreams *ds = nullptr;
+            if (int rc2 = device_streams(c, device, &ds)) return rc2;
+            if (c->n_scan_streams == kScanStreams) {
+                for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = ds->scan[k];
+            } else {
+                const unsigned pair = ds->next_pair++ & 1u;
+                c->scan_stream[0] = ds->scan[2 * pair];
+                c->scan_stream[1] = ds->scan[2 * pair + 1];
+            }
+            c->tail_stream = ds->low[ds->next_low++ & 3u];
+            c->score_stream = ds->low[ds->next_low++ & 3u];
+            if (!ds->free_own.empty()) {
+                c->own_stream = ds->free_own.back();
+                ds->free_own.pop_back();
+            } else {
+                HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+            }
         }
+        c->stream = c->own_stream;
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
         HIP_TRY(c, hipEventCreateWithFlags(&c->lazy_ev, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -163,13 +178,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             }
             cd.exact = c->exact_bm[0];
             cd.si = reinterpret_cast<uint32_t *>(cd.exact);  // (non-null: "scoring is available")
-            if (!c->score_stream) {
-                int least = 0, greatest = 0;
-                HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                int ps = least;  // with the tail stream's priority: its own hardware queue in that pool
-                if (const char *e = tuning_env("ADSB_SCORE_PRIO")) ps = std::atoi(e) == 2 ? greatest : (std::atoi(e) == 1 ? (least + greatest) / 2 : least);
-                HIP_TRY(c, hipStreamCreateWithPriority(&c->score_stream, hipStreamNonBlocking, ps));
-            }
             for (int si = 0; si < c->n_slots; si++) {
                 Slot &sl = c->slot[si];
                 ScoreDev &sd = sl.score;
@@ -404,29 +412,16 @@ void adsb_destroy(adsb_ctx *c)
                 }
         (void)hipFree(c->d_timeline);
     }
-    {
-        // the streams go back to the pool (a context whose creation failed half-way has no full set:
-        // its streams are simply destroyed)
-        StreamSet set;
-        set.device = c->device;
-        set.n_scan = c->n_scan_streams;
-        set.own = c->own_stream;
-        bool all_scan = true;
-        for (int k = 0; k < kScanStreams; k++) {
-            set.scan[k] = c->scan_stream[k];
-            all_scan = all_scan && (set.scan[k] || k >= c->n_scan_streams);
-        }
-        set.tail = c->tail_stream;
-        set.score = c->score_stream;
-        if (set.own && all_scan && set.tail && set.score) {
-            std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-            g_stream_pool.push_back(set);
-        } else {
-            for (hipStream_t q : {set.own, set.tail, set.score})
-                if (q) (void)hipStreamDestroy(q);
-            for (hipStream_t q : set.scan)
-                if (q) (void)hipStreamDestroy(q);
-        }
+    if (c->private_streams) {
+        for (hipStream_t q : {c->own_stream, c->tail_stream, c->score_stream})
+            if (q) (void)hipStreamDestroy(q);
+        for (hipStream_t q : c->scan_stream)
+            if (q) (void)hipStreamDestroy(q);
+    } else if (c->own_stream) {
+        // the scan / tail / score streams are the device's (shared, never destroyed); the context's own goes back
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        for (DeviceStreams *d : g_device_streams)
+            if (d->device == c->device) d->free_own.push_back(c->own_stream);
     }
     delete c;
 }

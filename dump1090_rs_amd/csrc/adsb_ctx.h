@@ -110,6 +110,7 @@ constexpr size_t kTimelineWords = (size_t)adsb::kApSegments * 8 * 8;  // 8 waves
 struct adsb_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
+    bool private_streams = false;   // tuning builds only: this context created (and destroys) its streams itself
     hipStream_t stream = nullptr;
     bool own_stream_dirty = false;  // the library has enqueued something on own_stream that the next pass reads (a host-pointer call's copy)
     int profiling = 1;  // 0: no events, 1: around the scan kernel, 2: around every kernel
