@@ -17,44 +17,71 @@ extern "C" {
 // a few buffers (four) held six high-priority streams, two of which shared a queue -- the one-buffer ring ran at 6.8
 // instead of 8.8 Gsample/s, or the large stream at 0.129 instead of 0.097 ms per step, depending on who came first --
 // unless the process set GPU_MAX_HW_QUEUES=8 before the runtime started.
-// So the library never holds more than four streams of a priority per device, whatever its users create: per device,
-// for the life of the process, FOUR highest-priority streams (created in a row, the first time a context is made on the
-// device: streams added to a set later did not behave like four created together) that every context's scans run on --
-// a context for passes of a few buffers uses all four, a large context one of the two pairs, contexts side by side take
-// the pairs in turn -- and four lowest-priority ones that the contexts' tail and score chains share the same way.  Two
-// contexts on one stream are simply two in-order users of it (every wait is for an event recorded before: no cycle).
-// No environment variable is needed by anybody.
+// So the library never holds more than four streams of a priority per device, whatever its users create
+// (profiles/r5_stream_pool_ab.txt).  Per device, for the life of the process:
+//   * TWO highest-priority streams that every large context's scans alternate between.  Exactly two: with four in
+//     existence -- even unused -- the large sparse stream's step went from 0.096 to 0.125 ms (consecutive scans no
+//     longer overlapped);
+//   * FOUR normal-priority streams, made when the first context for passes of a few buffers is, that every such
+//     context's one-launch passes rotate over: 10.3-10.6 Gsample/s for the one-buffer ring in a process of its own
+//     (four high-priority ones of its own, round 4: 8.7 on the same box; the two shared high-priority ones alone: 8.9;
+//     two high + two normal: 6.3 -- mixed priorities finish passes out of order);
+//   * TWO lowest-priority ones for the contexts' tail and score chains.
+// Contexts that share a stream are simply several in-order users of it (every wait is for an event recorded before it
+// was asked for: no cycle).  No environment variable is needed by anybody.
 struct DeviceStreams {
     int device = -1;
-    hipStream_t scan[kScanStreams] = {};   // highest priority
+    int least = 0, greatest = 0;
+    hipStream_t high[2] = {};              // highest priority: the scans of large contexts
+    hipStream_t small[kScanStreams] = {};  // the four scan streams of contexts for passes of a few buffers
     hipStream_t low[4] = {};               // lowest priority: tail and score chains
-    unsigned next_pair = 0, next_low = 0;
+    int n_low = 0;
+    unsigned next_low = 0;
     std::vector<hipStream_t> free_own;     // normal priority: a context's own stream (input order, host-pointer copies)
 };
 std::mutex g_streams_mu;
 std::vector<DeviceStreams *> g_device_streams;   // (never freed: the streams live as long as the process)
 
 // under g_streams_mu, the device current
-int device_streams(adsb_ctx *c, int device, DeviceStreams **out)
+int device_streams(adsb_ctx *c, int device, bool small, DeviceStreams **out)
 {
-    for (DeviceStreams *d : g_device_streams)
-        if (d->device == device) {
-            *out = d;
-            return ADSB_OK;
-        }
-    DeviceStreams *d = new (std::nothrow) DeviceStreams;
-    if (!d) return ADSB_ERR_NOMEM;
-    d->device = device;
-    int least = 0, greatest = 0;
-    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // The scan streams all take the highest priority: that pool holds nothing else of this process (the null stream,
+    DeviceStreams *d = nullptr;
+    for (DeviceStreams *e : g_device_streams)
+        if (e->device == device) d = e;
+    if (!d) {
+        d = new (std::nothrow) DeviceStreams;
+        if (!d) return ADSB_ERR_NOMEM;
+        d->device = device;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&d->least, &d->greatest));
+        g_device_streams.push_back(d);
+    }
+    // The two scan streams take the highest priority: that pool holds nothing else of this process (the null stream,
     // torch's and the caller's streams are of normal priority), so each gets a queue and consecutive scans overlap.
     // They must have the SAME priority: with different ones, whenever two scans are pending at once the higher one
     // starts first, its successor on that stream is then free earlier too, and the stream settles into finishing
     // passes in the order 2, 1, 4, 3, ... for thousands of passes, 8-10 % slower (measured over 22 000 passes).
-    for (auto &q : d->scan) HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, greatest));
-    for (auto &q : d->low) HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, least));
-    g_device_streams.push_back(d);
+    if (!d->high[0])
+        for (auto &q : d->high) HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, d->greatest));
+    if (!d->n_low) {
+        const int n = 2;
+        for (int k = 0; k < 4; k++) {
+            if (k < n) HIP_TRY(c, hipStreamCreateWithPriority(&d->low[k], hipStreamNonBlocking, d->least));
+            else d->low[k] = d->low[k % n];
+        }
+        d->n_low = n;
+    }
+    if (small && !d->small[0]) {
+        // (measurement aid, tuning builds: 0 the two high-priority streams + two more, 1 those two + two of normal
+        // priority, 2 four of normal priority, 3 four high-priority ones of its own, 4 four of the lowest priority)
+        const int variant = tuning_env("ADSB_POOL_SMALL") ? std::atoi(tuning_env("ADSB_POOL_SMALL")) : 2;
+        const int mid = (d->least + d->greatest) / 2;
+        for (int k = 0; k < kScanStreams; k++) {
+            const bool share = (variant == 0 || variant == 1) && k < 2;
+            const int prio = variant == 0 || variant == 3 ? d->greatest : (variant == 4 ? d->least : mid);
+            if (share) d->small[k] = d->high[k];
+            else HIP_TRY(c, hipStreamCreateWithPriority(&d->small[k], hipStreamNonBlocking, prio));
+        }
+    }
     *out = d;
     return ADSB_OK;
 }
@@ -125,14 +152,9 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         } else {
             std::lock_guard<std::mutex> lk(g_streams_mu);
             DeviceStreams *ds = nullptr;
-            if (int rc2 = device_streams(c, device, &ds)) return rc2;
-            if (c->n_scan_streams == kScanStreams) {
-                for (int k = 0; k < kScanStreams; k++) c->scan_stream[k] = ds->scan[k];
-            } else {
-                const unsigned pair = ds->next_pair++ & 1u;
-                c->scan_stream[0] = ds->scan[2 * pair];
-                c->scan_stream[1] = ds->scan[2 * pair + 1];
-            }
+            const bool small = c->n_scan_streams == kScanStreams;
+            if (int rc2 = device_streams(c, device, small, &ds)) return rc2;
+            for (int k = 0; k < c->n_scan_streams; k++) c->scan_stream[k] = small ? ds->small[k] : ds->high[k];
             c->tail_stream = ds->low[ds->next_low++ & 3u];
             c->score_stream = ds->low[ds->next_low++ & 3u];
             if (!ds->free_own.empty()) {
@@ -194,15 +216,26 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                 HIP_TRY(c, hipMemset(sd.state, 0, sizeof(ScoreState)));
                 HIP_TRY(c, hipEventCreateWithFlags(&sl.recorded, hipEventDisableTiming | hipEventDisableSystemFence));
             }
+            // The host side of every slot -- summary, score summary, additions, records, messages: mapped, coherent,
+            // written by the kernels with write-through stores -- as ONE pinned allocation per context, cut up here.
+            // (five separate allocations per slot were forty small pinned regions in a one-buffer context)
             const ScoreDev &sd = cd;
+            auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t o_ssum = up(sizeof(Summary)), o_adds = o_ssum + up(sizeof(ScoreSummary)),
+                         o_rec = o_adds + up((size_t)sd.cap * sizeof(uint32_t)),
+                         o_msgs = o_rec + up((size_t)c->hits_cap * sizeof(TrialRecord)),
+                         per_slot = o_msgs + up((size_t)sd.cap * sizeof(adsb_msg));
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_block, per_slot * (size_t)c->n_slots, hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(c, hipHostGetDevicePointer((void **)&c->h_block_dev, c->h_block, 0));
             for (int si = 0; si < c->n_slots; si++) {
                 Slot &sl = c->slot[si];
-                HIP_TRY(c, hipHostMalloc((void **)&sl.h_msgs, (size_t)sd.cap * sizeof(adsb_msg), hipHostMallocMapped | hipHostMallocCoherent));
-                HIP_TRY(c, hipHostMalloc((void **)&sl.h_adds, (size_t)sd.cap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-                HIP_TRY(c, hipHostMalloc((void **)&sl.h_ssum, sizeof(ScoreSummary), hipHostMallocMapped | hipHostMallocCoherent));
-                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_msgs_dev, sl.h_msgs, 0));
-                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_adds_dev, sl.h_adds, 0));
-                HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_ssum_dev, sl.h_ssum, 0));
+                char *h = c->h_block + per_slot * (size_t)si, *d = c->h_block_dev + per_slot * (size_t)si;
+                sl.h_sum = reinterpret_cast<Summary *>(h), sl.h_sum_dev = reinterpret_cast<Summary *>(d);
+                sl.h_ssum = reinterpret_cast<ScoreSummary *>(h + o_ssum), sl.h_ssum_dev = reinterpret_cast<ScoreSummary *>(d + o_ssum);
+                sl.h_adds = reinterpret_cast<uint32_t *>(h + o_adds), sl.h_adds_dev = reinterpret_cast<uint32_t *>(d + o_adds);
+                sl.h_rec = reinterpret_cast<TrialRecord *>(h + o_rec), sl.h_rec_dev = reinterpret_cast<TrialRecord *>(d + o_rec);
+                sl.h_msgs = reinterpret_cast<adsb_msg *>(h + o_msgs), sl.h_msgs_dev = reinterpret_cast<adsb_msg *>(d + o_msgs);
+                std::memset(sl.h_sum, 0, sizeof(Summary));
                 std::memset(sl.h_ssum, 0, sizeof(ScoreSummary));
             }
         }
@@ -219,13 +252,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         }
         for (int si = 0; si < c->n_slots; si++) {
             Slot &sl = c->slot[si];
-            // (mapped + coherent: the records kernel's write-through stores are visible to the host
-            // when its completion event fires, whatever the runtime's default for pinned memory)
-            HIP_TRY(c, hipHostMalloc((void **)&sl.h_sum, sizeof(Summary), hipHostMallocMapped | hipHostMallocCoherent));
-            HIP_TRY(c, hipHostMalloc((void **)&sl.h_rec, (size_t)c->hits_cap * sizeof(TrialRecord),
-                                     hipHostMallocMapped | hipHostMallocCoherent));
-            HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_sum_dev, sl.h_sum, 0));
-            HIP_TRY(c, hipHostGetDevicePointer((void **)&sl.h_rec_dev, sl.h_rec, 0));
+            // (the slot's summary and records live in the context's one pinned block: mapped + coherent, so the records
+            // kernel's write-through stores are visible to the host when its completion event fires)
             // timing-only events: no system-scope fence when they complete (~10 us each otherwise)
             for (int k = 2; k < 5; k++) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev[k], hipEventDisableSystemFence));
             const bool fenced = tuning_env("ADSB_DONE_FENCE") != nullptr;  // measurement aid only
@@ -299,12 +327,7 @@ void adsb_destroy(adsb_ctx *c)
         if (sl.d_order_cnt) (void)hipFree(sl.d_order_cnt);
         if (sl.d_order_base) (void)hipFree(sl.d_order_base);
         if (sl.d_order_tmp) (void)hipFree(sl.d_order_tmp);
-        if (sl.h_msgs) (void)hipHostFree(sl.h_msgs);
-        if (sl.h_adds) (void)hipHostFree(sl.h_adds);
-        if (sl.h_ssum) (void)hipHostFree(sl.h_ssum);
         if (sl.d_carry) (void)hipFree(sl.d_carry);
-        if (sl.h_sum) (void)hipHostFree(sl.h_sum);
-        if (sl.h_rec) (void)hipHostFree(sl.h_rec);
     }
     if (c->d_stage) (void)hipFree(c->d_stage);
     for (auto &b : c->d_bitmap)
@@ -315,6 +338,7 @@ void adsb_destroy(adsb_ctx *c)
         if (e) (void)hipEventDestroy(e);
     if (c->lazy_ev) (void)hipEventDestroy(c->lazy_ev);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_block) (void)hipHostFree(c->h_block);
     if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
     for (Slot &sl : c->slot) {
         for (void *q : {(void *)sl.score.si, (void *)sl.score.rec, (void *)sl.score.flag, (void *)sl.score.slot, (void *)sl.score.pos,
@@ -330,10 +354,8 @@ void adsb_destroy(adsb_ctx *c)
     if (c->fb.h_rec) (void)hipHostFree(c->fb.h_rec);
     for (const auto &r : c->host_ranges) (void)hipHostUnregister(r.base);
     if (c->d_tables) (void)hipFree(c->d_tables);
-    for (auto &r : c->ring) {
-        if (r.h_iq) (void)hipHostFree(r.h_iq);
-        if (r.d_iq) (void)hipFree(r.d_iq);
-    }
+    if (c->ring_h_block) (void)hipHostFree(c->ring_h_block);
+    if (c->ring_d_block) (void)hipFree(c->ring_d_block);
     if (c->d_addrs) (void)hipFree(c->d_addrs);
     for (auto &j : c->shard)
         if (j.h_addrs) (void)hipHostFree(j.h_addrs);

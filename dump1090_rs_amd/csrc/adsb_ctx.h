@@ -120,6 +120,7 @@ struct adsb_ctx {
     unsigned long long *d_timeline = nullptr;  // ADSB_TIMELINE=1: 8 blocks x 8 tiles x 8 stamps
     size_t max_chunks = 0;
 
+    char *h_block = nullptr, *h_block_dev = nullptr;   // the host side of every slot (summaries, records, messages): one pinned allocation
     void *d_stage = nullptr;  // IQ staging for host-pointer calls (lazy)
     size_t stage_bytes = 0;
     void *h_stage = nullptr, *h_stage_dev = nullptr;  // ... pinned and mapped, for calls of a few buffers: the pass reads it in place
@@ -202,6 +203,7 @@ struct adsb_ctx {
         void *d_iq = nullptr;
     } ring[kSlots];
     size_t ring_samples = 0;
+    char *ring_h_block = nullptr, *ring_d_block = nullptr;   // all slots' pinned / staging buffers: one allocation each
 
     bool carry_over = false;  // adsb_set_carry_over: opt-in, not the reference's semantics
     uint32_t *d_carry_next = nullptr;  // the end of the latest submission's input: the next one's lead-in

@@ -16,12 +16,18 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
     if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     auto body = [&]() -> int {
+        // every slot's pinned buffer from ONE allocation, and every staging buffer from one (slot starts 4 KB aligned):
+        // mapped and coherent -- slots of a few buffers are read in place by the pass itself
+        const size_t stride = (samples_per_slot * 4 + 4095) & ~(size_t)4095;
+        char *h_dev = nullptr;
+        HIP_TRY(c, hipHostMalloc((void **)&c->ring_h_block, stride * (size_t)c->n_slots, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&h_dev, c->ring_h_block, 0));
+        HIP_TRY(c, hipMalloc((void **)&c->ring_d_block, stride * (size_t)c->n_slots));
         for (int k = 0; k < c->n_slots; k++) {
             auto &r = c->ring[k];
-            // (mapped and coherent: slots of a few buffers are read in place by the pass itself)
-            HIP_TRY(c, hipHostMalloc((void **)&r.h_iq, samples_per_slot * 4, hipHostMallocMapped | hipHostMallocCoherent));
-            HIP_TRY(c, hipHostGetDevicePointer(&r.h_iq_dev, r.h_iq, 0));
-            HIP_TRY(c, hipMalloc(&r.d_iq, samples_per_slot * 4));
+            r.h_iq = reinterpret_cast<int16_t *>(c->ring_h_block + stride * (size_t)k);
+            r.h_iq_dev = h_dev + stride * (size_t)k;
+            r.d_iq = c->ring_d_block + stride * (size_t)k;
         }
         // One small copy per slot now, on an idle stream.  The runtime sets something up on the first copy between a
         // pair of buffers; left to the first pipelined submit (a ring that starts with its slots read in place) every
@@ -37,11 +43,10 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
     if (rc != ADSB_OK) {
         // nothing half-made stays behind: a retry starts from scratch instead of overwriting (and leaking) these
         for (int k = 0; k < c->n_scan_streams; k++) (void)hipStreamSynchronize(c->scan_stream[k]);
-        for (auto &r : c->ring) {
-            if (r.h_iq) (void)hipHostFree(r.h_iq);
-            if (r.d_iq) (void)hipFree(r.d_iq);
-            r = adsb_ctx::RingSlot{};
-        }
+        if (c->ring_h_block) (void)hipHostFree(c->ring_h_block);
+        if (c->ring_d_block) (void)hipFree(c->ring_d_block);
+        c->ring_h_block = c->ring_d_block = nullptr;
+        for (auto &r : c->ring) r = adsb_ctx::RingSlot{};
         return rc;
     }
     c->ring_samples = samples_per_slot;
