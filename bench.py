@@ -1128,6 +1128,51 @@ def run_config1(env: Env):
         L.adsb_icao_flush(h)
         L.adsb_demod_iq(h, own_ptr, len(own), raw_out, 4096, C.byref(raw_n))
 
+    # the benchmark's own loop shape pipelined: icao_flush + one buffer per call (benches/demod_benchmark.rs:9-11), eight
+    # calls in flight -- what a host that keeps the GPU fed pays per reference-shaped call.  Every pass starts from a
+    # flushed filter, so every pass's frames are the capture's own (checked below on 64 of them).
+    depth = ctx.max_in_flight()
+
+    def pipelined(count):
+        inflight, got = 0, 0
+        for _ in range(count):
+            L.adsb_icao_flush(h)
+            L.adsb_submit_iq_device(h, dev_ptr, len(iq))
+            inflight += 1
+            if inflight >= depth:
+                L.adsb_collect(h, raw_out, 4096, C.byref(raw_n))
+                got += raw_n.value
+                inflight -= 1
+        while inflight:
+            L.adsb_collect(h, raw_out, 4096, C.byref(raw_n))
+            got += raw_n.value
+            inflight -= 1
+        return got
+
+    t = time.perf_counter()
+    while time.perf_counter() - t < 0.25:
+        pipelined(200)
+    torch.cuda.synchronize()
+    t, reps, frames_seen = time.perf_counter(), 0, 0
+    while time.perf_counter() - t < 0.6:
+        frames_seen += pipelined(400)
+        reps += 400
+    torch.cuda.synchronize()
+    ms_pipelined_flush_each = (time.perf_counter() - t) / reps * 1e3
+    ok = ok and frames_seen == reps * len(fx["frames"])
+    inflight, lists = 0, []
+    for _ in range(64):
+        ctx.icao_flush()
+        ctx.submit_iq_device(dev.data_ptr(), len(iq))
+        inflight += 1
+        if inflight >= depth:
+            lists.append(ctx.collect())
+            inflight -= 1
+    while inflight:
+        lists.append(ctx.collect())
+        inflight -= 1
+    ok = ok and all([m.buffer().hex() for m in msgs] == fx["frames"] for msgs in lists)
+
     out = {"workload": "icao_flush + to_mag + demodulate2400 on test_1641427457780.iq, 131072 samples "
                        "(benches/demod_benchmark.rs:7-12; BASELINE config 1)",
            "ms_to_mag_plus_demodulate2400": round(timeit(ref_api), 4),
@@ -1137,6 +1182,9 @@ def run_config1(env: Env):
            "ms_fused_host_iq_c_abi": round(timeit(abi_host), 4),
            "ms_fused_resident_iq_c_abi": round(timeit(abi_dev), 4),
            "ms_fused_registered_host_iq_c_abi": None,
+           "ms_pipelined_flush_each": round(ms_pipelined_flush_each, 4),
+           "ms_pipelined_flush_each_is": f"adsb_icao_flush + adsb_submit_iq_device (resident capture) per call, {depth} calls in flight, "
+                                         "adsb_collect in order; per call; every call's frame count checked, 64 calls' frames compared",
            "timing": "mean of back-to-back calls over >= 0.6 s after 0.25 s of warm-up, each through the Python mirror "
                      "of the reference's API (dump1090_rs_amd.Context: a list of message objects built per call); "
                      "*_c_abi: adsb_icao_flush + the one ABI call, as a compiled caller makes them.  A call of one "
@@ -1211,8 +1259,18 @@ def main():
     elif args.workload == "shard":
         result = run_shard(env, args)
     else:
+        small_first = env.rank == 0 and env.world == 1 and not args.no_also and not args.sync and args.workload == "sparse"
+        if small_first:
+            # A context for passes of a few buffers made (and closed again) BEFORE this process builds its synthetic
+            # buffers with torch: measured (profiles/r5_stream_pool_ab.txt), the `also` legs' one-buffer ring then runs
+            # at 10.9-11.5 Gsample/s instead of 8.7-9.4, whatever else is done in between -- something in the order in
+            # which the runtime first sees the library's allocations; the headline leg is unaffected either way
+            # (0.096-0.098 ms per step).  Said in the line: config.small_context_first.
+            from dump1090_rs_amd import Context
+            Context(env.local_rank, 1).close()
         r = run_resident(env, args, args.workload, args.steps, args.warmup)
         result = resident_result(env, args, r, args.workload)
+        result["config"]["small_context_first"] = bool(small_first)
         if env.rank == 0 and not args.no_cpu_baseline:
             # N = 1: the CPU baseline beside the line; N > 1: the parity gate alone (rank 0's buffer 0
             # against the oracle), so that the line verifies itself wherever the driver runs it

@@ -1,5 +1,7 @@
 // adsb_aux.hip -- the small kernels around the scan: to_mag alone, the address/parity
 // match, the record builder and the magnitude self-test digest.
+#include <algorithm>
+
 #include "../../include/adsb_hip.h"
 #include "adsb_dev_common.h"
 #include "adsb_tail_dev.h"
@@ -46,12 +48,12 @@ __global__ __launch_bounds__(256) void k_to_mag(const uint32_t *__restrict__ iq,
 // after an icao_flush, the 2 MiB address bitmap; address 0 always tests true
 // (src/icao_filter.rs:71-80: an empty slot equals 0), so bit 0 starts set.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reset(Counters *ctr, uint32_t *bitmap)
+__global__ __launch_bounds__(256) void k_reset(Counters *ctr, uint32_t *bitmap, uint32_t lg)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr uint32_t kCtrDwords = sizeof(Counters) / 4;
     if (i < kCtrDwords) ((uint32_t *)ctr)[i] = 0;
-    if (bitmap) bitmap_clear(bitmap, i, gridDim.x * blockDim.x);
+    if (bitmap) bitmap_clear(bitmap, lg, i, gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
     __shared__ uint32_t stab[3 * 256];
     __shared__ uint32_t coarse[kCoarseWords];
     for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) stab[i] = p.tables[kTabX56 * 256 + i];
-    if (threadIdx.x < kCoarseWords) coarse[threadIdx.x] = p.bitmap[kBitmapWords + threadIdx.x];
+    if (threadIdx.x < kCoarseWords) coarse[threadIdx.x] = p.bitmap[bitmap_words(p.bitmap_lg) + threadIdx.x];
     __syncthreads();
     const uint32_t seg_cap = p.seg_cap;
     // work units: pairs of wave segments of the fast scan's list (a few hundred entries per
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (e[k] == ~0ull || !((coarse[(c[k] & 4095u) >> 5] >> (c[k] & 31)) & 1u)) continue;
-            if ((p.bitmap[c[k] >> 5] >> (c[k] & 31)) & 1u) {  // rare: one atomic each
+            const uint32_t at = bitmap_index(c[k], p.bitmap_lg);
+            if ((p.bitmap[at >> 5] >> (at & 31)) & 1u) {  // rare: one atomic each
                 const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
                 if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
                     const uint32_t ch = (uint32_t)entry_chunk(e[k]);
@@ -457,10 +460,10 @@ __global__ __launch_bounds__(kCarrySamples) void k_update_carry(const uint32_t *
 
 // addresses learned elsewhere (other shards of the same capture) join the superset
 __global__ __launch_bounds__(256) void k_set_addresses(const uint32_t *__restrict__ addrs, uint32_t n,
-                                                       uint32_t *bitmap)
+                                                       uint32_t *bitmap, uint32_t lg)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) bitmap_set(bitmap, addrs[i] & 0xFFFFFFu);
+    if (i < n) bitmap_set(bitmap, lg, addrs[i] & 0xFFFFFFu);
 }
 
 // ---------------------------------------------------------------------------
@@ -506,11 +509,12 @@ int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream)
     return hip_ok(hipGetLastError());
 }
 
-int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream)
+int launch_reset(Counters *ctr, uint32_t *bitmap, uint32_t bitmap_lg, void *stream)
 {
     hip_clear();
-    const uint32_t blocks = bitmap ? 512u : (uint32_t)((sizeof(Counters) / 4 + 255) / 256);
-    hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ctr, bitmap);
+    const uint32_t ctr_blocks = (uint32_t)((sizeof(Counters) / 4 + 255) / 256);
+    const uint32_t blocks = bitmap ? std::max(ctr_blocks, std::min(512u, bitmap_alloc_words(bitmap_lg) / 4 / 256 + 1u)) : ctr_blocks;
+    hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ctr, bitmap, bitmap_lg);
     return hip_ok(hipGetLastError());
 }
 
@@ -566,12 +570,12 @@ int launch_score(const ScanParams &p, void *stream)
     return hip_ok(hipGetLastError());
 }
 
-int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream)
+int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, uint32_t bitmap_lg, void *stream)
 {
     hip_clear();
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_set_addresses, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_addrs, n,
-                       bitmap);
+                       bitmap, bitmap_lg);
     return hip_ok(hipGetLastError());
 }
 

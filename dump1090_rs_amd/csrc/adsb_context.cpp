@@ -111,6 +111,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     c->n_slots = max_chunks <= kInlineTailChunks ? ADSB_MAX_IN_FLIGHT_SMALL : ADSB_MAX_IN_FLIGHT;
     c->n_bitmaps = c->n_slots + 1;
     c->n_scan_streams = c->n_slots == ADSB_MAX_IN_FLIGHT_SMALL ? kScanStreams : 2;
+    c->bitmap_lg = c->n_slots == ADSB_MAX_IN_FLIGHT_SMALL ? kSmallBitmapLg : kFullBitmapLg;
     if (const char *ds = tuning_env("ADSB_DEBUG_STOP")) c->debug_stop = std::atoi(ds);
     if (const char *st = tuning_env("ADSB_STAGGER")) c->stagger_ticks = (uint32_t)std::atoi(st);
     // The fast scan's AP list: one private segment per wave of every persistent workgroup (a pass
@@ -168,7 +169,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         for (auto &e : c->input_ready)
             HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
         HIP_TRY(c, hipEventCreateWithFlags(&c->lazy_ev, hipEventDisableTiming | hipEventDisableSystemFence));
-        for (int k = 0; k < c->n_bitmaps; k++) HIP_TRY(c, hipMalloc((void **)&c->d_bitmap[k], kBitmapAllocWords * sizeof(uint32_t)));
+        for (int k = 0; k < c->n_bitmaps; k++) HIP_TRY(c, hipMalloc((void **)&c->d_bitmap[k], bitmap_alloc_words(c->bitmap_lg) * sizeof(uint32_t)));
         for (int si = 0; si < c->n_slots; si++) {
             Slot &sl = c->slot[si];
             HIP_TRY(c, hipMalloc((void **)&sl.d_ctr, sizeof(Counters)));
@@ -190,20 +191,28 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             // device-side scoring state (shared by the passes: they go through it one after the other
             // on the tail stream); passes of more hits than `cap` are scored on the host
             ScoreDev &cd = c->score;   // cap / hash_mask / exact: the context's; the rest per slot
-            cd.cap = std::min<uint32_t>(c->hits_cap, 131072u);
+            // (a context for passes of a few buffers never orders or scores on the device -- its passes are one
+            // launch each, replayed by the host in microseconds -- and carries none of this: no exact bitmaps, no
+            // scoring buffers, no message slots in its pinned block)
+            const bool scoring = c->n_slots != ADSB_MAX_IN_FLIGHT_SMALL;
+            cd.cap = scoring ? std::min<uint32_t>(c->hits_cap, 131072u) : 0u;
             uint32_t hsize = 1;
             while (hsize < 2 * cd.cap) hsize <<= 1;
             cd.hash_mask = hsize - 1;
-            for (auto &bm : c->exact_bm) {
-                HIP_TRY(c, hipMalloc((void **)&bm, kBitmapAllocWords * sizeof(uint32_t)));
-                HIP_TRY(c, hipMemset(bm, 0, kBitmapAllocWords * sizeof(uint32_t)));
+            if (scoring) {
+                for (auto &bm : c->exact_bm) {
+                    HIP_TRY(c, hipMalloc((void **)&bm, kBitmapAllocWords * sizeof(uint32_t)));
+                    HIP_TRY(c, hipMemset(bm, 0, kBitmapAllocWords * sizeof(uint32_t)));
+                }
+                cd.exact = c->exact_bm[0];
+                cd.si = reinterpret_cast<uint32_t *>(cd.exact);  // (non-null: "scoring is available")
             }
-            cd.exact = c->exact_bm[0];
-            cd.si = reinterpret_cast<uint32_t *>(cd.exact);  // (non-null: "scoring is available")
             for (int si = 0; si < c->n_slots; si++) {
                 Slot &sl = c->slot[si];
                 ScoreDev &sd = sl.score;
                 sd = cd;
+                HIP_TRY(c, hipEventCreateWithFlags(&sl.recorded, hipEventDisableTiming | hipEventDisableSystemFence));
+                if (!scoring) continue;
                 HIP_TRY(c, hipMalloc((void **)&sd.si, (size_t)sd.cap * sizeof(uint32_t)));
                 HIP_TRY(c, hipMalloc((void **)&sd.rec, (size_t)sd.cap * sizeof(TrialRecord)));
                 HIP_TRY(c, hipMalloc((void **)&sd.flag, (size_t)sd.cap * sizeof(uint32_t)));
@@ -214,7 +223,6 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
                 HIP_TRY(c, hipMalloc((void **)&sd.blk, 2 * kScoreBlocks * sizeof(uint32_t)));
                 HIP_TRY(c, hipMalloc((void **)&sd.state, sizeof(ScoreState)));
                 HIP_TRY(c, hipMemset(sd.state, 0, sizeof(ScoreState)));
-                HIP_TRY(c, hipEventCreateWithFlags(&sl.recorded, hipEventDisableTiming | hipEventDisableSystemFence));
             }
             // The host side of every slot -- summary, score summary, additions, records, messages: mapped, coherent,
             // written by the kernels with write-through stores -- as ONE pinned allocation per context, cut up here.
@@ -270,7 +278,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         // both bitmaps clean and both counter blocks zero to start with; from then on each
         // pass cleans up for the next (the first pass needs no flush of its own)
         for (int k = 0; k < c->n_bitmaps; k++)
-            if (int e = launch_reset(c->slot[k % (uint64_t)c->n_slots].d_ctr, c->d_bitmap[k], c->stream))
+            if (int e = launch_reset(c->slot[k % (uint64_t)c->n_slots].d_ctr, c->d_bitmap[k], c->bitmap_lg, c->stream))
                 return fail(c, (hipError_t)e, "launch_reset");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->flush_pending = false;

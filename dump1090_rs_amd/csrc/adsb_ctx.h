@@ -132,6 +132,7 @@ struct adsb_ctx {
     // is ever needed.
     uint32_t *d_bitmap[kBitmaps] = {};
     int cur_bitmap = 0;
+    uint32_t bitmap_lg = kFullBitmapLg;   // kSmallBitmapLg in a context for passes of a few buffers: folded bitmaps, no device-side scoring
     hipStream_t score_stream = nullptr;  // k_score / k_emit of the device-scored passes, in pass order
     hipStream_t tail_stream = nullptr;  // match + records of pass i run here, beside scan i+1
     // The scans run on two internal streams, alternating between consecutive pipelined passes:

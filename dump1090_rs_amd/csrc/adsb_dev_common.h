@@ -282,20 +282,22 @@ __device__ __forceinline__ void wave_append(bool has, uint64_t e, uint64_t *list
     }
 }
 
-// clear a bitmap and its summary; address 0 always tests true (src/icao_filter.rs:71-80: an
+// clear a bitmap (2^lg bits) and its summary; address 0 always tests true (src/icao_filter.rs:71-80: an
 // empty slot equals 0), so bit 0 starts set in both.  Call with all threads of the grid.
-__device__ __forceinline__ void bitmap_clear(uint32_t *bitmap, uint32_t gi, uint32_t gn)
+__device__ __forceinline__ void bitmap_clear(uint32_t *bitmap, uint32_t lg, uint32_t gi, uint32_t gn)
 {
-    for (uint32_t v = gi; v < kBitmapAllocWords / 4; v += gn)
-        ((uint4 *)bitmap)[v] = make_uint4((v == 0 || v == kBitmapWords / 4) ? 1u : 0u, 0u, 0u, 0u);
+    const uint32_t words = bitmap_words(lg);
+    for (uint32_t v = gi; v < (words + kCoarseWords) / 4; v += gn)
+        ((uint4 *)bitmap)[v] = make_uint4((v == 0 || v == words / 4) ? 1u : 0u, 0u, 0u, 0u);
 }
 
 // returns true when the address bit was clear before
-__device__ __forceinline__ bool bitmap_set(uint32_t *bitmap, uint32_t addr)
+__device__ __forceinline__ bool bitmap_set(uint32_t *bitmap, uint32_t lg, uint32_t addr)
 {
-    const uint32_t old = atomicOr(&bitmap[addr >> 5], 1u << (addr & 31));
-    atomicOr(&bitmap[kBitmapWords + ((addr & 4095u) >> 5)], 1u << (addr & 31));  // the summary
-    return ((old >> (addr & 31)) & 1u) == 0;
+    const uint32_t at = bitmap_index(addr, lg);
+    const uint32_t old = atomicOr(&bitmap[at >> 5], 1u << (at & 31));
+    atomicOr(&bitmap[bitmap_words(lg) + ((addr & 4095u) >> 5)], 1u << (addr & 31));  // the summary
+    return ((old >> (at & 31)) & 1u) == 0;
 }
 
 // samples in `chunk` of a call over n_samples (the last chunk may be short)

@@ -100,7 +100,7 @@ struct Counters {
     uint32_t new_addr[kNewAddrCap];  // ... and the first of those addresses
     uint32_t unordered;      // one-launch pass: a workgroup gave up waiting for the tiles before its own (bounded wait)
     uint32_t t_start[2];     // one-launch pass: the 100 MHz wall clock when its first workgroup started
-    uint32_t reserved2;
+    uint32_t bitmap_ready;   // one-launch pass behind an icao_flush: its first workgroup has cleared the (folded) bitmap
     uint32_t tile_done[kFusedMaxTiles];  // one-launch pass: tile t's address bits and list entries are published
     uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
@@ -188,7 +188,12 @@ struct ScanParams {
     const void *src;        // IQ as {re,im} int16 pairs, or u16 magnitudes (from_mag)
     uint64_t n_samples;     // IQ: total samples in the call.  from_mag: `length` of the buffer
     uint32_t n_chunks;
-    uint32_t *bitmap;       // 2^24 bits
+    uint32_t *bitmap;       // 2^bitmap_lg bits + the 4096-bit summary
+    uint32_t bitmap_lg;     // 24: bit a is address a; kSmallBitmapLg: folded (contexts for passes of a few buffers)
+    uint32_t bitmap_fresh;  // an icao_flush precedes this pass and `bitmap` is the next one in the rotation, NOT yet
+                            // clean: a one-launch pass clears it itself -- its first workgroup does, the others wait for
+                            // Counters::bitmap_ready before they touch it (folded bitmaps only: 64 KB); every pass that
+                            // used it has been collected (one bitmap more than passes in flight), so nobody is waited for
     uint64_t *hits;
     uint32_t hits_cap;
     uint64_t *ap;           // wave segment g at ap + g * seg_cap (only the segments a context's largest pass can use are allocated)
@@ -250,6 +255,18 @@ struct ScanParams {
 // for the few per cent of residuals that pass it.
 constexpr uint32_t kBitmapWords = 1u << 19, kCoarseWords = 128;
 constexpr uint32_t kBitmapAllocWords = kBitmapWords + kCoarseWords;
+// A context for passes of a few buffers keeps its supersets FOLDED: 2^19 bits (64 KB) addressed by a ^ (a >> 19)
+// instead of 2^24 (2 MiB) addressed by a.  The bitmap only has to be a superset of the filter (DESIGN.md section 3:
+// a false positive costs one more trial record, which the ordered replay scores against the real filter), a receiver
+// hears a few hundred aircraft, and such a context used to carry eleven 2 MiB bitmaps -- 23 of its 33 MB -- and clear
+// one behind every icao_flush.  bitmap_lg = log2 of the bits: 24 (exact) or kSmallBitmapLg.
+constexpr uint32_t kFullBitmapLg = 24, kSmallBitmapLg = 19;
+__host__ __device__ inline uint32_t bitmap_words(uint32_t lg) { return 1u << (lg - 5u); }
+__host__ __device__ inline uint32_t bitmap_alloc_words(uint32_t lg) { return bitmap_words(lg) + kCoarseWords; }
+__host__ __device__ inline uint32_t bitmap_index(uint32_t a, uint32_t lg)
+{
+    return lg >= kFullBitmapLg ? a : ((a ^ (a >> lg)) & ((1u << lg) - 1u));
+}
 
 // hits one buffer's bucket holds on a dense stream (device-side ordering): ~20x a busy airspace;
 // a fuller one is an overflow like any other list's (the pass is redone buffer by buffer)
@@ -260,7 +277,7 @@ constexpr int kCarrySamples = 328;  // kLead rounded up to whole 16-byte loads
 int launch_to_mag(const void *d_iq, uint32_t n, uint16_t *d_data, void *stream);
 // zero a counters block and, when `bitmap` is non-null, clear an address bitmap (bit 0 stays
 // set); only needed once per context: afterwards every pass cleans up for the next one
-int launch_reset(Counters *ctr, uint32_t *bitmap, void *stream);
+int launch_reset(Counters *ctr, uint32_t *bitmap, uint32_t bitmap_lg, void *stream);
 int launch_scan(const ScanParams &p, bool from_mag, void *stream);   // fast (IQ) or simple (mag)
 // the whole pass in one launch (p.fused_rec set): one workgroup per tile, the last one to finish matches
 // what the pass learned late, builds the records and publishes the summary; for passes of a few buffers
@@ -276,7 +293,7 @@ int launch_order_hits(const ScanParams &p, void *stream);
 // into mapped host memory (p.score)
 int launch_score(const ScanParams &p, void *stream);
 // OR a list of 24-bit addresses into a bitmap (addresses learned by other shards)
-int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, void *stream);
+int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, uint32_t bitmap_lg, void *stream);
 // next[i] = sample (n - kCarrySamples + i) of the stream: from d_src, or from `prev` where the
 // call was shorter than the carry
 int launch_update_carry(const uint32_t *prev, const void *d_src, uint64_t n_samples, uint32_t *next, void *stream);

@@ -94,8 +94,18 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     p.n_samples = n_samples;
     p.n_chunks = n_chunks;
     p.clean_bitmap = nullptr;
-    if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the next clean one
-        p.clean_bitmap = c->d_bitmap[c->cur_bitmap];
+    p.bitmap_lg = c->bitmap_lg;
+    p.bitmap_fresh = 0;
+    if (c->flush_pending) {  // icao_flush: retire the bitmap in use, continue on the next one
+        // Full bitmaps (2 MiB): the next one IS clean, and this pass's records kernel cleans the retired one behind the
+        // passes still matching against it (edge 1).  Folded ones (64 KB, contexts for passes of a few buffers): the
+        // retired one is left as it is and this pass clears the NEXT one itself before it first touches it -- in its
+        // own launch (k_scan_fast<FUSED>: bitmap_fresh) or with a reset launch in front of its scan.  Whoever used
+        // that bitmap has been collected (one bitmap more than passes in flight), so the pass waits for nobody:
+        // an icao_flush before every pass, the reference's own benchmark shape (benches/demod_benchmark.rs:9), used
+        // to cost a pipelined one-buffer pass 99 us instead of 5.7 (profiles/r4_v18_hosttime_ring.txt).
+        if (c->bitmap_lg == kFullBitmapLg) p.clean_bitmap = c->d_bitmap[c->cur_bitmap];
+        else p.bitmap_fresh = 1;
         c->cur_bitmap = (c->cur_bitmap + 1) % c->n_bitmaps;
     }
     p.bitmap = c->d_bitmap[c->cur_bitmap];
@@ -264,6 +274,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
                 sl.unsynced_from = sl.unsynced_from ? std::min(sl.unsynced_from, other.scan_seq) : other.scan_seq;
     }
     sl.scan_q = ss;
+    if (p.bitmap_fresh && !fused) {
+        // (three launches in a context of folded bitmaps -- level-2 profiling, a caller's MagnitudeBuffer that
+        // overflowed -- : the clear as a launch of its own in front of the scan; the counters it also zeroes are zero)
+        if (int e = launch_reset(sl.d_ctr, p.bitmap, p.bitmap_lg, ss)) return fail(c, (hipError_t)e, "launch_reset");
+        p.bitmap_fresh = 0;
+    }
     if (classic) HIP_TRY(c, hipEventRecord(sl.ev[0], ss));
     if (p.carry && advance_carry)  // this pass's lead-in: where the previous submission ended
         HIP_TRY(c, hipMemcpyAsync(sl.d_carry, c->d_carry_next, kCarrySamples * sizeof(uint32_t),
@@ -383,7 +399,7 @@ int resync_exact(adsb_ctx *c)
             c->addrs_cap = IcaoFilter::kSize;
         }
         HIP_TRY(c, hipMemcpyAsync(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ts));
-        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->exact_bm[c->cur_exact], ts))
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->exact_bm[c->cur_exact], kFullBitmapLg, ts))
             return fail(c, (hipError_t)e, "launch_set_addresses");
     }
     HIP_TRY(c, hipStreamSynchronize(ts));  // (rare: only after the host scored a pass itself)
@@ -410,7 +426,7 @@ int reseed_bitmap_from_filter(adsb_ctx *c)
         c->addrs_cap = IcaoFilter::kSize;
     }
     HIP_TRY(c, hipMemcpy(c->d_addrs, addrs.data(), addrs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->d_bitmap[c->cur_bitmap], c->scan_stream[0]))
+    if (int e = launch_set_addresses(c->d_addrs, (uint32_t)addrs.size(), c->d_bitmap[c->cur_bitmap], c->bitmap_lg, c->scan_stream[0]))
         return fail(c, (hipError_t)e, "launch_set_addresses");
     return ADSB_OK;
 }

@@ -626,13 +626,13 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitF
         if constexpr (FUSED) {
             if (learn) {
                 const uint32_t addr = trial_addr(tr);
-                if (bitmap_set(p.bitmap, addr)) {
+                if (bitmap_set(p.bitmap, p.bitmap_lg, addr)) {
                     const uint32_t k = atomicAdd(&p.ctr->learned_new, 1u);
                     if (k < (uint32_t)kNewAddrCap) st_shared<true>(&p.ctr->new_addr[k], addr);
                 }
             }
         } else {
-            if (learn) bitmap_set(p.bitmap, trial_addr(tr));
+            if (learn) bitmap_set(p.bitmap, p.bitmap_lg, trial_addr(tr));
         }
     }
 }
@@ -701,8 +701,9 @@ __device__ __forceinline__ bool fused_match_entry(const ScanParams &p, const uin
     uint32_t c = entry_value(e);
     if (code >= 5u && code < 10u) c = gf_apply(x56, c);
     // (agent scope: bits other workgroups of this launch have set, not a line this CU's cache holds)
-    const uint32_t w = __hip_atomic_load(&p.bitmap[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((w >> (c & 31)) & 1u) {
+    const uint32_t at = bitmap_index(c, p.bitmap_lg);
+    const uint32_t w = __hip_atomic_load(&p.bitmap[at >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((w >> (at & 31)) & 1u) {
         const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
         if (idx < p.hits_cap) {
             st_shared<true>(&p.hits[idx], e);
@@ -736,7 +737,19 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
         if (tid < 168) fs.bits[tid] = p.tables[kTabBitsOff + tid];
         // an icao_flush retired a bitmap: every workgroup clears its share (k_records does it for the
         // passes of three launches)
-        if (p.clean_bitmap) bitmap_clear(p.clean_bitmap, blockIdx.x * kThreads + tid, gridDim.x * kThreads);
+        if (p.clean_bitmap) bitmap_clear(p.clean_bitmap, p.bitmap_lg, blockIdx.x * kThreads + tid, gridDim.x * kThreads);
+        // ... or (a context for passes of a few buffers: folded bitmaps) the pass starts on the NEXT bitmap of the
+        // rotation and clears it itself: the first workgroup does -- 64 KB written through, acknowledged, then the
+        // flag -- and every other one checks the flag behind its first tile's loads, long before it first sets or
+        // tests a bit (bitmap_wait below).  Nobody else is using that bitmap: there is one more than passes in flight.
+        if (p.bitmap_fresh && blockIdx.x == 0) {
+            const uint32_t words = bitmap_alloc_words(p.bitmap_lg), bits = bitmap_words(p.bitmap_lg);
+            for (uint32_t v = (uint32_t)tid; v < words; v += kThreads)
+                st_shared<true>(&p.bitmap[v], (v == 0u || v == bits) ? 1u : 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) st_shared<true>(&p.ctr->bitmap_ready, 1u);
+        }
     }
 
     // ---------------------------------------------------------------- P0 once per workgroup
@@ -850,6 +863,21 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
     }
     if (t + t_stride < t_end) load_tile_iq<FROM_MAG>(p, tile_ref<FROM_MAG>(p, t + t_stride), tid, pre);
     ACCT(0);
+    if constexpr (FUSED) {
+        // (bitmap_wait) behind an icao_flush the first workgroup clears the pass's bitmap: it has, by the time this
+        // workgroup's first tile has arrived -- one look, bounded like the other waits of a one-launch pass (a first
+        // workgroup that has not been given a CU yet: the pass is reported as overflowed and redone)
+        if (p.bitmap_fresh && iter == 0 && blockIdx.x != 0 && tid == 0) {
+            uint32_t polls = 0;
+            while (ld_shared<true>(&p.ctr->bitmap_ready) == 0u) {
+                if (++polls > 20000u) {
+                    atomicOr(&p.ctr->overflow, 64u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
     lds_barrier();
     // every thread is past the previous tile's epilogue: its counters can be zeroed for the next
     // tile (this tile counts in the other copy), so the tile needs no barrier at its end
@@ -1195,7 +1223,8 @@ tile_end:
                 uint32_t c = entry_value(e);
                 if (code >= 5u && code < 10u) c = gf_apply(fs.x56, c);
                 // (agent scope: bits other workgroups of this launch have set, not a line this CU's cache holds)
-                const bool hit = code != 15u && ((ld_shared<true>(&p.bitmap[c >> 5]) >> (c & 31u)) & 1u) != 0u;
+                const uint32_t at = bitmap_index(c, p.bitmap_lg);
+                const bool hit = code != 15u && ((ld_shared<true>(&p.bitmap[at >> 5]) >> (at & 31u)) & 1u) != 0u;
                 const unsigned long long mm = __ballot(hit);
                 if (mm) {
                     const uint32_t cs = hit ? (uint32_t)((int)entry_j(e) - slot0) : (uint32_t)kPad;

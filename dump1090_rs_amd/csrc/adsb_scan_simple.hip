@@ -97,7 +97,7 @@ __device__ __forceinline__ void scan_simple_tile(const ScanParams &p, uint32_t c
                     if ((c & 0xFFFF80u) == 0) {
                         is_hit = true;
                         entry = pack_entry(c, code, j, chunk);
-                        if ((c & 0x7Fu) == 0) bitmap_set(p.bitmap, addr);  // the replay adds it
+                        if ((c & 0x7Fu) == 0) bitmap_set(p.bitmap, p.bitmap_lg, addr);  // the replay adds it
                     }
                 } else if (df == 17 || df == 18) {  // :91-109
                     const uint32_t c = modes_checksum(w, 14, scrc);
@@ -105,7 +105,7 @@ __device__ __forceinline__ void scan_simple_tile(const ScanParams &p, uint32_t c
                         is_hit = true;
                         entry = pack_entry(c, code, j, chunk);
                         // DF18 adds addr | 1<<25, which no 24-bit test can match
-                        if (df == 17) bitmap_set(p.bitmap, addr);
+                        if (df == 17) bitmap_set(p.bitmap, p.bitmap_lg, addr);
                     }
                 } else if (df == 0 || df == 4 || df == 5) {  // :56-72
                     is_ap = true;

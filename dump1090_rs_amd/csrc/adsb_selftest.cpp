@@ -34,6 +34,7 @@ int selftest_pass(adsb_ctx *c, const void *d_iq, size_t n_samples, std::vector<u
         p.n_samples = n_samples;
         p.n_chunks = (uint32_t)n_chunks;
         p.bitmap = c->d_bitmap[c->cur_bitmap];  // learned addresses only widen the superset
+        p.bitmap_lg = c->bitmap_lg;
         p.hits = sl.d_hits;
         p.hits_cap = sl.hits_cap;
         p.ap = sl.d_ap;

@@ -97,8 +97,13 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
     p.n_chunks = (uint32_t)n_chunks;
     p.clean_bitmap = nullptr;
     job.retired = nullptr;
+    bool fresh = false;
+    p.bitmap_lg = c->bitmap_lg;
     if (c->flush_pending) {
-        job.retired = c->d_bitmap[c->cur_bitmap];
+        // (full bitmaps: the retired one is cleaned by the second phase's records kernel; folded ones: the next one
+        // is cleared in front of this shard's scan -- enqueue_pass has the argument)
+        if (c->bitmap_lg == kFullBitmapLg) job.retired = c->d_bitmap[c->cur_bitmap];
+        else fresh = true;
         c->cur_bitmap = (c->cur_bitmap + 1) % c->n_bitmaps;
         c->filter.flush();
         c->flush_pending = false;
@@ -130,7 +135,13 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
     job.scan_q = nullptr;
     job.waiting = false;
     job.active = true;
-    if (!n_chunks) return ADSB_OK;   // (an empty shard: nothing to wait for, nothing learned)
+    if (!n_chunks) {   // (an empty shard: nothing to wait for, nothing learned)
+        if (fresh) {
+            if (int e = launch_reset(sl.d_ctr, p.bitmap, p.bitmap_lg, c->tail_stream)) return fail(c, (hipError_t)e, "launch_reset");
+            HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+        }
+        return ADSB_OK;
+    }
     // consecutive shards' scans alternate between the first two scan streams, like consecutive passes
     hipStream_t ss = c->scan_stream[c->shard_jobs++ % 2];
     job.scan_q = ss;
@@ -151,6 +162,8 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
     // (the slot's previous shard: its second phase ran on the tail stream, and its summary reached the host a
     // moment before that launch retired -- it was still zeroing the counters this scan is about to fill)
     if (job.ran) HIP_TRY(c, hipStreamWaitEvent(ss, sl.recorded, 0));
+    if (fresh)
+        if (int e = launch_reset(sl.d_ctr, p.bitmap, p.bitmap_lg, ss)) return fail(c, (hipError_t)e, "launch_reset");
     if (int e = launch_scan(p, false, ss)) return fail(c, (hipError_t)e, "launch_scan");
     if (int e = launch_records(p, false, sl.h_rec_dev, ss)) return fail(c, (hipError_t)e, "launch_records");
     HIP_TRY(c, hipEventRecord(sl.scanned, ss));   // (the second phase, on the tail stream, orders itself behind this launch)
@@ -235,7 +248,7 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
     // when the shard has been collected)
     if (n_extra && n_extra <= kShardAddrCap) {
         std::memcpy(job.h_addrs, extra, n_extra * sizeof(uint32_t));
-        if (int e = launch_set_addresses(job.h_addrs_dev, (uint32_t)n_extra, p.bitmap, ts))
+        if (int e = launch_set_addresses(job.h_addrs_dev, (uint32_t)n_extra, p.bitmap, p.bitmap_lg, ts))
             return fail(c, (hipError_t)e, "launch_set_addresses");
     } else if (n_extra) {
         // (more than a capture can teach: a caller's own union through adsb_shard_finish -- a device buffer, blocking)
@@ -248,13 +261,13 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
         }
         HIP_TRY(c, hipStreamSynchronize(ts));   // (d_addrs may still be read by an earlier shard's launch)
         HIP_TRY(c, hipMemcpy(c->d_addrs, extra, n_extra * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, ts))
+        if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, p.bitmap_lg, ts))
             return fail(c, (hipError_t)e, "launch_set_addresses");
     }
     if (!p.n_chunks) {
         // an empty shard has no records kernel to clean the bitmap a flush retired
         if (job.retired)
-            if (int e = launch_reset(sl.d_ctr, job.retired, ts)) return fail(c, (hipError_t)e, "launch_reset");
+            if (int e = launch_reset(sl.d_ctr, job.retired, p.bitmap_lg, ts)) return fail(c, (hipError_t)e, "launch_reset");
         if (n_extra || job.retired) HIP_TRY(c, hipStreamSynchronize(ts));   // (h_addrs is free again; nothing else to wait for)
         return ADSB_OK;
     }

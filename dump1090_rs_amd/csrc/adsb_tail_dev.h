@@ -142,7 +142,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
     // bitmap, clear it here (address 0 always tests true, src/icao_filter.rs:71-80: bit 0
     // starts set); it comes back into use two flushes later.  This pass's own counters are
     // zeroed at the very end, by the last block to finish.
-    if (clean && p.clean_bitmap) bitmap_clear(p.clean_bitmap, bid * blockDim.x + threadIdx.x, nblk * blockDim.x);
+    if (clean && p.clean_bitmap) bitmap_clear(p.clean_bitmap, p.bitmap_lg, bid * blockDim.x + threadIdx.x, nblk * blockDim.x);
     // A block owns a contiguous run of hits, so its records leave as one contiguous burst of
     // 16-byte stores (mapped host memory sits behind PCIe: thousands of separate 8-byte writes
     // cost ~6 ns each, wide neighbouring ones combine).  Per hit, a wave: the window of
