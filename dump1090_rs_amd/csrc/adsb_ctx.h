@@ -153,6 +153,13 @@ struct adsb_ctx {
     bool prev_fused = false;                // ... as part of the scan's own launch (no event behind it: prev_scanned is stale)
     hipEvent_t lazy_ev = nullptr;           // recorded on a stream at the moment somebody has to wait for a one-launch pass on it
     uint64_t last_new_insert_seq = 0;       // the latest pass whose replay put a NEW address into the filter
+    // folded bitmaps (contexts for passes of a few buffers): the pass behind the latest icao_flush clears the next
+    // bitmap itself when it starts; a pass submitted after it shares that bitmap, so while the flushed pass is still
+    // in flight on ANOTHER stream the later one is ordered behind it (it must not set a bit the clear then wipes).
+    // epoch_first_seq: that pass's number -- what older passes teach the filter is no business of this epoch's.
+    hipStream_t fresh_q = nullptr;
+    uint64_t fresh_seq = 0, epoch_first_seq = 0;
+    int fresh_slot = -1;
     uint64_t rematches = 0;                 // one-launch passes redone because a pass in flight beside them did
     uint32_t order_polls = 200;             // ScanParams::order_polls (adsb_selftest_set_order_polls)
     const unsigned long long *next_src_ready = nullptr;  // ScanParams::src_ready of the next pass enqueued (adsb_demod_iq)

@@ -256,6 +256,22 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
     //     a three-launch pass that needs one of them behind it records an event on that stream now; a
     //     one-launch pass notes from which pass on its match is unsynchronised (Slot::unsynced_from) and
     //     the host redoes it if one of those turns out to have taught the filter a new address.
+    bool behind_fresh = false;   // this launch has been ordered behind the pass that opened the epoch
+    if (c->bitmap_lg != kFullBitmapLg) {
+        const long my_slot = &sl - c->slot;
+        if (p.bitmap_fresh) {   // this pass opens the filter's next epoch and clears its bitmap
+            c->fresh_q = ss;
+            c->fresh_seq = c->epoch_first_seq = sl.scan_seq;
+            c->fresh_slot = my_slot >= 0 && my_slot < kSlots ? (int)my_slot : -1;
+        } else if (c->fresh_q && c->fresh_q != ss && c->fresh_slot >= 0 && c->fresh_slot != my_slot) {
+            const Slot &f = c->slot[c->fresh_slot];
+            if (f.busy && f.scan_seq == c->fresh_seq) {   // still in flight: behind it (rare: the first passes after a flush)
+                HIP_TRY(c, hipEventRecord(c->lazy_ev, c->fresh_q));
+                HIP_TRY(c, hipStreamWaitEvent(ss, c->lazy_ev, 0));
+                behind_fresh = true;
+            }
+        }
+    }
     if (fused) {
         HT(c, HT_EV_SCANNED);
         if (p.clean_bitmap)
@@ -269,8 +285,12 @@ int enqueue_pass(adsb_ctx *c, Slot &sl, const void *d_src, bool from_mag, uint64
         }
         // (every pass in flight whose scan is not in stream order before this launch: not on this stream, and not
         // on the stream of the three-launch pass just waited for -- that wait covers what ran on ITS stream only)
+        // (... and that belongs to the filter's current epoch: what a pass from before the latest icao_flush taught
+        // the filter is gone when this pass is replayed -- with a flush before every pass, the reference's benchmark
+        // shape, every pass used to be redone because its predecessor had "taught a new address")
         for (Slot &other : c->slot)
-            if (&other != &sl && other.busy && other.scan_q != ss && !(other_stream_synced && other.scan_q == c->prev_scan_stream))
+            if (&other != &sl && other.busy && other.scan_q != ss && other.scan_seq >= c->epoch_first_seq &&
+                !(other_stream_synced && other.scan_q == c->prev_scan_stream) && !(behind_fresh && other.scan_seq == c->fresh_seq))
                 sl.unsynced_from = sl.unsynced_from ? std::min(sl.unsynced_from, other.scan_seq) : other.scan_seq;
     }
     sl.scan_q = ss;

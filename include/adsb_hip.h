@@ -105,14 +105,16 @@ typedef struct {
  * demodulation, dump1090_rs/src/main.rs:161-167): each of its passes is a single kernel launch, and it
  * keeps ADSB_MAX_IN_FLIGHT_SMALL (8) of them in flight instead of ADSB_MAX_IN_FLIGHT (4).
  * Footprint (each pass in flight has its own lists):
- *   device   2 MiB address bitmaps (passes in flight + 1 in rotation for the superset test, two for the
- *            device-side copy of the filter), plus per pass in flight the address/parity list, the hit
- *            list with the scan's bit fields per hit, and the scoring buffers: ~1.25 MB each for
- *            max_chunks = 1 (~33 MB in all, 23 of them bitmaps), ~101 MB each for 512 (~420 MB in all);
- *   pinned host (mapped, written by the kernels)  per pass in flight 32 B per trial record
- *            (4096 + 1024 max_chunks of them) + 44 B per scored message slot (min(that, 131072)):
- *            ~3 MB in all for max_chunks = 1, ~90 MB for 512; host-pointer calls of a few buffers add a
- *            pinned staging buffer of their size.
+ *   device   the address supersets the match tests against, one more than passes in flight in rotation: 2 MiB each
+ *            (bit a = address a) in a large context, plus two for the device-side copy of the filter; 64 KB each
+ *            (2^19 bits, address folded: a superset is all the match needs) in a context created with
+ *            max_chunks <= 16, which never scores on the device.  Per pass in flight the address/parity list, the
+ *            hit list with the scan's bit fields per hit, and (large contexts) the scoring buffers: ~0.8 MB each for
+ *            max_chunks = 1 (~7 MB in all, 0.6 of them bitmaps), ~101 MB each for 512 (~420 MB in all);
+ *   pinned host (mapped, written by the kernels; one allocation per context)  per pass in flight 32 B per trial
+ *            record (4096 + 1024 max_chunks of them) + in large contexts 44 B per scored message slot
+ *            (min(that, 131072)): ~1.3 MB in all for max_chunks = 1, ~90 MB for 512; host-pointer calls of a few
+ *            buffers add a pinned staging buffer of their size, the ring its slots.
  * Input denser than the lists are sized for (several times a busy airspace) is still
  * demodulated exactly, buffer by buffer through worst-case lists allocated on first use
  * (another 10 MB of device and 20 MB of pinned memory; stats.retries). */
@@ -131,8 +133,11 @@ int adsb_set_stream(adsb_ctx *ctx, void *hip_stream);
  * stream several microseconds, so level 2 slows a call down noticeably). */
 int adsb_set_profiling(adsb_ctx *ctx, int level);
 
-/* == icao_filter::icao_flush() (src/icao_filter.rs:11-17) for this context.  Stream-ordered:
- * costs nothing until the next demod call, whose first kernel clears the device side. */
+/* == icao_filter::icao_flush() (src/icao_filter.rs:11-17) for this context.  Stream-ordered: costs nothing by
+ * itself; the next pass starts on the next address superset of the rotation (a large context's is clean already,
+ * a context for passes of a few buffers has that pass clear its 64 KB when it starts) and waits for no pass in
+ * flight -- a flush before every pipelined call, the reference's benchmark shape (benches/demod_benchmark.rs:9),
+ * costs the same as none. */
 int adsb_icao_flush(adsb_ctx *ctx);
 
 /* == utils::to_mag (src/utils.rs:43-58).  iq_re_im is the in-memory

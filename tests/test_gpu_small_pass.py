@@ -314,3 +314,100 @@ def test_samples_in_a_registered_host_buffer_are_read_in_place(hip_lib, oracle_m
         orc.icao_flush()
         c.icao_flush()
         assert [key(m) for m in c.demod_iq(big[:n])] == [want_key(w) for w in orc.demod_iq(big[:n])[0]]
+
+
+@pytest.mark.parametrize("depth", [1, 2, 8])
+def test_icao_flush_before_every_pipelined_pass_is_exact_and_redoes_nothing(hip_lib, oracle_mod, depth):
+    """The reference's benchmark shape (benches/demod_benchmark.rs:9-11: icao_flush, then one buffer) pipelined:
+    every pass opens a new epoch of the filter on the next (folded) bitmap of the rotation and clears it itself, waits
+    for no other pass, and no pass is redone for what a pass from BEFORE its flush taught the filter.  200 passes
+    over 12 distinct buffers that all teach the same aircraft; each equal to the oracle behind a flush."""
+    import torch
+    from dump1090_rs_amd import Context
+    bufs = [synth.make_iq(CHUNK - (977 if k == 5 else 0), n_bursts=14, seed=31000 + k, n_icao=4, df11_every=3) for k in range(12)]
+    wants = []
+    for b in bufs:
+        orc = oracle_mod.Oracle()
+        wants.append([want_key(w) for w in orc.demod_iq(b)[0]])
+    assert all(len(w) >= 8 for w in wants)
+    devs = [torch.from_numpy(b).cuda() for b in bufs]
+    torch.cuda.synchronize()
+    with Context(0, 1) as c:
+        got, sub = [], 0
+        for i in range(200):
+            if c.pending() == depth:
+                got.append([key(m) for m in c.collect()])
+            c.icao_flush()
+            c.submit_iq_device(devs[i % 12].data_ptr(), len(bufs[i % 12]))
+            sub += 1
+        while c.pending():
+            got.append([key(m) for m in c.collect()])
+        assert len(got) == 200
+        for i, g in enumerate(got):
+            assert g == wants[i % 12], f"pass {i}"
+        assert rematches(c) == 0
+        # the ring the same way (slots read in place)
+        c.ring_create(CHUNK)
+        got = []
+        for i in range(64):
+            if c.pending() == depth:
+                got.append([key(m) for m in c.collect()])
+            c.icao_flush()
+            buf = c.ring_acquire()
+            buf[: len(bufs[i % 12])] = bufs[i % 12]
+            c.ring_submit(len(bufs[i % 12]))
+        while c.pending():
+            got.append([key(m) for m in c.collect()])
+        for i, g in enumerate(got):
+            assert g == wants[i % 12], f"ring pass {i}"
+        assert rematches(c) == 0
+
+
+@pytest.mark.parametrize("depth", [2, 4, 8])
+def test_passes_right_behind_a_flush_share_the_bitmap_the_flushed_pass_clears(hip_lib, oracle_mod, depth):
+    """icao_flush, then a pass that teaches an address, then -- launched while that one is still in flight, on other
+    streams -- passes with address/parity frames for it, for an address from BEFORE the flush (must not decode any
+    more) and one that teaches another address a later pass needs: the passes behind the flush share the bitmap the
+    flushed pass clears when it starts, so they are ordered behind it; against one oracle stream, over and over."""
+    import torch
+    from dump1090_rs_amd import Context
+    old, a, b = 0x3C6589, 0x4840D6, 0x7C1B2A
+    df4 = lambda icao, k: ap_frame(bytes([0x20, 0x00, 0x05, 0x30 + k]), icao)
+    at = lambda j, ph: 5 * j + ph
+    bufs = []
+    for k in range(6):
+        iq = synth.make_iq(CHUNK, n_bursts=6, seed=32000 + k, n_icao=3)
+        if k == 0:      # the pass behind the flush: teaches a (late in the buffer), holds a frame for `old`
+            synth.add_bursts(iq, [synth.Burst(at(120000, 2), 22000, 1, synth.df17_frame(a, 3)), synth.Burst(at(4000, 1), 22000, 2, df4(old, 0))])
+        if k == 1:      # needs a; teaches b
+            synth.add_bursts(iq, [synth.Burst(at(3000, 3), 22000, 3, df4(a, 1)), synth.Burst(at(90000, 0), 22000, 4, synth.df11_frame(b))])
+        if k == 2:      # needs a and b, and `old` again
+            synth.add_bursts(iq, [synth.Burst(at(2700, 1), 22000, 5, df4(a, 2)), synth.Burst(at(5000, 4), 22000, 6, df4(b, 2)),
+                                  synth.Burst(at(60000, 2), 22000, 7, df4(old, 2))])
+        if k == 5:      # teaches `old` again for the next round's first frames (which come after a flush: must not count)
+            synth.add_bursts(iq, [synth.Burst(at(30000, 3), 22000, 8, synth.df17_frame(old, 9))])
+        bufs.append(iq)
+    orc = oracle_mod.Oracle()
+    wants = []
+    for rnd in range(8):
+        for k, iq in enumerate(bufs):
+            if k == 0:
+                orc.icao_flush()
+            wants.append([want_key(w) for w in orc.demod_iq(iq)[0]])
+    frames_of = lambda ws, f: sum(1 for w in ws if bytes(w[4][:7]) == f)
+    assert frames_of(wants[6 + 1], df4(a, 1)) >= 1 and frames_of(wants[6 + 2], df4(b, 2)) >= 1
+    assert frames_of(wants[6 + 0], df4(old, 0)) == 0 and frames_of(wants[6 + 2], df4(old, 2)) == 0   # flushed away
+    devs = [torch.from_numpy(x).cuda() for x in bufs]
+    torch.cuda.synchronize()
+    with Context(0, 1) as c:
+        got = []
+        for i in range(len(wants)):
+            if c.pending() == depth:
+                got.append([key(m) for m in c.collect()])
+            if i % 6 == 0:
+                c.icao_flush()
+            c.submit_iq_device(devs[i % 6].data_ptr(), CHUNK)
+        while c.pending():
+            got.append([key(m) for m in c.collect()])
+        for i, (g, w) in enumerate(zip(got, wants)):
+            assert g == w, f"pass {i}"
