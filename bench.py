@@ -192,7 +192,10 @@ class Env:
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         self.dist = None
-        if self.world > 1:
+        # (ADSB_BENCH_FORCE_DIST=1: a single rank still joins a process group and every fence / reduction below goes
+        # through the backend's collectives -- how the RCCL path of this file is exercised on a one-GPU box,
+        # tests/test_gpu_multidevice.py)
+        if self.world > 1 or os.environ.get("ADSB_BENCH_FORCE_DIST"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
@@ -525,7 +528,7 @@ def resident_result(env: Env, args, r, workload: str):
         "frames_per_s": round(frames / elapsed, 1),
         "frames_per_step": frames // max(1, steps * env.world),
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
-        "backend": env.backend if env.world > 1 else None,
+        "backend": env.backend if env.dist is not None else None,
         "world_size_seen": env.world,
         "config": {
             "workload": f"{args.chunks} x 131072-sample buffers = {n * 4 // (1 << 20)} MiB synthetic 2.4 MSPS "
@@ -897,7 +900,7 @@ def run_shard(env: Env, args):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "ms_per_step_two_blocking_phases": round(env.reduce(blocking_ms / 1e3, 0)[0] * 1e3, 4),
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
-        "backend": env.backend if env.world > 1 else None, "world_size_seen": env.world,
+        "backend": env.backend if env.dist is not None else None, "world_size_seen": env.world,
         # the capture is the same whatever N is: total work fixed, per-GPU work = 1 / N of it
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "frames_per_s": round(frames / elapsed, 1),
