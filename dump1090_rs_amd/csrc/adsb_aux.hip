@@ -4,6 +4,7 @@
 
 #include "../../include/adsb_hip.h"
 #include "adsb_dev_common.h"
+#include "adsb_scan_geometry.h"
 #include "adsb_tail_dev.h"
 
 namespace adsb {
@@ -121,13 +122,14 @@ __global__ __launch_bounds__(256) void k_match(ScanParams p)
             const uint32_t at = bitmap_index(c[k], p.bitmap_lg);
             if ((p.bitmap[at >> 5] >> (at & 31)) & 1u) {  // rare: one atomic each
                 const uint32_t idx = atomicAdd(&p.ctr->n_hits, 1u);
-                if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
-                    const uint32_t ch = (uint32_t)entry_chunk(e[k]);
-                    const uint32_t at = atomicAdd(&p.order_cnt[ch], 1u);
-                    if (at < kOrderBucket) {
-                        p.order_tmp[(size_t)ch * kOrderBucket + at] = e[k];
+                if (p.order_cnt) {  // dense stream: into the buffer's bucket, its tile's part of it (adsb_device.h: order_tmp)
+                    const uint32_t ch = (uint32_t)entry_chunk(e[k]), tl = entry_j(e[k]) / (uint32_t)fastgeo::kTile;
+                    const uint32_t at = atomicAdd(&p.order_cnt[ch * fastgeo::kTilesPerChunk + tl], 1u);
+                    if (at < kTileBucket) {
+                        const size_t place = (size_t)ch * kOrderBucket + tl * kTileBucket + at;
+                        p.order_tmp[place] = e[k];
                         // (an address/parity hit: no fields from the scan, the record builder slices it)
-                        if (p.hit_fields) p.hit_fields[((size_t)ch * kOrderBucket + at) * kHitFieldWords + 5] = 0u;
+                        if (p.hit_fields) p.hit_fields[place * kHitFieldWords + 5] = 0u;
                     } else {
                         atomicOr(&p.ctr->overflow, 1u);
                     }
@@ -162,15 +164,19 @@ __global__ __launch_bounds__(1024) void k_order_prefix(ScanParams p)
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
     const uint32_t tid = threadIdx.x;
+    constexpr uint32_t T = fastgeo::kTilesPerChunk;
     if (p.ctr->overflow) {  // (uniform) nothing will be ordered: leave the counts clean
-        for (uint32_t c = tid; c <= p.n_chunks; c += 1024) p.order_cnt[c] = 0;
+        for (uint32_t c = tid; c < p.n_chunks * T; c += 1024) p.order_cnt[c] = 0;
         return;
     }
     if (tid == 0) carry = 0;
     __syncthreads();
     for (uint32_t c0 = 0; c0 <= p.n_chunks; c0 += 1024) {
         const uint32_t c = c0 + tid;
-        const uint32_t v = c < p.n_chunks ? p.order_cnt[c] : 0u;
+        uint32_t v = 0;   // the buffer's hits = its tiles' counts (adsb_device.h: kTileBucket)
+        if (c < p.n_chunks)
+#pragma unroll
+            for (uint32_t t = 0; t < T; t++) v += min(p.order_cnt[c * T + t], kTileBucket);
         part[tid] = v;
         __syncthreads();
         for (uint32_t off = 1; off < 1024; off <<= 1) {

@@ -177,8 +177,8 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             HIP_TRY(c, hipMalloc((void **)&sl.d_hits, (size_t)c->hits_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_hit_fields, (size_t)c->hits_cap * kHitFieldWords * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_ap, (size_t)c->ap_cap * sizeof(uint64_t)));
-            HIP_TRY(c, hipMalloc((void **)&sl.d_order_cnt, (max_chunks + 1) * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemset(sl.d_order_cnt, 0, (max_chunks + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&sl.d_order_cnt, (max_chunks * fastgeo::kTilesPerChunk + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(sl.d_order_cnt, 0, (max_chunks * fastgeo::kTilesPerChunk + 1) * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_order_base, (max_chunks + 1) * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc((void **)&sl.d_order_tmp, (size_t)c->hits_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipEventCreateWithFlags(&sl.scanned, hipEventDisableTiming | hipEventDisableSystemFence));

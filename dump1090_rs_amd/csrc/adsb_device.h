@@ -217,11 +217,11 @@ struct ScanParams {
     // previous call), or from src[-kCarrySamples..] when lead_from_src is set.
     const uint32_t *carry;
     uint32_t lead_from_src;
-    // device-side ordering of the hit list (k_order_prefix / k_order_buckets; null: the host sorts).
-    // Whoever finds a hit puts it straight into its buffer's bucket -- order_tmp[chunk * kOrderBucket +
-    // order_cnt[chunk]++] -- and the hit list proper is written by k_order_buckets, each bucket sorted,
-    // at the buckets' exclusive prefix (order_base).  order_cnt / order_base: n_chunks + 1 entries,
-    // the counts all zero between passes; order_tmp: hits_cap >= n_chunks * kOrderBucket entries.
+    // device-side ordering of the hit list (k_order_prefix / k_records; null: the host sorts).
+    // Whoever finds a hit puts it straight into its buffer's bucket, in the sub-bucket of its tile --
+    // order_tmp[chunk * kOrderBucket + tile * kTileBucket + place] -- and the hit list proper is written by k_records,
+    // each buffer's bucket sorted, at the buckets' exclusive prefix (order_base, one per buffer).  order_cnt: one count
+    // per TILE (17 n_chunks), all zero between passes; order_base: n_chunks + 1; order_tmp: n_chunks * kOrderBucket.
     uint32_t *order_cnt, *order_base;
     uint64_t *order_tmp;
     // self-test only (adsb_selftest_stage_lists): every position that passes the gates is also
@@ -271,6 +271,11 @@ __host__ __device__ inline uint32_t bitmap_index(uint32_t a, uint32_t lg)
 // hits one buffer's bucket holds on a dense stream (device-side ordering): ~20x a busy airspace;
 // a fuller one is an overflow like any other list's (the pass is redone buffer by buffer)
 constexpr uint32_t kOrderBucket = 1024;
+// ... cut into one sub-bucket per tile of the buffer (17 of them): a tile has ONE writer in the scan, so its staged
+// hits go to places 0 .. n-1 of its sub-bucket and its count is a plain store -- no returning atomic, no wait, no
+// barrier at the end of a tile (round 5: the two dependent atomics there, behind an s_waitcnt that also covered the
+// next tile's prefetch, were the dense stream's 13 us; profiles/r5_dense_acct.txt).  order_cnt has one count per tile.
+constexpr uint32_t kTileBucket = 60;
 constexpr int kCarrySamples = 328;  // kLead rounded up to whole 16-byte loads
 
 // launches; all asynchronous on `stream`, return a hipError_t as int

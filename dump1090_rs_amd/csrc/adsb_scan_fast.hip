@@ -441,12 +441,13 @@ __device__ __forceinline__ void stage_hit(const ScanParams &p, FastLds &s, HitFi
             }
         } else {  // more hits in one tile than the staging holds: one by one
             const uint32_t gi = atomicAdd(&p.ctr->n_hits, 1u);
-            if (p.order_cnt) {  // dense stream: into the buffer's bucket (adsb_device.h: order_tmp)
-                const uint32_t c = (uint32_t)entry_chunk(entry);
-                const uint32_t k = atomicAdd(&p.order_cnt[c], 1u);
-                if (k < kOrderBucket) {
-                    p.order_tmp[(size_t)c * kOrderBucket + k] = entry;
-                    if constexpr (FIELDS) put_hit_fields<FUSED>(p, (size_t)c * kOrderBucket + k, f);
+            if (p.order_cnt) {  // dense stream: into the buffer's bucket, its tile's part of it (adsb_device.h: order_tmp)
+                const uint32_t c = (uint32_t)entry_chunk(entry), tl = entry_j(entry) / (uint32_t)kTile;
+                const uint32_t k = atomicAdd(&p.order_cnt[c * kTilesPerChunk + tl], 1u);
+                if (k < kTileBucket) {
+                    const size_t at = (size_t)c * kOrderBucket + tl * kTileBucket + k;
+                    p.order_tmp[at] = entry;
+                    if constexpr (FIELDS) put_hit_fields<FUSED>(p, at, f);
                 } else {
                     atomicOr(&p.ctr->overflow, 1u);
                 }
@@ -1143,22 +1144,37 @@ tile_end:
             emit_record(p, s, ff, (uint32_t)((int)entry_j(me) - (jbase - kPad)), me, entry_value(me), lane);
         }
     } else
-    if (nhit) {  // rare: a handful per chunk
-        // (a tile's hits share its buffer: on a dense stream they go into that buffer's bucket)
-        uint64_t *const dst = p.order_cnt ? p.order_tmp + (size_t)chunk * kOrderBucket : p.hits;
-        const uint32_t dst_cap = p.order_cnt ? kOrderBucket : p.hits_cap;
-        if (tid == 0) {
-            const uint32_t at = atomicAdd(&p.ctr->n_hits, nhit);
-            s.hit_base = p.order_cnt ? atomicAdd(&p.order_cnt[chunk], nhit) : at;
+    if (nhit) {  // sparse streams: a handful per buffer; dense ones: most tiles
+        // Dense stream: the hits of a tile go into the tile's own part of its buffer's bucket.  This workgroup is that
+        // part's only writer during the scan, so unless the staging overflowed (more than kHitCap hits in one tile:
+        // the rest went in one by one, stage_hit) they take places 0 .. nhit - 1 and the count is a plain store:
+        // nothing to wait for, no barrier.  Sparse stream (one flat list): a place from the list's counter.
+        const bool dense = p.order_cnt != nullptr;
+        const uint32_t tile_g = chunk * (uint32_t)kTilesPerChunk + (uint32_t)cur.tile;
+        const bool alone = dense && s.nhit[par] <= (uint32_t)kHitCap;   // (uniform)
+        uint64_t *const dst = dense ? p.order_tmp + (size_t)chunk * kOrderBucket + (size_t)cur.tile * kTileBucket : p.hits;
+        const uint32_t dst_cap = dense ? kTileBucket : p.hits_cap;
+        uint32_t hit_base = 0;
+        if (alone) {
+            if (tid == 0) {
+                atomicAdd(&p.ctr->n_hits, nhit);   // (no value taken: fire and forget)
+                p.order_cnt[tile_g] = nhit;
+            }
+        } else {
+            if (tid == 0) {
+                const uint32_t at = atomicAdd(&p.ctr->n_hits, nhit);
+                s.hit_base = dense ? atomicAdd(&p.order_cnt[tile_g], nhit) : at;
+            }
+            lds_barrier();
+            hit_base = s.hit_base;
         }
-        lds_barrier();
-        if (s.hit_base + nhit > dst_cap) {
+        if (hit_base + nhit > dst_cap) {
             if (tid == 0) atomicOr(&p.ctr->overflow, 1u);
         } else {
             for (uint32_t i = tid; i < nhit; i += kThreads) {
-                st_shared<FUSED>(&dst[s.hit_base + i], s.hit[i]);
+                st_shared<FUSED>(&dst[hit_base + i], s.hit[i]);
                 if constexpr (FIELDS)
-                    put_hit_fields<FUSED>(p, (size_t)(dst - (p.order_cnt ? p.order_tmp : p.hits)) + s.hit_base + i, hf.f[i]);
+                    put_hit_fields<FUSED>(p, (size_t)(dst - (dense ? p.order_tmp : p.hits)) + hit_base + i, hf.f[i]);
             }
         }
     }

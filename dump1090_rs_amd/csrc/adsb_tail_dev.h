@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/adsb_hip.h"
 #include "adsb_dev_common.h"
+#include "adsb_scan_geometry.h"
 
 namespace adsb {
 namespace {
@@ -175,26 +176,45 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
         if (overflowed || next_chunk >= p.n_chunks) break;
         const uint32_t c = next_chunk;
         next_chunk += nblk;
-        const uint32_t bn = min(p.order_cnt[c], kOrderBucket), lo = p.order_base[c];
+        // the buffer's bucket is seventeen sub-buckets, one per tile (adsb_device.h: kTileBucket): their counts, the
+        // places their entries take in the compacted bucket
+        constexpr uint32_t T = fastgeo::kTilesPerChunk;
+        static_assert(T * kTileBucket <= kOrderBucket && kOrderBucket % 256 == 0, "sub-buckets fit the bucket");
+        __shared__ uint32_t tcnt[T], tpre[T + 1];
+        const uint32_t lo = p.order_base[c];
         const uint64_t *bucket = p.order_tmp + (size_t)c * kOrderBucket;
-        __syncthreads();  // (the previous run is through with `sorted`, everyone has read this count)
-        if (threadIdx.x == 0) p.order_cnt[c] = 0;
+        __syncthreads();  // (the previous run is through with `sorted` and the counts)
+        if (threadIdx.x < T) tcnt[threadIdx.x] = min(p.order_cnt[c * T + threadIdx.x], kTileBucket);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t at = 0;
+            for (uint32_t t = 0; t < T; t++) {
+                tpre[t] = at;
+                at += tcnt[t];
+            }
+            tpre[T] = at;
+        }
+        if (threadIdx.x < T) p.order_cnt[c * T + threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t bn = tpre[T];
         uint64_t mine[kOrderBucket / 256];
         uint32_t rank[kOrderBucket / 256];
-        // (behind the sorted entries: where each one sat in the bucket -- its slot in ScanParams::hit_fields)
+        bool have[kOrderBucket / 256];
+        // (behind the sorted entries: where each one sits in the bucket -- its slot in ScanParams::hit_fields)
         uint16_t *const sorted_at = reinterpret_cast<uint16_t *>(sorted + kOrderBucket);
 #pragma unroll
         for (int k = 0; k < (int)kOrderBucket / 256; k++) {
-            const uint32_t i = threadIdx.x + 256u * k;
-            mine[k] = i < bn ? bucket[i] : 0ull;
-            if (i < bn) sorted[i] = mine[k];
+            const uint32_t sl = threadIdx.x + 256u * k;                 // place in the bucket: tile * kTileBucket + index
+            const uint32_t t = sl / kTileBucket, i = sl - t * kTileBucket;
+            have[k] = t < T && i < tcnt[t];
+            mine[k] = have[k] ? bucket[sl] : 0ull;
+            if (have[k]) sorted[tpre[t] + i] = mine[k];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < (int)kOrderBucket / 256; k++) {
-            const uint32_t i = threadIdx.x + 256u * k;
             rank[k] = 0;
-            if (i < bn) {
+            if (have[k]) {
                 const uint64_t key = order_key(mine[k]);
                 for (uint32_t q = 0; q < bn; q++) rank[k] += order_key(sorted[q]) < key;
             }
@@ -202,7 +222,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < (int)kOrderBucket / 256; k++)
-            if (threadIdx.x + 256u * k < bn) {
+            if (have[k]) {
                 sorted[rank[k]] = mine[k];
                 sorted_at[rank[k]] = (uint16_t)(threadIdx.x + 256u * k);
             }
