@@ -425,6 +425,27 @@ void adsb_destroy(adsb_ctx *c)
             std::fprintf(stderr, "phase accounting over %d waves (clock64 ticks per wave, share):\n", nw);
             for (int k = 0; k < 8; k++)
                 std::fprintf(stderr, "  %-9s %10.0f  %5.1f %%\n", name[k], sum[k] / (nw ? nw : 1), 100.0 * sum[k] / (all ? all : 1));
+            // ... and how evenly the work fell: a workgroup's total (its waves agree to a barrier wait) and its
+            // wave-private stage, over the workgroups -- the launch ends with the slowest one
+            std::vector<double> tot, late;
+            for (size_t w = 0; w + 3 < kTimelineWords / 8; w += 4) {
+                double t = 0, l = 0;
+                for (int k = 0; k < 8; k++) t += (double)tl[w * 8 + k];
+                for (size_t v = 0; v < 4; v++) l = std::max(l, (double)tl[(w + v) * 8 + 4]);
+                if (t == 0) continue;
+                tot.push_back(t);
+                late.push_back(l);
+            }
+            auto pct = [](std::vector<double> &v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(q * (double)(v.size() - 1))]; };
+            double mt = 0, ml = 0;
+            for (double v : tot) mt += v;
+            for (double v : late) ml += v;
+            mt /= tot.empty() ? 1 : (double)tot.size();
+            ml /= late.empty() ? 1 : (double)late.size();
+            std::fprintf(stderr, "  per workgroup (wave 0's total): mean %.0f  p50 %.0f  p99 %.0f  max %.0f  (max / mean %.3f)\n", mt, pct(tot, 0.5),
+                         pct(tot, 0.99), pct(tot, 1.0), mt > 0 ? pct(tot, 1.0) / mt : 0.0);
+            std::fprintf(stderr, "  per workgroup (its slowest wave's P3-5): mean %.0f  p50 %.0f  p99 %.0f  max %.0f  (max / mean %.3f)\n", ml,
+                         pct(late, 0.5), pct(late, 0.99), pct(late, 1.0), ml > 0 ? pct(late, 1.0) / ml : 0.0);
         }
         (void)hipFree(c->d_timeline);
     } else if (c->d_timeline) {

@@ -82,7 +82,7 @@ constexpr uint64_t kMaxChunks = 1ull << 19;  // per device pass (256 GiB of IQ)
 // shared counter: it is the slow path anyway.
 constexpr int kHitFieldWords = 8;  // ScanParams::hit_fields: f0..f4, flag, 2 spare
 constexpr int kNewAddrCap = 16;
-constexpr int kFusedMaxTiles = 16 * 17;  // the largest one-launch pass: 16 buffers of 17 tiles
+constexpr int kFusedMaxTiles = 16 * 18;  // the largest one-launch pass: 16 buffers of 17 tiles (18 with -DADSB_TILE=7284)
 constexpr int kApSegments = 1280;
 constexpr int kApWaveSegs = 4 * kApSegments;  // one per wave of a persistent workgroup
 
@@ -275,7 +275,7 @@ constexpr uint32_t kOrderBucket = 1024;
 // hits go to places 0 .. n-1 of its sub-bucket and its count is a plain store -- no returning atomic, no wait, no
 // barrier at the end of a tile (round 5: the two dependent atomics there, behind an s_waitcnt that also covered the
 // next tile's prefetch, were the dense stream's 13 us; profiles/r5_dense_acct.txt).  order_cnt has one count per tile.
-constexpr uint32_t kTileBucket = 60;
+constexpr uint32_t kTileBucket = 56;   // (x 18 tiles <= kOrderBucket, should the tile ever shrink: adsb_scan_geometry.h)
 constexpr int kCarrySamples = 328;  // kLead rounded up to whole 16-byte loads
 
 // launches; all asynchronous on `stream`, return a hipError_t as int

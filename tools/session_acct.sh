@@ -9,6 +9,6 @@ cp variants/lib_acct.so dump1090_rs_amd/libadsb_hip.so
 for w in sparse dense; do
   for mode in "--sync" ""; do
     echo "== $w ${mode:-pipelined}"
-    ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2 timeout 300 python bench.py --workload $w $mode --steps 12 --warmup 8 --blocks 0 --no-cpu-baseline --no-also 2>&1 >/dev/null | grep -A9 "phase accounting" | tail -10
+    ADSB_DEBUG_STOP=100 ADSB_TIMELINE=2 timeout 300 python bench.py --workload $w $mode --steps 12 --warmup 8 --blocks 0 --no-cpu-baseline --no-also 2>&1 >/dev/null | grep -A11 "phase accounting" | tail -12
   done
 done
