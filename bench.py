@@ -44,6 +44,7 @@ if str(ROOT) not in sys.path:
 
 CHUNK = 131072
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+HBM_ACHIEVABLE_GBS = 6290.0  # ... and what a float4 copy measures on the chip (79 % of it): the guide's "achievable"
 BYTES_PER_SAMPLE = 4   # algorithmic bytes: one i16 IQ pair read per sample
 PUBLISHED_CONFIG1_MS = 3.6950  # reference README.md:107, bench "01", Intel i7-7700K, 1 thread
 DTYPE = "i16 IQ -> f32 magnitude (exact) -> u16/i32 integer"
@@ -554,6 +555,8 @@ def resident_result(env: Env, args, r, workload: str):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+            "frac_of_achievable_is": f"achieved / {HBM_ACHIEVABLE_GBS:.0f} GB/s, the guide's measured float4-copy bandwidth (79 % of the spec peak)",
             "traffic": None,
             "kernel": "k_scan_fast",
             "kernel_avg_ms": round(kernel_ms, 4),
@@ -607,6 +610,18 @@ def resident_result(env: Env, args, r, workload: str):
             "is": v.get("is"), "wave_cycle_split": v.get("wave_cycle_split"),
             "source": "read from profiles/scan_sq_counters.json (rocprofv3 --pmc passes over `bench.py --sync` of this "
                       "library build, tools/sq_counters.py; not measured in this run)"}
+    # ... and the two floors of the kernel beside it: the memory floor of its access pattern (the kernel cut after P1: the
+    # whole HBM read, none of the later stages) and where its vector instructions go, stage by stage -- committed
+    # measurements of this library build (tools/session_ablate.sh, tools/stage_split.py), not taken in this run.
+    split = _profile_json("scan_stage_split.json", library, args.chunks)
+    if split:
+        result["roofline"]["memory_floor_ms"] = split["memory_floor_ms"]
+        result["roofline"]["memory_floor_is"] = (split["memory_floor_is"] + f"; frac of the HBM peak at that floor: "
+                                                 f"{round(algo / (split['memory_floor_ms'] / 1e3) / 1e9 / HBM_PEAK_GBS, 3)}")
+        result["roofline"]["valu_by_stage"] = {"per_launch": split["valu_wave_insts_per_launch"],
+                                               "stages": [{k: st[k] for k in ("stage", "valu_wave_insts", "per_wave_tile", "share")}
+                                                          for st in split["stages"]],
+                                               "source": "read from profiles/scan_stage_split.json (not measured in this run): " + split["source"]}
     return result
 
 

@@ -535,6 +535,6 @@ int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.18 gfx950 scan=v8-gate-reads tail=v6-records-in-place"; }
+const char *adsb_version(void) { return "adsb_hip 0.19 gfx950 scan=v9-tile-buckets tail=v7-folded-supersets multi=v1"; }
 
 }  // extern "C"

@@ -1073,6 +1073,11 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : kWavesPerSimd) ADSB_NO_UNALIG
                 wave_lds_fence();
                 in_round = true;
                 base = 0;
+                if (ADSB_STOP_AT(p, 6)) {  // profiling: patterns + compaction, no gates
+                    in_round = false;
+                    round++;
+                    continue;
+                }
             }
 
             // ------------------------------------------------------------ P4 value gates

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Per-phase instruction counts of k_scan_fast: SQ counters with the kernel cut short after
-# P1 / P2 / P3 / P4 / (all but the epilogue) / whole.  usage: tools/pmc_ablate.sh <outdir-name>
+# P1 / P2 / P3 patterns / + compaction (6) / P4 gates / (all but the epilogue) / whole.  Needs a -DADSB_TUNING library installed.  usage: tools/pmc_ablate.sh <outdir-name>
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }; N=$1; cd /tmp; export TMPDIR=/tmp
-for stop in 1 2 3 4 5 0; do
+for stop in 1 2 3 6 4 5 0; do
   export ADSB_DEBUG_STOP=$stop
   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $R/gpurun_out/$N/s$stop -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --buffers 2 > /dev/null 2>&1
   python3 - <<PY
