@@ -339,7 +339,7 @@ int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
 {
     if (!c || (!out && cap)) return ADSB_ERR_INVALID;
     if (c->submitted == c->delivered) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     std::vector<adsb_msg> msgs;
     int rc = collect_next(c, msgs);
     if (rc) return rc;

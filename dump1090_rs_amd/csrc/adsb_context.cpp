@@ -120,7 +120,11 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     // samples become address/parity entries).  Denser input falls back to buffer-by-buffer
     // passes through the reference-shaped kernel, whose list (dap) and the hit list hold one
     // buffer's worst case: every position sliced, five trials each.
-    (void)hipSetDevice(device);  // scan_resident_blocks() asks the current device
+    DeviceGuard on_device(device);  // (scan_resident_blocks() asks the current device; the caller's is put back on the way out)
+    if (on_device.err != hipSuccess) {
+        delete c;
+        return ADSB_ERR_NO_DEVICE;
+    }
     const uint64_t used_segs = 4 * std::min<uint64_t>((uint64_t)scan_resident_blocks(), max_chunks * (uint64_t)fastgeo::kTilesPerChunk);
     c->seg_cap = (uint32_t)std::max<uint64_t>(1024, (max_chunks * (uint64_t)kChunkSamples / 8 + used_segs - 1) / used_segs);
     c->ap_cap = (uint32_t)(used_segs * c->seg_cap);
@@ -316,7 +320,7 @@ void adsb_destroy(adsb_ctx *c)
                              1e6 * c->ht_s[k] / c->ht_n[k], 100.0 * c->ht_s[k] / (all > 0 ? all : 1));
     }
 #endif
-    (void)hipSetDevice(c->device);
+    DeviceGuard on_device(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto &pair : c->scan_ev)
         for (auto &e : pair)
@@ -500,7 +504,7 @@ int adsb_set_carry_over(adsb_ctx *c, int enabled)
 {
     if (!c) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     c->carry_over = enabled != 0;
     // the stream starts here: nothing precedes the next call
     for (int si = 0; si < c->n_slots; si++)
@@ -513,7 +517,6 @@ int adsb_set_carry_over(adsb_ctx *c, int enabled)
 int adsb_icao_flush(adsb_ctx *c)
 {
     if (!c) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
     // Takes effect for everything submitted after this call: the next pass's reset kernel
     // clears the device bitmap (stream-ordered), and the host filter is flushed when that
     // pass is collected, after the passes before it have been replayed.

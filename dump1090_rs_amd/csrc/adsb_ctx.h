@@ -284,6 +284,32 @@ inline int fail(adsb_ctx *c, hipError_t e, const char *what)
         if (e_ != hipSuccess) return ::adsb::host::fail((ctx), e_, #call); \
     } while (0)
 
+// Every entry point runs on its context's device and leaves the calling thread's current device as it found it: a
+// host with several GPUs (torch, or a Rust main loop that drives a context per device from one thread) must not find
+// its current device moved under it by a library call.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    bool restore = false;
+    explicit DeviceGuard(int want)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) {
+            err = hipSetDevice(want);
+            restore = err == hipSuccess && prev >= 0;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (restore) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ADSB_ON_DEVICE(ctx)                                    \
+    ::adsb::host::DeviceGuard dev_guard_((ctx)->device);       \
+    if (dev_guard_.err != hipSuccess) return ::adsb::host::fail((ctx), dev_guard_.err, "hipSetDevice")
+
 // Host seconds per kind of HIP call of a pass (tuning builds only; ADSB_HOST_TIMES=1 prints the table when the
 // context is destroyed: tools/hosttime.py).  `{ HT(c, HT_SCAN_LAUNCH); launch ...; }`
 enum HtKey { HT_RING_MEMCPY, HT_RING_EVENT, HT_IN_READY, HT_SCAN_LAUNCH, HT_EV_SCANNED, HT_MATCH_LAUNCH, HT_RECORDS_LAUNCH,

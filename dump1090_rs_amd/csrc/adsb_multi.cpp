@@ -465,7 +465,7 @@ void adsb_multi_destroy(adsb_multi *m)
     for (auto &d : m->dev)
         if (d->th.joinable()) d->th.join();
     for (auto &d : m->dev) {
-        (void)hipSetDevice(d->device);
+        DeviceGuard on_device(d->device);
         for (void *p : d->d_stage)
             if (p) (void)hipFree(p);
         adsb_destroy(d->ctx);

@@ -554,7 +554,7 @@ int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, si
 {
     if (!c || (!iq && n) || !data_out) return ADSB_ERR_INVALID;
     if (n > kChunkSamples) return ADSB_ERR_TOO_LONG;  // reference: index panic, lib.rs:48
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     // Through pinned, mapped memory both ways: one host copy in, the kernel reads the samples and writes
     // the 131398 magnitudes in place over the link, one host copy out -- instead of two copy commands
     // from / to pageable memory with their staging inside the runtime (62 -> ~36 us for the reference's
@@ -578,7 +578,7 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
 {
     if (!c || !data || (!out && cap)) return ADSB_ERR_INVALID;
     if (length > kChunkSamples) return ADSB_ERR_TOO_LONG;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     c->stats = adsb_stats{};
     c->stats.n_samples = length;
@@ -600,7 +600,7 @@ int adsb_demod_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples, adsb_m
 {
     if (!c || (!d_iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
     if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     std::vector<adsb_msg> msgs;
     int rc = demod_device(c, d_iq, n_samples, msgs);
     if (rc) return rc;
@@ -613,7 +613,7 @@ int adsb_submit_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples)
     if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
     if ((n_samples + kChunkSamples - 1) / kChunkSamples > std::min<uint64_t>(kMaxChunks, c->max_chunks))
         return ADSB_ERR_INVALID;  // more buffers than the context was created for
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     return submit(c, d_iq, false, n_samples);
 }
 
@@ -621,7 +621,7 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
                   size_t *n_out)
 {
     if (!c || (!iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     // stage through the device in pieces of at most max_chunks chunks
     std::vector<adsb_msg> msgs;
     adsb_stats total{};

@@ -14,7 +14,7 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
 {
     if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
     if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     auto body = [&]() -> int {
         // every slot's pinned buffer from ONE allocation, and every staging buffer from one (slot starts 4 KB aligned):
         // mapped and coherent -- slots of a few buffers are read in place by the pass itself
@@ -66,7 +66,7 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
 {
     if (!c || !c->ring_samples || n_samples == 0 || n_samples > c->ring_samples) return ADSB_ERR_INVALID;
     if (c->slot[c->submitted % (uint64_t)c->n_slots].busy || c->slot[c->submitted % (uint64_t)c->n_slots].parked) return ADSB_ERR_BUSY;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     auto &r = c->ring[c->submitted % (uint64_t)c->n_slots];
     const uint32_t n_chunks = (uint32_t)((n_samples + kChunkSamples - 1) / kChunkSamples);
     // Two ways for a slot to reach the pass (dump1090_rs/src/main.rs:161-167 reads and demodulates 131072
@@ -112,7 +112,7 @@ int adsb_host_register(adsb_ctx *c, void *host_ptr, size_t bytes)
     char *b = static_cast<char *>(host_ptr);
     for (const auto &r : c->host_ranges)
         if (b < r.base + r.bytes && r.base < b + bytes) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     HIP_TRY(c, hipHostRegister(host_ptr, bytes, hipHostRegisterMapped));
     void *dev = nullptr;
     if (hipError_t e = hipHostGetDevicePointer(&dev, host_ptr, 0); e != hipSuccess) {
@@ -133,7 +133,7 @@ int adsb_host_unregister(adsb_ctx *c, void *host_ptr)
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     for (size_t k = 0; k < c->host_ranges.size(); k++)
         if (c->host_ranges[k].base == static_cast<char *>(host_ptr)) {
-            HIP_TRY(c, hipSetDevice(c->device));
+            ADSB_ON_DEVICE(c);
             HIP_TRY(c, hipHostUnregister(host_ptr));
             c->host_ranges.erase(c->host_ranges.begin() + (long)k);
             return ADSB_OK;

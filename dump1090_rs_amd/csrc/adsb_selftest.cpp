@@ -16,7 +16,7 @@ int selftest_pass(adsb_ctx *c, const void *d_iq, size_t n_samples, std::vector<u
     if ((uintptr_t)d_iq % 16) return ADSB_ERR_INVALID;
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     if (int rc = order_behind_slot0(c)) return rc;
     Slot &sl = c->slot[0];
     const uint32_t dev_cap = (uint32_t)std::min<uint64_t>(n_samples, 1u << 26);  // a list entry per position at most
@@ -133,7 +133,7 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
 {
     if (!c || !sum_out || !xor_out) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     // the counters block doubles as the 16-byte result area
     static_assert(sizeof(Counters) >= 16, "digest result fits the counters block");
     // the counters block the next pass will use doubles as the 16-byte result area; it is

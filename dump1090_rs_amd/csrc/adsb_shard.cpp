@@ -360,7 +360,7 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     if (n_addrs) *n_addrs = 0;
     if ((uintptr_t)device_iq % 16) return ADSB_ERR_INVALID;
     // (the caller may be a worker thread whose current device is not this context's: sharding.ShardPipeline)
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     if (int rc = shard_begin(c, 0, device_iq, n_samples)) return rc;
     std::vector<uint32_t> addrs;
     int rc = shard_phase_wait(c, 0);
@@ -382,7 +382,7 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
     if (!c || (!extra_addrs && n_extra) || (!records_out && cap)) return ADSB_ERR_INVALID;
     if (!c->shard_active) return ADSB_ERR_INVALID;
     if (n_records) *n_records = 0;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ADSB_ON_DEVICE(c);
     c->shard_active = false;
     const TrialRecord *rec = nullptr;
     size_t n = 0;

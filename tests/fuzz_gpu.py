@@ -241,6 +241,101 @@ def mixed_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
     ctx.close()
 
 
+def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
+    """adsb_multi_*: a sequence of captures of random length over a random number of contexts on the one GPU (the
+    devices wherever there are several), random icao_flush, the host form and resident shards, blocking and up to four
+    captures in flight -- every capture against ONE oracle stream fed the same sequence."""
+    n_dev = torch.cuda.device_count()
+    k = int(rng.choice([1, 2, 3, 5, 8]))
+    devices = [int(rng.integers(0, n_dev)) if n_dev > 1 else 0 for _ in range(k)]
+    per = int(rng.integers(1, 7))
+    icaos = [int(x) for x in rng.integers(1, 1 << 24, size=int(rng.integers(2, 24)))]
+
+    def capture():
+        chunks = int(rng.integers(0, k * per + 1)) if rng.random() < 0.9 else int(rng.integers(k * per + 1, 2 * k * per + 2))
+        n = max(0, chunks * CHUNK - (int(rng.integers(0, CHUNK - 400)) // 4 * 4 if rng.random() < 0.6 and chunks else 0))
+        iq = synth.noise_numpy(n, seed=int(rng.integers(1, 1 << 30)))
+        bursts = []
+        for _ in range(int(rng.integers(0, 12)) * max(1, chunks) if n > 4000 else 0):
+            icao = icaos[int(rng.integers(0, len(icaos)))]
+            kind = rng.random()
+            if kind < 0.35:
+                frame = synth.df17_frame(icao, int(rng.integers(0, 1 << 56)))
+            elif kind < 0.45:
+                frame = synth.df11_frame(icao)
+            elif kind < 0.8:
+                body = bytes([int(rng.choice([0x00, 0x20, 0x28])) | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 3).tolist())
+                frame = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+            else:
+                body = bytes([int(rng.choice([0x80, 0xA0, 0xA8])) | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 10).tolist())
+                frame = body + (synth.crc24(body) ^ icao).to_bytes(3, "big")
+            tick = int(rng.integers(2000, max(2001, 5 * (n - 400))))
+            if rng.random() < 0.2:   # hug a buffer edge = often a shard boundary
+                tick = max(2000, 5 * (CHUNK * int(rng.integers(1, max(2, chunks))) - int(rng.integers(0, 330))) + int(rng.integers(0, 5)))
+            bursts.append(synth.Burst(min(tick, max(2000, 5 * (n - 400))), int(rng.integers(6000, 30000)), int(rng.integers(0, 16)), frame))
+        if n > 4000:
+            synth.add_bursts(iq, bursts)
+        return iq
+
+    caps = [capture() for _ in range(int(rng.integers(2, 6)))]
+    multi = MultiContext(devices, per)
+    orc = Oracle()
+    steps = int(rng.integers(4, 12))
+    plan = []
+    for _ in range(steps):
+        flush = rng.random() < 0.3
+        c = int(rng.integers(0, len(caps)))
+        fits = len(caps[c]) <= k * per * CHUNK
+        form = "host" if (not fits or rng.random() < 0.3) else ("device" if rng.random() < 0.3 else "submit")
+        if flush:
+            orc.icao_flush()
+        plan.append((flush, c, form, [okey(w) for w in orc.demod_iq(caps[c], cap=1 << 18)[0]]))
+    resident = {}
+    for c, iq in enumerate(caps):
+        if len(iq) > k * per * CHUNK:
+            continue
+        ts, ptrs, ns = [], [], []
+        for dev, (a, n) in zip(devices, multi.shard_ranges(len(iq))):
+            t = torch.from_numpy(np.ascontiguousarray(iq[a:a + n])).to(f"cuda:{dev}") if n else None
+            ts.append(t)
+            ptrs.append(t.data_ptr() if n else 0)
+            ns.append(n)
+        resident[c] = (ts, ptrs, ns)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    pending = []
+
+    def check(got, want, what):
+        if [key(m) for m in got] != want:
+            print(f"MISMATCH multi case {case} (fuzz seed {seed}) at {what}: devices {devices}, {per} buffers each, "
+                  f"captures {[len(x) for x in caps]}, {len(got)} frames, {len(want)} expected")
+            for x, y in zip(want, [key(m) for m in got]):
+                if x != y:
+                    print(" first difference:", x, y)
+                    break
+            sys.exit(1)
+
+    depth = int(rng.integers(1, 5))
+    for step, (flush, c, form, want) in enumerate(plan):
+        if form != "submit" or len(pending) == depth:
+            while pending and (form != "submit" or len(pending) == depth):   # the blocking forms want nothing in flight
+                check(multi.collect(cap=1 << 18), pending.pop(0), f"step {step} (collect)")
+        if flush:
+            multi.icao_flush()
+        if form == "host":
+            check(multi.demod_iq(caps[c], cap=1 << 18), want, f"step {step} (host)")
+        elif form == "device":
+            check(multi.demod_iq_device(resident[c][1], resident[c][2], cap=1 << 18), want, f"step {step} (device)")
+        else:
+            multi.submit_iq_device(resident[c][1], resident[c][2])
+            pending.append(want)
+    while pending:
+        check(multi.collect(cap=1 << 18), pending.pop(0), "drain")
+    modes[("multi", False)] = modes.get(("multi", False), 0) + 1
+    modes[("multi:captures", False)] = modes.get(("multi:captures", False), 0) + steps
+    multi.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -255,9 +350,13 @@ def main():
     ap.add_argument("--mixed", type=int, default=8,
                     help="also run this many mixed pipelines: small and large passes in flight together over "
                          "captures that share addresses, random flushes, device-resident and ring-fed")
+    ap.add_argument("--multi", type=int, default=8,
+                    help="also run this many adsb_multi_* sequences: captures over 1-8 contexts, flushes, host / resident, "
+                         "blocking and pipelined, against one oracle stream")
     args = ap.parse_args()
     import torch
     from dump1090_rs_amd import Context, sharding, synth
+    from dump1090_rs_amd.multi import MultiContext
     from dump1090_rs_amd.context import replay_records
     from oracle import binding
     from oracle.binding import demod_iq_carry
@@ -385,6 +484,8 @@ def main():
             dense_pipeline_case(np.random.default_rng([args.seed, k]), synth, Context, binding.Oracle, torch, modes, k, args.seed)
         for k in range(args.mixed):
             mixed_pipeline_case(np.random.default_rng([args.seed, 1000003, k]), synth, Context, binding.Oracle, torch, modes, k, args.seed)
+        for k in range(args.multi):
+            multi_case(np.random.default_rng([args.seed, 2000003, k]), synth, MultiContext, binding.Oracle, torch, modes, k, args.seed)
     print(f"{args.cases} cases identical in {time.time() - t0:.1f} s; modes: "
           + ", ".join(f"{k[0]}{'+carry' if k[1] else ''}={v}" for k, v in sorted(modes.items())))
 

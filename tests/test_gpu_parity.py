@@ -1325,12 +1325,12 @@ def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
     import subprocess
     import sys
     from tests.conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "300", "--seed", "7", "--dense", "20", "--mixed", "40"],
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "300", "--seed", "7", "--dense", "20", "--mixed", "40", "--multi", "30"],
                        capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     # (+ 20 dense pipelines: device-side order / score; + 40 mixed ones: small and large passes in flight
     # together over shared addresses -- the kind of case that found round 2's cross-stream ordering hole)
-    assert "300 cases identical" in r.stdout and "dense_pipeline=20" in r.stdout and "mixed_pipeline=40" in r.stdout
+    assert "300 cases identical" in r.stdout and "dense_pipeline=20" in r.stdout and "mixed_pipeline=40" in r.stdout and "multi=30" in r.stdout
 
 
 def test_four_host_threads_each_with_its_own_context(hip_lib, oracle_mod):
