@@ -213,7 +213,7 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
                 const int k = (int)(cmd.step % kMultiSteps);
                 if (cmd.kind == Cmd::kPhase1) {
                     sd.t_p1_issue = now_s();
-                    if (s.flush_before) c->flush_pending = true;
+                    c->flush_pending = s.flush_before;   // (set either way: a shard that failed before it began must not leave its flush to the next capture)
                     const void *src = sd.src;
                     if (sd.host_src && sd.n_samples) {
                         // the host-pointer form: the shard's samples into this capture's staging buffer, on the
