@@ -291,7 +291,8 @@ int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra
  *                            the call and unchanged until the capture is collected.
  * adsb_msg.chunk is the buffer's index in the whole capture.  Errors and ADSB_ERR_CAPACITY behave as for
  * the one-device calls (adsb_multi_fetch_messages hands out the whole list of a capture whose `out` was too
- * small).  One adsb_multi is driven by one host thread at a time. */
+ * small).  One adsb_multi is driven by one host thread at a time.  Like every entry point of this header, these leave
+ * the calling thread's current HIP device as they found it. */
 typedef struct adsb_multi adsb_multi;
 typedef struct {
     uint64_t n_samples;

@@ -94,3 +94,32 @@ def test_feed_tool_fails_loudly_without_a_gpu(hip_lib, golden):
     r = subprocess.run([str(feed), str(ROOT / "tests" / "golden" / golden["fixtures"][0]["file"])],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and r.stdout == "" and "no CPU fallback" in r.stderr
+
+
+def test_multi_entry_points_refuse_bad_arguments_without_a_device(hip_lib):
+    """adsb_multi_*: argument checks and the contiguous split are host code -- no GPU needed, nothing computed."""
+    from dump1090_rs_amd import sharding
+    L = hip_lib
+    h = C.c_void_p()
+    assert L.adsb_multi_create(C.byref(h), None, 2, 1) == -1 and not h.value
+    assert L.adsb_multi_create(C.byref(h), (C.c_int * 1)(0), 0, 1) == -1
+    assert L.adsb_multi_create(C.byref(h), (C.c_int * 1)(0), 65, 1) == -1
+    assert L.adsb_multi_create(None, (C.c_int * 1)(0), 1, 1) == -1
+    assert L.adsb_multi_create(C.byref(h), (C.c_int * 1)(-1), 1, 1) == -2 and not h.value   # no CPU backend here either
+    L.adsb_multi_destroy(None)
+    assert L.adsb_multi_device_count(None) == 0 and L.adsb_multi_pending(None) == 0 and L.adsb_multi_max_in_flight(None) == 0
+    assert L.adsb_multi_icao_flush(None) == -1 and L.adsb_multi_collect(None, None, 0, None) == -1
+    assert L.adsb_multi_last_error(None) == b""
+    CHUNK = 131072
+    for n_samples in (0, 1, CHUNK - 1, CHUNK, CHUNK + 1, 38 * CHUNK - 4321, 4096 * CHUNK):
+        for world in (1, 2, 3, 8, 64):
+            total = 0
+            for k in range(world):
+                a, n = C.c_size_t(), C.c_size_t()
+                assert L.adsb_multi_shard_range(n_samples, world, k, C.byref(a), C.byref(n)) == 0
+                lo, hi = sharding.sample_range(n_samples, world, k)
+                assert (a.value, a.value + n.value) == (lo, hi) and a.value == total
+                assert n.value % CHUNK == 0 or a.value + n.value == n_samples      # whole buffers but for the capture's end
+                total += n.value
+            assert total == n_samples
+    assert L.adsb_multi_shard_range(10, 0, 0, None, None) == -1 and L.adsb_multi_shard_range(10, 2, 2, None, None) == -1
