@@ -49,6 +49,7 @@ struct StepDev {   // one device's share of one capture
     std::vector<uint32_t> learned;
     const TrialRecord *rec = nullptr;
     size_t n_rec = 0;
+    std::vector<TrialRecord> sorted;    // the shard's records in replay order (sorted by its device thread), when they were not
     int rc = 0;
     adsb_stats st{};
     double t_p1_issue = 0, t_p1_done = 0, t_p2_issue = 0, t_p2_done = 0;
@@ -262,6 +263,9 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
             StepDev &sd = s.dev[(size_t)d->index];
             if (sd.rc != ADSB_OK || shard_phase_landed(c, k)) {
                 if (sd.rc == ADSB_OK) sd.rc = shard_records(c, k, &sd.rec, &sd.n_rec);
+                // (in replay order before they are handed over: the shards' sorts then run side by side, on the device
+                // threads, instead of one after the other on the caller's)
+                if (sd.rc == ADSB_OK && sd.n_rec > 96 && sort_records(sd.rec, sd.n_rec, sd.sorted)) sd.rec = sd.sorted.data();
                 if (sd.rc != ADSB_OK) {
                     sd.rec = nullptr;
                     sd.n_rec = 0;

@@ -28,58 +28,77 @@ inline uint64_t replay_key(const TrialRecord &r)
 namespace adsb {
 namespace host {
 
-void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
-            std::vector<adsb_msg> &out, uint64_t *host_sorts)
+// The order records are replayed in: false and `order` = their indices by (chunk, j, try_phase) when they are not in
+// it already, true (and `order` untouched) when they are.  Insertion for a handful, LSD radix otherwise; stable.
+bool replay_order(const TrialRecord *rec, size_t n, std::vector<uint32_t> &order_out)
 {
-    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
-    // else is put in order here -- the records stay where they are (they may sit in mapped host
-    // memory), only 16-byte (key, index) pairs are sorted.
     struct Ref {
         uint64_t key;
         uint32_t idx;
     };
     bool sorted = true;
     for (size_t i = 1; i < n && sorted; i++) sorted = replay_key(rec[i - 1]) <= replay_key(rec[i]);
-    std::vector<Ref> order;
-    if (!sorted) {
-        if (host_sorts) ++*host_sorts;
-        order.resize(n);
-        uint64_t all_or = 0;
-        for (size_t i = 0; i < n; i++) {
-            order[i] = {replay_key(rec[i]), (uint32_t)i};
-            all_or |= order[i].key;
-        }
-        if (n <= 96) {
-            // a pass of a buffer or two (its workgroups write their records as they find them): by insertion,
-            // stable, nothing to allocate or to count
-            for (size_t a = 1; a < n; a++) {
-                const Ref r = order[a];
-                size_t b = a;
-                for (; b > 0 && order[b - 1].key > r.key; b--) order[b] = order[b - 1];
-                order[b] = r;
-            }
-            all_or = 0;   // (sorted: the passes below all skip)
-        }
-        // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
-        // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
-        std::vector<Ref> tmp(all_or ? n : 0);
-        Ref *src = order.data(), *dst = tmp.data();
-        for (int shift = 0; shift < 64; shift += 11) {
-            if (((all_or >> shift) & 0x7FFu) == 0) continue;
-            uint32_t count[2048] = {0};
-            for (size_t i = 0; i < n; i++) count[(src[i].key >> shift) & 0x7FFu]++;
-            uint32_t at = 0;
-            for (uint32_t &c : count) {
-                const uint32_t k = c;
-                c = at;
-                at += k;
-            }
-            for (size_t i = 0; i < n; i++) dst[count[(src[i].key >> shift) & 0x7FFu]++] = src[i];
-            std::swap(src, dst);
-        }
-        if (src != order.data()) order.swap(tmp);
+    if (sorted) return true;
+    std::vector<Ref> order(n);
+    uint64_t all_or = 0;
+    for (size_t i = 0; i < n; i++) {
+        order[i] = {replay_key(rec[i]), (uint32_t)i};
+        all_or |= order[i].key;
     }
-    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i].idx]; };
+    if (n <= 96) {
+        // a pass of a buffer or two (its workgroups write their records as they find them): by insertion,
+        // stable, nothing to allocate or to count
+        for (size_t a = 1; a < n; a++) {
+            const Ref r = order[a];
+            size_t b = a;
+            for (; b > 0 && order[b - 1].key > r.key; b--) order[b] = order[b - 1];
+            order[b] = r;
+        }
+        all_or = 0;   // (sorted: the passes below all skip)
+    }
+    // LSD radix sort, 11 bits a pass, skipping digits no key uses (a device pass has
+    // chunk < 2^19, j < 2^18, try_phase < 16: four passes); stable
+    std::vector<Ref> tmp(all_or ? n : 0);
+    Ref *src = order.data(), *dst = tmp.data();
+    for (int shift = 0; shift < 64; shift += 11) {
+        if (((all_or >> shift) & 0x7FFu) == 0) continue;
+        uint32_t count[2048] = {0};
+        for (size_t i = 0; i < n; i++) count[(src[i].key >> shift) & 0x7FFu]++;
+        uint32_t at = 0;
+        for (uint32_t &c : count) {
+            const uint32_t k = c;
+            c = at;
+            at += k;
+        }
+        for (size_t i = 0; i < n; i++) dst[count[(src[i].key >> shift) & 0x7FFu]++] = src[i];
+        std::swap(src, dst);
+    }
+    order_out.resize(n);
+    for (size_t i = 0; i < n; i++) order_out[i] = src[i].idx;
+    return false;
+}
+
+// A copy of the records in replay order (what a shard's device thread hands the one replaying thread: the sort is
+// the larger half of a replay's time and the shards' sorts run side by side); false: they are in order as they are.
+bool sort_records(const TrialRecord *rec, size_t n, std::vector<TrialRecord> &sorted_out)
+{
+    std::vector<uint32_t> order;
+    if (replay_order(rec, n, order)) return false;
+    sorted_out.resize(n);
+    for (size_t i = 0; i < n; i++) sorted_out[i] = rec[order[i]];
+    return true;
+}
+
+void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out, uint64_t *host_sorts)
+{
+    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
+    // else is put in order here -- the records stay where they are (they may sit in mapped host
+    // memory), only 16-byte (key, index) pairs are sorted.
+    std::vector<uint32_t> order;
+    const bool sorted = replay_order(rec, n, order);
+    if (!sorted && host_sorts) ++*host_sorts;
+    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i]]; };
     size_t i = 0;
     while (i < n) {
         const uint64_t pos = replay_key(at(i)) >> 8;  // (chunk, j)

@@ -18,6 +18,9 @@ namespace host {
 void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
             std::vector<adsb_msg> &out, uint64_t *host_sorts = nullptr);
 
+bool replay_order(const TrialRecord *rec, size_t n, std::vector<uint32_t> &order_out);
+bool sort_records(const TrialRecord *rec, size_t n, std::vector<TrialRecord> &sorted_out);
+
 // The sorted union of several sorted, duplicate-free address lists (the shards' learned addresses), appended to
 // `out` (cleared first); what is already in `known` (sorted, duplicate-free) is left out.
 void union_sorted(const std::vector<const std::vector<uint32_t> *> &lists, const std::vector<uint32_t> &known,
