@@ -271,7 +271,7 @@ class Env:
             self.dist.destroy_process_group()
 
 
-def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2: bool = True):
+def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2: bool = True, short_block: int = 0):
     """The device-resident pass loop (BASELINE configs 2 and 5).  Returns a dict of raw numbers and
     keeps the context / buffers alive in it for the parity leg."""
     torch = env.torch
@@ -351,6 +351,13 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
         run_steps(warmup + steps * (b + 1), steps, args.timed_profiling)
         env.fence()
         blocks.append((time.perf_counter() - tb) / steps * 1e3)
+    short_ms = None
+    if short_block > 0:   # one block of fewer steps between the same fences: what the pipeline's fill and drain weigh in it
+        env.fence()
+        tb = time.perf_counter()
+        run_steps(warmup, short_block, args.timed_profiling)
+        env.fence()
+        short_ms = (time.perf_counter() - tb) / short_block * 1e3
     gc.enable()
     stats = ctx.stats()
     tot2 = None
@@ -370,7 +377,7 @@ def run_resident(env: Env, args, workload: str, steps: int, warmup: int, level2:
     iv = [b - a for a, b in zip(stamps, stamps[1:])]
     return {"ctx": ctx, "bufs": bufs, "n": n, "n_bursts": n_bursts, "cap": cap, "frames": frames, "elapsed": elapsed,
             "tot": tot, "tot2": tot2, "stats": stats, "intervals": iv, "depth": depth, "ramp": ramp,
-            "alone_ms": alone_ms, "blocks": blocks}
+            "alone_ms": alone_ms, "blocks": blocks, "short_block_ms": short_ms}
 
 
 def clock_ramp(env: Env, args, run) -> dict:
@@ -1310,12 +1317,21 @@ def main():
             also["config1_cargo_bench_case"] = run_config1(env)
             also["config3_streaming_ring"] = config3_leg(env, args)
             also["live_receiver"] = live_leg(env, args)
-            d = run_resident(env, args, "dense", args.steps, args.warmup, level2=False)
-            dr = resident_result(env, args, d, "dense")
+            # (a dense pass is a longer chain -- scan, match, order, records, score, emit, replay -- so the fill and the
+            # drain of the pipeline between the two fences weigh ~0.3 ms: 14 us per step in a block of 20, 1.4 in one
+            # of 200.  This leg reports the steady state, over at least 200 steps, and the short block beside it.)
+            dargs = argparse.Namespace(**vars(args))
+            dargs.steps = max(args.steps, 200)
+            d = run_resident(env, dargs, "dense", dargs.steps, dargs.warmup, level2=False, short_block=args.steps)
+            dr = resident_result(env, dargs, d, "dense")
             _, dsame, dframes = parity_leg(env, d, args.chunks, baseline=False) if not args.no_cpu_baseline else (None, None, None)
             also["config5_dense"] = {
                 "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
-                "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
+                "steps": dargs.steps, "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
+                "ms_per_step_blocks": (dr["ms_per_step_blocks"] or {}).get("all"),
+                "ms_per_step_in_a_block_of": {"steps": args.steps, "ms_per_step": round(d["short_block_ms"], 4),
+                                              "is": "the same loop over only this many steps between the fences: the "
+                                                    "pipeline's fill and drain (one pass's whole chain, ~0.3 ms) included once"},
                 "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
                 "device_ms_per_launch": dr["roofline"]["sustained"]["device_ms_per_launch"],
                 "n_records_last_step": dr["device_stats_last_step"]["n_records"],

@@ -1017,6 +1017,31 @@ def test_feed_tool_prints_and_serves_reference_raw_lines(hip_lib, oracle_mod, go
             feed.kill()
 
 
+def test_feed_tool_reads_a_capture_file_with_several_readers(hip_lib, oracle_mod, tmp_path):
+    """A regular file is filled into the ring's slots by R threads that each pread() and swap their own part
+    (adsb_feed.cpp: FileFill): a capture of 37 buffers and a ragged end, in file order and in memory order, with
+    1 / 3 / 4 / 16 readers and slots of 1 / 5 / 64 buffers (whole slots, a last slot that the file ends in, a
+    slot below the size at which the readers split) -- every run's lines equal to the oracle's stream."""
+    import subprocess
+    from tests.conftest import ROOT
+    n = 37 * 131072 + 77777
+    iq = synth.make_iq(n, n_bursts=500, seed=6061, n_icao=14, df11_every=4)
+    want, _ = oracle_mod.Oracle().demod_iq(iq)
+    lines = [f"*{w['buffer'].hex()};" for w in want]
+    assert len(lines) > 300
+    file_order, mem_order = tmp_path / "cap.iq", tmp_path / "cap_mem.iq"
+    file_order.write_bytes(np.ascontiguousarray(iq[:, ::-1]).tobytes())     # the capture format: im first
+    mem_order.write_bytes(np.ascontiguousarray(iq).tobytes() + b"\x01\x02")   # (+ half a pair: dropped)
+    feed = str(ROOT / "dump1090_rs_amd" / "adsb_feed")
+    for path, extra in ((file_order, []), (mem_order, ["--mem-order"])):
+        for readers, buffers in ((1, 5), (3, 5), (4, 64), (16, 5), (4, 1), (7, 64)):
+            r = subprocess.run([feed, *extra, "--readers", str(readers), "--buffers", str(buffers), str(path)],
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            assert r.stdout.splitlines() == lines, (extra, readers, buffers)
+            assert f"{n} samples, {len(lines)} frames in " in r.stderr
+
+
 def _start_feed(args):
     import socket
     import subprocess

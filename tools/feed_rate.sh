@@ -13,6 +13,7 @@ with open("/dev/shm/adsb_cap.iq", "wb") as f:
 print("wrote 1 GiB")
 PY
 for rep in 1 2; do
+for r in 1 2 4 8; do echo -n "--buffers 64 --readers $r: "; ./dump1090_rs_amd/adsb_feed --readers $r --buffers 64 /dev/shm/adsb_cap.iq 2>&1 > /dev/null | grep "^adsb_feed:"; done
 for b in 1 4 16 64; do
   for order in "--mem-order" ""; do
     echo -n "--buffers $b ${order:-(file order: swapped on the way in)}: "
