@@ -164,6 +164,9 @@ def lib() -> C.CDLL:
     L.adsb_multi_demod_iq.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.adsb_multi_demod_iq_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.POINTER(sz)]
     L.adsb_multi_submit_iq_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.adsb_multi_submit_iq.argtypes = [vp, vp, sz]
+    L.adsb_multi_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.adsb_multi_host_free.argtypes = [vp, vp]
     L.adsb_multi_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_multi_pending.argtypes = [vp]
     L.adsb_multi_fetch_messages.argtypes = [vp, vp, sz, C.POINTER(sz)]
@@ -173,6 +176,7 @@ def lib() -> C.CDLL:
     L.adsb_multi_last_error.restype = C.c_char_p
     for name in ("adsb_multi_create", "adsb_multi_device_count", "adsb_multi_max_in_flight", "adsb_multi_shard_range",
                  "adsb_multi_icao_flush", "adsb_multi_demod_iq", "adsb_multi_demod_iq_device", "adsb_multi_submit_iq_device",
+                 "adsb_multi_submit_iq", "adsb_multi_host_alloc", "adsb_multi_host_free",
                  "adsb_multi_collect", "adsb_multi_pending", "adsb_multi_fetch_messages", "adsb_multi_get_stats",
                  "adsb_multi_filter_table"):
         getattr(L, name).restype = C.c_int

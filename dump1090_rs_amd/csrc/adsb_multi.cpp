@@ -101,6 +101,7 @@ struct adsb_multi {
     std::vector<adsb_msg> undelivered;
     bool has_undelivered = false;
     std::string last_error;
+    std::vector<void *> host_blocks;   // adsb_multi_host_alloc
 };
 
 namespace {
@@ -468,6 +469,10 @@ void adsb_multi_destroy(adsb_multi *m)
     for (auto &d : m->dev) push_cmd(*d, Cmd{Cmd::kStop, 0});
     for (auto &d : m->dev)
         if (d->th.joinable()) d->th.join();
+    {
+        DeviceGuard on_device(m->dev[0]->device);
+        for (void *p : m->host_blocks) (void)hipHostFree(p);
+    }
     for (auto &d : m->dev) {
         DeviceGuard on_device(d->device);
         for (void *p : d->d_stage)
@@ -475,6 +480,45 @@ void adsb_multi_destroy(adsb_multi *m)
         adsb_destroy(d->ctx);
     }
     delete m;
+}
+
+int adsb_multi_host_alloc(adsb_multi *m, size_t bytes, void **out)
+{
+    if (!m || !out || bytes == 0) return ADSB_ERR_INVALID;
+    *out = nullptr;
+    DeviceGuard on_device(m->dev[0]->device);
+    void *p = nullptr;
+    // pinned for every device of the process (portable): each device thread's copy of its range out of it is
+    // a DMA over that device's own link
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        m->last_error = "hipHostMalloc (pinned, portable) failed";
+        return ADSB_ERR_NOMEM;
+    }
+    m->host_blocks.push_back(p);
+    *out = p;
+    return ADSB_OK;
+}
+
+int adsb_multi_host_free(adsb_multi *m, void *p)
+{
+    if (!m || !p) return ADSB_ERR_INVALID;
+    if (m->submitted != m->collected) return ADSB_ERR_BUSY;   // a capture in flight may still be read out of it
+    auto it = std::find(m->host_blocks.begin(), m->host_blocks.end(), p);
+    if (it == m->host_blocks.end()) return ADSB_ERR_INVALID;
+    DeviceGuard on_device(m->dev[0]->device);
+    (void)hipHostFree(p);
+    m->host_blocks.erase(it);
+    return ADSB_OK;
+}
+
+int adsb_multi_submit_iq(adsb_multi *m, const int16_t *iq_re_im, size_t n_samples)
+{
+    if (!m || !iq_re_im || n_samples == 0) return ADSB_ERR_INVALID;
+    if ((n_samples + kChunkSamples - 1) / kChunkSamples > (size_t)m->n * m->max_chunks) return ADSB_ERR_INVALID;
+    std::vector<size_t> n((size_t)m->n);
+    for (int k = 0; k < m->n; k++) (void)adsb_multi_shard_range(n_samples, m->n, k, nullptr, &n[(size_t)k]);
+    return submit_capture(m, nullptr, iq_re_im, true, n.data());
 }
 
 int adsb_multi_device_count(const adsb_multi *m) { return m ? m->n : 0; }

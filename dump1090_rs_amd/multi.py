@@ -30,6 +30,7 @@ class MultiContext:
             raise AdsbError(st, "adsb_multi_create", self._L.adsb_strerror(st).decode())
         self.max_chunks_per_device = int(max_chunks_per_device)
         self._out_cap = 0
+        self._held = []   # per capture in flight: the host array adsb_multi_submit_iq reads from (None for device captures)
 
     # -- lifetime
     def close(self) -> None:
@@ -110,17 +111,44 @@ class MultiContext:
     def submit_iq_device(self, device_ptrs: Sequence[int], n_samples: Sequence[int]) -> None:
         ptrs, ns = self._arrays(device_ptrs, n_samples)
         self._check(self._L.adsb_multi_submit_iq_device(self._h, ptrs, ns), "adsb_multi_submit_iq_device")
+        self._held.append(None)
+
+    def submit_iq(self, iq) -> None:
+        """adsb_multi_submit_iq: a HOST capture of at most len(devices) x max_chunks buffers, asynchronously; every
+        device thread copies its range to its device in front of its scan (a DMA per device when `iq` lives in
+        memory from host_alloc).  `iq` must stay alive and unchanged until the capture is collected."""
+        a = _as_iq(iq)
+        self._check(self._L.adsb_multi_submit_iq(self._h, a.__array_interface__["data"][0], a.shape[0]), "adsb_multi_submit_iq")
+        self._held.append(a)
+
+    def host_alloc(self, n_samples: int) -> np.ndarray:
+        """(n_samples, 2) int16 in pinned host memory that every device of this MultiContext reads by DMA
+        (adsb_multi_host_alloc); freed by host_free or with the MultiContext."""
+        p = C.c_void_p()
+        self._check(self._L.adsb_multi_host_alloc(self._h, int(n_samples) * 4, C.byref(p)), "adsb_multi_host_alloc")
+        buf = (C.c_int16 * (2 * int(n_samples))).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.int16).reshape(-1, 2)
+
+    def host_free(self, array: np.ndarray) -> None:
+        self._check(self._L.adsb_multi_host_free(self._h, array.__array_interface__["data"][0]), "adsb_multi_host_free")
 
     def submit_raw(self, ptrs, ns) -> None:
         """adsb_multi_submit_iq_device on prepared ctypes arrays (a bench loop builds them once)."""
         self._check(self._L.adsb_multi_submit_iq_device(self._h, ptrs, ns), "adsb_multi_submit_iq_device")
+        self._held.append(None)
 
     def collect(self, cap: int = 1 << 16) -> List[ModeSMessage]:
-        return self._take(lambda out, c, n: self._L.adsb_multi_collect(self._h, out, c, n), "adsb_multi_collect", cap)
+        try:
+            return self._take(lambda out, c, n: self._L.adsb_multi_collect(self._h, out, c, n), "adsb_multi_collect", cap)
+        finally:
+            del self._held[: max(0, len(self._held) - self.pending())]
 
     def collect_raw(self, out_buf, cap: int) -> int:
         n = C.c_size_t()
-        self._check(self._L.adsb_multi_collect(self._h, out_buf, cap, C.byref(n)), "adsb_multi_collect")
+        try:
+            self._check(self._L.adsb_multi_collect(self._h, out_buf, cap, C.byref(n)), "adsb_multi_collect")
+        finally:
+            del self._held[: max(0, len(self._held) - self.pending())]
         return n.value
 
     def pending(self) -> int:

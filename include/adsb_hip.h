@@ -289,6 +289,13 @@ int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra
  *                            the scans of capture i + 1 run while capture i is exchanged, matched and
  *                            replayed.  The samples must be complete (their producer synchronised) before
  *                            the call and unchanged until the capture is collected.
+ *   adsb_multi_submit_iq     the asynchronous form for a HOST capture of at most n_devices x
+ *                            max_chunks_per_device buffers: every device thread copies its range to its device in
+ *                            front of its scan.  Out of memory from adsb_multi_host_alloc (pinned for every
+ *                            device) the copies are DMAs, one per device over its own link, and overlap the
+ *                            scans of the captures in flight; out of ordinary memory they go through the
+ *                            runtime's staging buffers (a third of the rate).  The samples stay the caller's
+ *                            and must not change before the capture is collected.
  * adsb_msg.chunk is the buffer's index in the whole capture.  Errors and ADSB_ERR_CAPACITY behave as for
  * the one-device calls (adsb_multi_fetch_messages hands out the whole list of a capture whose `out` was too
  * small).  One adsb_multi is driven by one host thread at a time.  Like every entry point of this header, these leave
@@ -327,6 +334,11 @@ int adsb_multi_demod_iq(adsb_multi *m, const int16_t *iq_re_im, size_t n_samples
 int adsb_multi_demod_iq_device(adsb_multi *m, const void *const *device_iq, const size_t *n_samples, adsb_msg *out,
                                size_t cap, size_t *n_out);
 int adsb_multi_submit_iq_device(adsb_multi *m, const void *const *device_iq, const size_t *n_samples);
+int adsb_multi_submit_iq(adsb_multi *m, const int16_t *iq_re_im, size_t n_samples);
+/* Pinned host memory every device of the adsb_multi reads by DMA (hipHostMalloc, portable).  Freed by
+ * adsb_multi_host_free (ADSB_ERR_BUSY while captures are in flight) or by adsb_multi_destroy. */
+int adsb_multi_host_alloc(adsb_multi *m, size_t bytes, void **out);
+int adsb_multi_host_free(adsb_multi *m, void *host_ptr);
 int adsb_multi_collect(adsb_multi *m, adsb_msg *out, size_t cap, size_t *n_out);
 int adsb_multi_pending(const adsb_multi *m);
 int adsb_multi_fetch_messages(adsb_multi *m, adsb_msg *out, size_t cap, size_t *n_out);

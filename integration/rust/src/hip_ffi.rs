@@ -124,6 +124,9 @@ unsafe extern "C" {
     pub fn adsb_multi_demod_iq(m: *mut AdsbMulti, iq_re_im: *const i16, n_samples: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_multi_demod_iq_device(m: *mut AdsbMulti, device_iq: *const *const c_void, n_samples: *const usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_multi_submit_iq_device(m: *mut AdsbMulti, device_iq: *const *const c_void, n_samples: *const usize) -> c_int;
+    pub fn adsb_multi_submit_iq(m: *mut AdsbMulti, iq_re_im: *const i16, n_samples: usize) -> c_int;
+    pub fn adsb_multi_host_alloc(m: *mut AdsbMulti, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn adsb_multi_host_free(m: *mut AdsbMulti, host_ptr: *mut c_void) -> c_int;
     pub fn adsb_multi_collect(m: *mut AdsbMulti, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_multi_pending(m: *const AdsbMulti) -> c_int;
     pub fn adsb_multi_fetch_messages(m: *mut AdsbMulti, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;

@@ -287,6 +287,8 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
         c = int(rng.integers(0, len(caps)))
         fits = len(caps[c]) <= k * per * CHUNK
         form = "host" if (not fits or rng.random() < 0.3) else ("device" if rng.random() < 0.3 else "submit")
+        if form == "submit" and len(caps[c]) and rng.random() < 0.4:   # the asynchronous HOST form, pinned or ordinary memory
+            form = "submit_pinned" if rng.random() < 0.5 else "submit_host"
         if flush:
             orc.icao_flush()
         plan.append((flush, c, form, [okey(w) for w in orc.demod_iq(caps[c], cap=1 << 18)[0]]))
@@ -316,9 +318,10 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
             sys.exit(1)
 
     depth = int(rng.integers(1, 5))
+    pinned = {}
     for step, (flush, c, form, want) in enumerate(plan):
-        if form != "submit" or len(pending) == depth:
-            while pending and (form != "submit" or len(pending) == depth):   # the blocking forms want nothing in flight
+        if not form.startswith("submit") or len(pending) == depth:
+            while pending and (not form.startswith("submit") or len(pending) == depth):   # the blocking forms want nothing in flight
                 check(multi.collect(cap=1 << 18), pending.pop(0), f"step {step} (collect)")
         if flush:
             multi.icao_flush()
@@ -326,6 +329,15 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
             check(multi.demod_iq(caps[c], cap=1 << 18), want, f"step {step} (host)")
         elif form == "device":
             check(multi.demod_iq_device(resident[c][1], resident[c][2], cap=1 << 18), want, f"step {step} (device)")
+        elif form == "submit_host":
+            multi.submit_iq(caps[c])
+            pending.append(want)
+        elif form == "submit_pinned":
+            if c not in pinned:
+                pinned[c] = multi.host_alloc(len(caps[c]))
+                pinned[c][:] = caps[c]
+            multi.submit_iq(pinned[c])
+            pending.append(want)
         else:
             multi.submit_iq_device(resident[c][1], resident[c][2])
             pending.append(want)
@@ -333,6 +345,7 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
         check(multi.collect(cap=1 << 18), pending.pop(0), "drain")
     modes[("multi", False)] = modes.get(("multi", False), 0) + 1
     modes[("multi:captures", False)] = modes.get(("multi:captures", False), 0) + steps
+    modes[("multi:host_submits", False)] = modes.get(("multi:host_submits", False), 0) + sum(f in ("submit_host", "submit_pinned") for _, _, f, _ in plan)
     multi.close()
 
 

@@ -157,6 +157,59 @@ def test_captures_in_flight_four_deep_with_flushes_between_some(hip_lib, oracle_
             assert [key(m) for m in g] == [want_key(x) for x in w], f"capture {i}"
 
 
+def test_host_captures_in_flight_from_pinned_and_from_ordinary_memory(hip_lib, oracle_mod):
+    """adsb_multi_submit_iq: HOST captures asynchronously, four in flight over three contexts -- out of memory from
+    adsb_multi_host_alloc (every device thread's copy is a DMA in front of its scan) and out of ordinary numpy
+    memory, mixed with device-resident captures, an icao_flush in front of some: one oracle stream flushed at the
+    same points.  A capture longer than the contexts hold together is refused; pinned memory cannot be freed
+    under a capture in flight."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    seeds = [4301, 4302, 4303, 4304, 4305, 4306, 4307]
+    flush_before = {0, 2, 5}
+    caps = []
+    for i, s in enumerate(seeds):
+        iq = coupled_capture8(s)
+        caps.append(np.ascontiguousarray(iq[: (20 - 3 * (i % 3)) * CHUNK + (777 if i % 2 else 0)]))
+    orc = oracle_mod.Oracle()
+    wants = []
+    for i, iq in enumerate(caps):
+        if i in flush_before:
+            orc.icao_flush()
+        wants.append(orc.demod_iq(iq)[0])
+    with MultiContext([0] * 3, 7) as multi:
+        with pytest.raises(Exception):
+            multi.submit_iq(np.zeros((22 * CHUNK, 2), dtype=np.int16))       # 22 buffers > 3 x 7
+        assert multi.pending() == 0
+        pinned = [multi.host_alloc(21 * CHUNK) for _ in range(3)]
+        resident = {}
+        gots = []
+        for i, iq in enumerate(caps):
+            if multi.pending() == multi.max_in_flight():
+                gots.append(multi.collect())
+            if i in flush_before:
+                multi.icao_flush()
+            if i % 3 == 2:                              # a device-resident capture between the host ones
+                resident[i] = to_devices(iq, multi, torch)
+                multi.submit_iq_device(resident[i][1], resident[i][2])
+            elif i % 3 == 0:                            # out of pinned memory (a slot nothing in flight reads)
+                slot = pinned[(i // 3) % 3]
+                slot[: len(iq)] = iq
+                multi.submit_iq(slot[: len(iq)])
+            else:
+                multi.submit_iq(iq)                     # out of ordinary memory
+        with pytest.raises(Exception):
+            multi.host_free(pinned[0])                  # captures in flight
+        while multi.pending():
+            gots.append(multi.collect())
+        for i, (g, w) in enumerate(zip(gots, wants)):
+            assert [key(m) for m in g] == [want_key(x) for x in w], f"capture {i}"
+        multi.host_free(pinned[0])
+        with pytest.raises(Exception):
+            multi.host_free(pinned[0])                  # twice
+        # (the other two blocks go with the MultiContext)
+
+
 def test_small_ragged_and_empty_captures(hip_lib, oracle_mod):
     """Fewer buffers than devices, a capture shorter than one buffer, an empty capture: shards without samples
     still take part in the exchange (their superset must learn what the others taught)."""

@@ -71,5 +71,29 @@ if a.host:
     dt = (time.perf_counter() - t0) / 3
     res["host_form"] = {"ms_per_capture": round(dt * 1e3, 3), "Msamples_per_s": round(len(host) / dt / 1e6, 1), "GB_per_s": round(4 * len(host) / dt / 1e9, 2),
                         "is": "adsb_multi_demod_iq from pageable host memory: every device thread copies its range to its device (hipMemcpyAsync through the runtime's staging) in front of its scan"}
+    # ... and the asynchronous host form out of pinned memory (adsb_multi_host_alloc / adsb_multi_submit_iq): three
+    # pinned captures rotated, four in flight -- every device's copy is a DMA over its own link, overlapped with the scans
+    pinned = [multi.host_alloc(len(host)) for _ in range(3)]
+    for p in pinned:
+        p[:] = host
+    def run_pinned(count):
+        done = 0
+        for i in range(count):
+            multi.icao_flush()
+            multi.submit_iq(pinned[i % 3])
+            if i - done >= multi.max_in_flight() - 1:
+                multi.collect_raw(out, 1 << 18)
+                done += 1
+        while done < count:
+            multi.collect_raw(out, 1 << 18)
+            done += 1
+    run_pinned(4)
+    t0 = time.perf_counter()
+    run_pinned(12)
+    dt = (time.perf_counter() - t0) / 12
+    res["host_form_pinned"] = {"ms_per_capture": round(dt * 1e3, 3), "Msamples_per_s": round(len(host) / dt / 1e6, 1), "GB_per_s": round(4 * len(host) / dt / 1e9, 2),
+                               "is": "adsb_multi_submit_iq out of adsb_multi_host_alloc memory, four captures in flight"}
+    for p in pinned:
+        multi.host_free(p)
 print(json.dumps(res))
 multi.close()
