@@ -464,6 +464,20 @@ __global__ __launch_bounds__(kCarrySamples) void k_update_carry(const uint32_t *
     next[i] = idx >= 0 ? src[idx] : prev[i + n];
 }
 
+// first phase of a shard that listed its fresh addresses as it scanned (ScanParams::fresh): only the summary is
+// left to write.  Same ten words, same order as the records kernel's (seq last); rec_sum_lo carries the sum of the
+// listed addresses, n_dap their count.
+__global__ __launch_bounds__(64) void k_shard_summary(ScanParams p)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t *sm = (uint32_t *)p.summary;
+    const uint32_t vals[9] = {p.ctr->n_hits, p.ctr->overflow, p.ctr->fresh_sum, p.ctr->n_fresh, 0u, 0u, 0u, p.seq, 0u};
+    host_store32(sm + 9, summary_check(vals));
+    host_store32(sm + 8, 0u);
+#pragma unroll
+    for (int k = 0; k < 8; k++) host_store32(sm + k, vals[k]);
+}
+
 // addresses learned elsewhere (other shards of the same capture) join the superset
 __global__ __launch_bounds__(256) void k_set_addresses(const uint32_t *__restrict__ addrs, uint32_t n,
                                                        uint32_t *bitmap, uint32_t lg)
@@ -582,6 +596,13 @@ int launch_set_addresses(const uint32_t *d_addrs, uint32_t n, uint32_t *bitmap, 
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_set_addresses, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_addrs, n,
                        bitmap, bitmap_lg);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_shard_summary(const ScanParams &p, void *stream)
+{
+    hip_clear();
+    hipLaunchKernelGGL(k_shard_summary, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
     return hip_ok(hipGetLastError());
 }
 

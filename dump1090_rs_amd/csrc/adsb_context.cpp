@@ -369,8 +369,10 @@ void adsb_destroy(adsb_ctx *c)
     if (c->ring_h_block) (void)hipHostFree(c->ring_h_block);
     if (c->ring_d_block) (void)hipFree(c->ring_d_block);
     if (c->d_addrs) (void)hipFree(c->d_addrs);
-    for (auto &j : c->shard)
+    for (auto &j : c->shard) {
         if (j.h_addrs) (void)hipHostFree(j.h_addrs);
+        if (j.h_fresh) (void)hipHostFree(j.h_fresh);
+    }
     if (c->d_carry_next) (void)hipFree(c->d_carry_next);
     if (c->d_timeline && tuning_env("ADSB_TIMELINE") && std::atoi(tuning_env("ADSB_TIMELINE")) == 3) {
         // profiling aid: the stamps of the last one-launch pass (100 MHz wall clock)

@@ -232,8 +232,15 @@ struct adsb_ctx {
         hipStream_t scan_q = nullptr;
         uint32_t *h_addrs = nullptr, *h_addrs_dev = nullptr;   // the other shards' addresses, in mapped host memory
                                                                // (k_set_addresses reads them in place: no copy command)
+        bool fresh_list = false;  // phase 1 is the scan alone: it lists the addresses whose bit it set (ScanParams::fresh)
+        uint32_t *h_fresh = nullptr, *h_fresh_dev = nullptr;   // ... here (mapped host memory, kShardAddrCap of them)
     } shard[kSlots];
     uint64_t shard_jobs = 0;      // shards begun (their scans alternate between the first two scan streams)
+    uint32_t shard_fresh_cap = 0; // how many fresh addresses a shard may list before it falls back to reading them out of
+                                  // its records (0: kShardAddrCap; smaller only in tests of that fallback)
+    uint64_t shard_fresh_fallbacks = 0, shard_device_ordered = 0;   // (counters for the tests: adsb_multi_selftest_counters)
+    bool shard_dense = false;     // the shards of this context leave >= 8 records per buffer: their second phase hands the
+                                  // records over in replay order (device-side ordering, as dense single-stream passes do)
     uint32_t *d_addrs = nullptr;
     size_t addrs_cap = 0;
 
@@ -379,7 +386,7 @@ bool summary_landed(const Summary *s, uint32_t seq);
 // (and the buffer-by-buffer fallback of a shard that overflows the lists).  Order of calls per slot:
 // shard_begin -> [landed] -> shard_learned -> shard_match -> [landed] -> shard_records.
 constexpr size_t kShardAddrCap = 16384;   // addresses per launch of k_set_addresses from mapped memory
-int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples);
+int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool fresh_list = false);
 bool shard_phase_landed(adsb_ctx *c, int k);
 int shard_phase_wait(adsb_ctx *c, int k);
 int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs);

@@ -101,6 +101,8 @@ struct Counters {
     uint32_t unordered;      // one-launch pass: a workgroup gave up waiting for the tiles before its own (bounded wait)
     uint32_t t_start[2];     // one-launch pass: the 100 MHz wall clock when its first workgroup started
     uint32_t bitmap_ready;   // one-launch pass behind an icao_flush: its first workgroup has cleared the (folded) bitmap
+    uint32_t n_fresh;        // shard phase 1 (ScanParams::fresh): address bits this scan found clear and set ...
+    uint32_t fresh_sum;      // ... and the sum of those addresses (the host checks the list it reads against it)
     uint32_t tile_done[kFusedMaxTiles];  // one-launch pass: tile t's address bits and list entries are published
     uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
     uint32_t seg_cand[kApSegments];  // candidates seen by each fast workgroup (diagnostic)
@@ -211,6 +213,13 @@ struct ScanParams {
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
     uint32_t keep_counters; // records kernel: leave the counters and lists as they are (first phase of a shard)
+    // first phase of a shard of an adsb_multi (full bitmaps only: bit a IS address a): every address whose bit this
+    // scan finds clear and sets is appended here (mapped host memory) -- what the OTHER devices' supersets may lack.
+    // An address whose bit was set already has been handed to every device before (it was learned in an earlier
+    // capture, or came from the exchange), so the list is all the exchange needs: no records kernel, no per-record
+    // work on the host in the first phase.  Null everywhere else.
+    uint32_t *fresh;
+    uint32_t fresh_cap;
     // carry-over mode (opt-in, not the reference's semantics): the 326-sample lead-in of a
     // buffer holds the samples that preceded it.  Buffers after the first take them from src
     // itself; the first takes them from `carry` (kCarrySamples IQ samples, the end of the
@@ -294,6 +303,9 @@ int launch_records(const ScanParams &p, bool from_mag, TrialRecord *d_rec, void 
 // sort the hit list by (buffer, j, try_phase) on the device, so that the records come out in the
 // order the host replays them in (src/demod_2400.rs:121,158: ascending j, then try_phase)
 int launch_order_hits(const ScanParams &p, void *stream);
+// first phase of a shard that lists its fresh addresses (ScanParams::fresh): the summary alone -- n_hits, overflow,
+// Summary::rec_sum_lo = sum of the fresh addresses, Summary::n_dap = how many -- behind the scan on its stream
+int launch_shard_summary(const ScanParams &p, void *stream);
 // score the (ordered) hits of the pass on the device: messages, filter additions and a summary
 // into mapped host memory (p.score)
 int launch_score(const ScanParams &p, void *stream);

@@ -68,6 +68,88 @@ struct Step {
     double t_submit = 0, t_exchange0 = 0, t_exchange1 = 0, t_done = 0;
 };
 
+// The threads that score a capture's records side by side (adsb_replay_host.h: ParallelReplay).  A job is a stage of
+// one capture's replay -- parts handed out by a counter to whoever is awake, the caller included -- and is done when
+// every part is; a thread that wakes up late finds the counter of ITS job used up and goes back to waiting.
+class ReplayPool {
+  public:
+    explicit ReplayPool(int workers)
+    {
+        for (int k = 0; k < workers; k++) th_.emplace_back([this] { work(); });
+    }
+    ~ReplayPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int threads() const { return (int)th_.size() + 1; }
+    void run(ParallelReplay &pr, void (ParallelReplay::*stage)(int))
+    {
+        auto job = std::make_shared<Job>();
+        job->pr = &pr;
+        job->stage = stage;
+        job->parts = pr.parts();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = job;
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        take(*job);
+        while (job->done.load(std::memory_order_acquire) < job->parts) __builtin_ia32_pause();
+    }
+
+  private:
+    struct Job {
+        ParallelReplay *pr = nullptr;
+        void (ParallelReplay::*stage)(int) = nullptr;
+        int parts = 0;
+        std::atomic<int> next{0}, done{0};
+    };
+    static void take(Job &job)
+    {
+        for (;;) {
+            const int i = job.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= job.parts) return;
+            (job.pr->*job.stage)(i);
+            job.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void work()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            // a capture's second stage follows its first within microseconds, a busy stream's next capture within a
+            // millisecond: stay hot that long, then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500))
+                __builtin_ia32_pause();
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_relaxed) != seen; });
+                seen = gen_.load(std::memory_order_relaxed);
+                if (stop_) return;
+                job = job_;
+            }
+            if (job) take(*job);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    bool stop_ = false;
+    std::shared_ptr<Job> job_;
+};
+
+constexpr size_t kParallelReplayMin = 8192;   // records in a capture from which its replay is worth fanning out
+
 }  // namespace
 
 struct adsb_multi {
@@ -99,9 +181,15 @@ struct adsb_multi {
     Crc24 crc;
     adsb_multi_stats stats{};
     std::vector<adsb_msg> undelivered;
+    std::vector<adsb_msg> msgs;   // the capture being collected (kept: a busy sky's list is megabytes, page by page when new)
     bool has_undelivered = false;
     std::string last_error;
     std::vector<void *> host_blocks;   // adsb_multi_host_alloc
+    std::atomic<uint64_t> shards_sorted_on_host{0};
+    std::unique_ptr<ReplayPool> pool;   // (created with the first capture that is large enough to want it)
+    ParallelReplay parallel;
+    uint64_t parallel_scored = 0;
+    size_t parallel_min = kParallelReplayMin;
 };
 
 namespace {
@@ -198,6 +286,26 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
     adsb_ctx *c = d->ctx;
     std::deque<uint64_t> w1, w2;   // captures whose phase 1 / phase 2 is out on this device, oldest first
     uint32_t seen = 0;
+#ifdef ADSB_TUNING
+    // where this thread's time goes, printed when it ends (ADSB_HOST_TIMES=1): issuing the phases, reading the learned
+    // addresses out of phase 1's records, taking phase 2's records (checksum), putting them in order
+    struct Spent {
+        double issue1 = 0, issue2 = 0, learned = 0, records = 0, sort = 0;
+        uint64_t captures = 0, n_rec = 0;
+        int index;
+        ~Spent()
+        {
+            if (tuning_env("ADSB_HOST_TIMES") && captures)
+                std::fprintf(stderr, "adsb_multi device thread %d: %llu captures, %.1f records each; us per capture: issue phase 1 %.1f, learned %.1f, "
+                             "issue phase 2 %.1f, records %.1f, order %.1f\n", index, (unsigned long long)captures, (double)n_rec / captures,
+                             issue1 / captures * 1e6, learned / captures * 1e6, issue2 / captures * 1e6, records / captures * 1e6, sort / captures * 1e6);
+        }
+    } spent;
+    spent.index = d->index;
+#define SPENT(field, expr) do { const double t_ = now_s(); expr; spent.field += now_s() - t_; } while (0)
+#else
+#define SPENT(field, expr) do { expr; } while (0)
+#endif
     double last_progress = now_s();
     for (;;) {
         bool progressed = false;
@@ -233,11 +341,11 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
                         else
                             sd.rc = ADSB_ERR_NOMEM;
                     }
-                    if (sd.rc == ADSB_OK) sd.rc = shard_begin(c, k, src, sd.n_samples);
+                    if (sd.rc == ADSB_OK) SPENT(issue1, sd.rc = shard_begin(c, k, src, sd.n_samples, true));
                     w1.push_back(cmd.step);
                 } else {
                     sd.t_p2_issue = now_s();
-                    if (sd.rc == ADSB_OK) sd.rc = shard_match(c, k, s.fresh.data(), s.fresh.size());
+                    if (sd.rc == ADSB_OK) SPENT(issue2, sd.rc = shard_match(c, k, s.fresh.data(), s.fresh.size()));
                     w2.push_back(cmd.step);
                 }
             }
@@ -249,7 +357,7 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
             Step &s = m->step[k];
             StepDev &sd = s.dev[(size_t)d->index];
             if (sd.rc != ADSB_OK || shard_phase_landed(c, k)) {
-                if (sd.rc == ADSB_OK) sd.rc = shard_learned(c, k, sd.learned);
+                if (sd.rc == ADSB_OK) SPENT(learned, sd.rc = shard_learned(c, k, sd.learned));
                 if (sd.rc != ADSB_OK) sd.learned.clear();
                 sd.t_p1_done = now_s();
                 w1.pop_front();
@@ -263,10 +371,14 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
             Step &s = m->step[k];
             StepDev &sd = s.dev[(size_t)d->index];
             if (sd.rc != ADSB_OK || shard_phase_landed(c, k)) {
-                if (sd.rc == ADSB_OK) sd.rc = shard_records(c, k, &sd.rec, &sd.n_rec);
+                if (sd.rc == ADSB_OK) SPENT(records, sd.rc = shard_records(c, k, &sd.rec, &sd.n_rec));
                 // (in replay order before they are handed over: the shards' sorts then run side by side, on the device
                 // threads, instead of one after the other on the caller's)
-                if (sd.rc == ADSB_OK && sd.n_rec > 96 && sort_records(sd.rec, sd.n_rec, sd.sorted)) sd.rec = sd.sorted.data();
+                if (sd.rc == ADSB_OK && sd.n_rec > 1) SPENT(sort, if (sort_records(sd.rec, sd.n_rec, sd.sorted)) { sd.rec = sd.sorted.data(); m->shards_sorted_on_host.fetch_add(1, std::memory_order_relaxed); });
+#ifdef ADSB_TUNING
+                spent.captures++;
+                spent.n_rec += sd.n_rec;
+#endif
                 if (sd.rc != ADSB_OK) {
                     sd.rec = nullptr;
                     sd.n_rec = 0;
@@ -389,12 +501,37 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out)
         p2_max = std::max(p2_max, sd.t_p2_done - sd.t_p2_issue);
     }
     const double tr0 = now_s();
-    if (rc == ADSB_OK)
-        // the shards are contiguous ascending buffer ranges: device by device IS global (buffer, j, try_phase) order
-        for (int k = 0; k < m->n; k++) {
-            const StepDev &sd = s.dev[(size_t)k];
-            if (sd.n_rec) replay(m->filter, m->crc, sd.rec, sd.n_rec, sd.chunk_base, out);
+    if (rc == ADSB_OK) {
+        // the shards are contiguous ascending buffer ranges, each in replay order (its device thread saw to that):
+        // device by device IS global (buffer, j, try_phase) order
+        bool done = false;
+        if (st.n_records >= m->parallel_min) {
+            // a busy sky: tens of thousands of records -- scored by several threads at once, each record against the
+            // filter as it was plus the positions at which the capture's new addresses enter it (adsb_replay_host.h)
+            if (!m->pool) {
+                const unsigned hw = std::thread::hardware_concurrency();
+                m->pool.reset(new ReplayPool((int)std::min(6u, std::max(1u, hw / 4))));
+            }
+            std::vector<RecordRun> runs;
+            for (int k = 0; k < m->n; k++)
+                if (s.dev[(size_t)k].n_rec) runs.push_back({s.dev[(size_t)k].rec, s.dev[(size_t)k].n_rec, s.dev[(size_t)k].chunk_base});
+            ParallelReplay &pr = m->parallel;
+            if (pr.plan(m->filter, m->crc, runs, 4 * m->pool->threads(), true)) {
+                m->pool->run(pr, &ParallelReplay::scan_part);
+                if (pr.merge()) {
+                    m->pool->run(pr, &ParallelReplay::score_part);
+                    pr.finish(m->filter, out);
+                    m->parallel_scored++;
+                    done = true;
+                }
+            }
         }
+        if (!done)
+            for (int k = 0; k < m->n; k++) {
+                const StepDev &sd = s.dev[(size_t)k];
+                if (sd.n_rec) replay_sorted(m->filter, m->crc, sd.rec, sd.n_rec, sd.chunk_base, out);
+            }
+    }
     const double tr1 = now_s();
     st.n_messages = out.size();
     st.ms_wall = (float)((s.t_done - s.t_submit) * 1e3);
@@ -556,9 +693,9 @@ int adsb_multi_submit_iq_device(adsb_multi *m, const void *const *device_iq, con
 int adsb_multi_collect(adsb_multi *m, adsb_msg *out, size_t cap, size_t *n_out)
 {
     if (!m || (!out && cap)) return ADSB_ERR_INVALID;
-    std::vector<adsb_msg> msgs;
-    if (int rc = collect_capture(m, msgs)) return rc;
-    return deliver_multi(m, msgs, out, cap, n_out);
+    m->msgs.clear();
+    if (int rc = collect_capture(m, m->msgs)) return rc;
+    return deliver_multi(m, m->msgs, out, cap, n_out);
 }
 
 int adsb_multi_demod_iq_device(adsb_multi *m, const void *const *device_iq, const size_t *n_samples, adsb_msg *out,
@@ -567,9 +704,9 @@ int adsb_multi_demod_iq_device(adsb_multi *m, const void *const *device_iq, cons
     if (!m || !device_iq || !n_samples || (!out && cap)) return ADSB_ERR_INVALID;
     if (m->submitted != m->collected) return ADSB_ERR_BUSY;
     if (int rc = submit_capture(m, device_iq, nullptr, false, n_samples)) return rc;
-    std::vector<adsb_msg> msgs;
-    if (int rc = collect_capture(m, msgs)) return rc;
-    return deliver_multi(m, msgs, out, cap, n_out);
+    m->msgs.clear();
+    if (int rc = collect_capture(m, m->msgs)) return rc;
+    return deliver_multi(m, m->msgs, out, cap, n_out);
 }
 
 int adsb_multi_demod_iq(adsb_multi *m, const int16_t *iq_re_im, size_t n_samples, adsb_msg *out, size_t cap, size_t *n_out)
@@ -628,6 +765,29 @@ int adsb_multi_filter_table(const adsb_multi *m, uint32_t *out4096)
     if (!m || !out4096) return ADSB_ERR_INVALID;
     if (m->submitted != m->collected) return ADSB_ERR_BUSY;
     m->filter.store(out4096);
+    return ADSB_OK;
+}
+
+int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min)
+{
+    if (!m) return ADSB_ERR_INVALID;
+    if (m->submitted != m->collected) return ADSB_ERR_BUSY;
+    for (auto &d : m->dev) d->ctx->shard_fresh_cap = fresh_cap;   // (the device threads are idle: nothing in flight)
+    m->parallel_min = parallel_min ? parallel_min : kParallelReplayMin;
+    return ADSB_OK;
+}
+
+int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out4)
+{
+    if (!m || !out4) return ADSB_ERR_INVALID;
+    if (m->submitted != m->collected) return ADSB_ERR_BUSY;
+    out4[0] = m->shards_sorted_on_host.load(std::memory_order_relaxed);
+    out4[1] = out4[2] = 0;
+    for (auto &d : m->dev) {
+        out4[1] += d->ctx->shard_fresh_fallbacks;
+        out4[2] += d->ctx->shard_device_ordered;
+    }
+    out4[3] = m->parallel_scored;
     return ADSB_OK;
 }
 

@@ -4,6 +4,8 @@
 // adsb_selftest_crc_table, adsb_strerror).  No HIP in this unit: besides the library build it is compiled by plain
 // g++ with -fsanitize=address,undefined and fed every trial the CPU checker slices plus adversarial records
 // (tests/test_host_sanitizers.py) -- the GPU pool offers no device sanitizer, the host side needs none.
+#include <thread>
+
 #include "adsb_replay_host.h"
 
 #include <algorithm>
@@ -89,16 +91,17 @@ bool sort_records(const TrialRecord *rec, size_t n, std::vector<TrialRecord> &so
     return true;
 }
 
-void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
-            std::vector<adsb_msg> &out, uint64_t *host_sorts)
+namespace {
+
+struct NoPosition {
+    void operator()(const TrialRecord &) const {}
+};
+
+// demod_2400.rs:149-207 over records taken in replay order through `at`: per (chunk, j) the best of the trial phases,
+// strict >, from -2; `before` is told every record just before it is scored (the position-aware view wants its place)
+template <class Filter, class At, class Before>
+void replay_in_order(Filter &filter, const Crc24 &crc, size_t n, uint64_t chunk_offset, std::vector<adsb_msg> &out, At at, Before before)
 {
-    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
-    // else is put in order here -- the records stay where they are (they may sit in mapped host
-    // memory), only 16-byte (key, index) pairs are sorted.
-    std::vector<uint32_t> order;
-    const bool sorted = replay_order(rec, n, order);
-    if (!sorted && host_sorts) ++*host_sorts;
-    auto at = [&](size_t i) -> const TrialRecord & { return sorted ? rec[i] : rec[order[i]]; };
     size_t i = 0;
     while (i < n) {
         const uint64_t pos = replay_key(at(i)) >> 8;  // (chunk, j)
@@ -107,6 +110,7 @@ void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t
         for (; i < n; i++) {
             const TrialRecord &r = at(i);
             if ((replay_key(r) >> 8) != pos) break;
+            before(r);
             // records built on the device bring the CRC residual along (pad bit 0) and the filter
             // hash of the value their DF asks about (pad bit 1, hash in bits 4..15)
             const Score s = (r.pad & 1) ? score_modes_message(filter, (uint32_t)(r.power >> 40), r.msg,
@@ -129,6 +133,211 @@ void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t
         m.chunk = chunk_offset + (pos >> 24);
         out.push_back(m);
     }
+}
+
+inline uint32_t record_residual(const Crc24 &crc, const TrialRecord &r)
+{
+    return (r.pad & 1) ? (uint32_t)(r.power >> 40) : crc.residual(r.msg, (r.msg[0] & 0x80) ? 14 : 7);
+}
+
+inline ParallelReplay::Pos global_pos(const TrialRecord &r, uint64_t chunk_offset)
+{
+    return (ParallelReplay::Pos)(chunk_offset + r.chunk) << 32 | (uint32_t)((r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24));
+}
+
+// the filter as it was when the capture began + the first adders: what score_modes_message asks at `now`
+struct FilterView {
+    const IcaoFilter &filter;
+    const ParallelReplay::FirstAdds &adds;
+    ParallelReplay::Pos now = 0;
+    bool test(uint32_t addr, uint32_t start) const { return filter.test(addr, start) || adds.get(addr) < now; }
+    void add(uint32_t, uint32_t) {}   // (ParallelReplay::finish: in the order of the first adders)
+};
+
+}  // namespace
+
+void replay_sorted(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset, std::vector<adsb_msg> &out)
+{
+    replay_in_order(filter, crc, n, chunk_offset, out, [&](size_t i) -> const TrialRecord & { return rec[i]; }, NoPosition{});
+}
+
+void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
+            std::vector<adsb_msg> &out, uint64_t *host_sorts)
+{
+    // order = (chunk, j, try_phase).  Large passes arrive in that order from the device; anything
+    // else is put in order here -- the records stay where they are (they may sit in mapped host
+    // memory), only 16-byte (key, index) pairs are sorted.
+    std::vector<uint32_t> order;
+    const bool sorted = replay_order(rec, n, order);
+    if (!sorted && host_sorts) ++*host_sorts;
+    if (sorted) replay_in_order(filter, crc, n, chunk_offset, out, [&](size_t i) -> const TrialRecord & { return rec[i]; }, NoPosition{});
+    else replay_in_order(filter, crc, n, chunk_offset, out, [&](size_t i) -> const TrialRecord & { return rec[order[i]]; }, NoPosition{});
+}
+
+void ParallelReplay::FirstAdds::reset(uint32_t capacity_pow2)
+{
+    key.assign(capacity_pow2, 0u);
+    pos.assign(capacity_pow2, ~(Pos)0);
+    mask = capacity_pow2 - 1;
+    used = 0;
+}
+
+void ParallelReplay::FirstAdds::put_min(uint32_t value, Pos p)
+{
+    if (2 * (used + 1) > mask + 1) {   // half full: twice the size
+        FirstAdds bigger;
+        bigger.reset(2 * (mask + 1));
+        for (uint32_t i = 0; i <= mask; i++)
+            if (key[i]) bigger.put_min(key[i] - 1, pos[i]);
+        *this = std::move(bigger);
+    }
+    uint32_t h = (value * 2654435761u) >> 7 & mask;
+    while (key[h] && key[h] != value + 1) h = (h + 1) & mask;
+    if (!key[h]) {
+        key[h] = value + 1;
+        used++;
+    }
+    if (p < pos[h]) pos[h] = p;
+}
+
+ParallelReplay::Pos ParallelReplay::FirstAdds::get(uint32_t value) const
+{
+    uint32_t h = (value * 2654435761u) >> 7 & mask;
+    while (key[h] && key[h] != value + 1) h = (h + 1) & mask;
+    return key[h] ? pos[h] : ~(Pos)0;
+}
+
+bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order)
+{
+    filter_ = &filter;
+    crc_ = &crc;
+    // (the parts keep their vectors' memory from capture to capture: tens of thousands of messages each time)
+    for (Part &p : part_) {
+        p.runs.clear();
+        p.out.clear();
+    }
+    new_values_.clear();
+    size_t total = 0;
+    Pos last = 0;
+    bool first = true;
+    for (const RecordRun &r : runs) {
+        total += r.n;
+        if (!r.n) continue;
+        // in replay order throughout: inside every run (unless the caller has seen to that), and from one run to the next
+        for (size_t i = 1; i < r.n && !runs_in_order; i++)
+            if (replay_key(r.rec[i - 1]) > replay_key(r.rec[i])) return false;
+        if (!first && global_pos(r.rec[0], r.chunk_offset) < last) return false;
+        last = global_pos(r.rec[r.n - 1], r.chunk_offset);
+        first = false;
+    }
+    if (parts < 2 || total < (size_t)parts) return false;
+    part_.resize((size_t)parts);
+    n_records_ = total;
+    const size_t per = (total + (size_t)parts - 1) / (size_t)parts;
+    size_t k = 0, in_part = 0;
+    for (const RecordRun &r : runs) {
+        size_t at = 0;
+        while (at < r.n) {
+            const size_t take = in_part < per ? std::min(r.n - at, per - in_part) : r.n - at;   // (the last part takes what is left)
+            // a position's trial phases stay together: the cut moves to the next (chunk, j)
+            size_t end = at + take;
+            while (end < r.n && (replay_key(r.rec[end]) >> 8) == (replay_key(r.rec[end - 1]) >> 8)) end++;
+            part_[k].runs.push_back({r.rec + at, end - at, r.chunk_offset});
+            in_part += end - at;
+            at = end;
+            if (in_part >= per && k + 1 < part_.size()) {
+                k++;
+                in_part = 0;
+            }
+        }
+    }
+    return true;
+}
+
+void ParallelReplay::scan_part(int i)
+{
+    Part &p = part_[(size_t)i];
+    p.adds.reset(1024);
+    p.twice = false;
+    for (const RecordRun &run : p.runs)
+        for (size_t q = 0; q < run.n; q++) {
+            const TrialRecord &r = run.rec[q];
+            // (two records of one (buffer, j, try_phase): the device never makes them -- a trial is one hit -- but a
+            // caller's own records may; the second would find what the first added, and a position cannot say that)
+            if (q && replay_key(run.rec[q - 1]) == replay_key(r)) p.twice = true;
+            const uint32_t df = r.msg[0] >> 3;
+            if (df != 17 && df != 18 && df != 11) continue;
+            if (record_residual(*crc_, r) != 0) continue;   // mod.rs:80-84 (IID 0: the whole residual is zero), :97-99
+            const uint32_t addr = uint32_t(r.msg[1]) << 16 | uint32_t(r.msg[2]) << 8 | r.msg[3];
+            p.adds.put_min(df == 18 ? (addr | IcaoFilter::kAdsbNt) : addr, global_pos(r, run.chunk_offset));
+        }
+}
+
+bool ParallelReplay::merge()
+{
+    uint32_t total = 0;
+    for (const Part &p : part_) {
+        if (p.twice) return false;
+        total += p.adds.used;
+    }
+    uint32_t cap = 1024;
+    while (cap < 4 * total) cap <<= 1;
+    all_.reset(cap);
+    for (const Part &p : part_)
+        for (uint32_t i = 0; i <= p.adds.mask; i++)
+            if (p.adds.key[i]) all_.put_min(p.adds.key[i] - 1, p.adds.pos[i]);
+    // what will newly enter the table, and when
+    new_values_.clear();
+    for (uint32_t i = 0; i <= all_.mask; i++) {
+        if (!all_.key[i]) continue;
+        const uint32_t value = all_.key[i] - 1;
+        const Pos at = all_.pos[i];
+        if (value & IcaoFilter::kAdsbNt) {
+            // DF18: tests the plain address, adds the tagged value -- at its first record that finds the address unknown;
+            // knowledge only grows, so that is its first record or none
+            const uint32_t addr = value & 0xFFFFFFu;
+            if (filter_->test(addr) || all_.get(addr) < at) continue;
+            bool held = false;   // (the tagged value itself may be in the table from an earlier capture)
+            for (uint32_t v : filter_->table()) held = held || v == value;
+            if (!held) new_values_.push_back({at, value});
+        } else if (!filter_->test(value)) {
+            new_values_.push_back({at, value});
+        }
+    }
+    std::sort(new_values_.begin(), new_values_.end());
+    size_t held = 0;
+    for (uint32_t v : filter_->table()) held += v != 0;
+    // add() gives up on a full table and test() then walks all of it: membership stops being a set's
+    return held + new_values_.size() + 64 < IcaoFilter::kSize;
+}
+
+void ParallelReplay::score_part(int i)
+{
+    Part &p = part_[(size_t)i];
+    p.out.clear();
+    size_t mine = 0;
+    for (const RecordRun &run : p.runs) mine += run.n;
+    p.out.reserve(mine / 2);   // (a frame leaves ~3 records)
+    FilterView view{*filter_, all_};
+    for (const RecordRun &run : p.runs) {
+        const TrialRecord *rec = run.rec;
+        replay_in_order(view, *crc_, run.n, run.chunk_offset, p.out, [&](size_t q) -> const TrialRecord & { return rec[q]; },
+                        [&](const TrialRecord &r) { view.now = global_pos(r, run.chunk_offset); });
+    }
+}
+
+void ParallelReplay::apply_adds(IcaoFilter &filter) const
+{
+    for (const auto &nv : new_values_) filter.add(nv.second, IcaoFilter::hash(nv.second & 0xFFFFFFu));
+}
+
+void ParallelReplay::finish(IcaoFilter &filter, std::vector<adsb_msg> &out)
+{
+    size_t total = 0;
+    for (const Part &p : part_) total += p.out.size();
+    out.reserve(out.size() + total);
+    for (const Part &p : part_) out.insert(out.end(), p.out.begin(), p.out.end());
+    apply_adds(filter);
 }
 
 // mode_s/mod.rs:80-84 (DF11, IID 0) and :97-99 (DF17): the addresses the replay will add
@@ -236,6 +445,58 @@ int adsb_selftest_learned_union(const adsb_trial *records, size_t n, const uint3
     const size_t k = std::min(cap, fresh.size());
     if (k) std::memcpy(out, fresh.data(), k * sizeof(uint32_t));
     return fresh.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
+}
+
+int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *records, size_t n, int runs, int parts, int threads,
+                                  adsb_msg *out, size_t cap, size_t *n_out, int *went_parallel)
+{
+    if (!filter_table || (!records && n) || (!out && cap) || runs < 1 || parts < 1 || threads < 1) return ADSB_ERR_INVALID;
+    static const Crc24 crc;
+    IcaoFilter filter;
+    filter.load(filter_table);
+    // the records in replay order, cut into `runs` runs at changes of the buffer index (what shards are), each handed
+    // over with the buffers before it taken out of its `chunk` and put into its chunk_offset
+    std::vector<TrialRecord> sorted;
+    const TrialRecord *rec = reinterpret_cast<const TrialRecord *>(records);
+    if (sort_records(rec, n, sorted)) rec = sorted.data();
+    else sorted.assign(rec, rec + n), rec = sorted.data();
+    std::vector<RecordRun> rr;
+    size_t at = 0;
+    for (int k = 0; k < runs && at < n; k++) {
+        size_t end = k + 1 == runs ? n : std::min(n, at + (n + (size_t)runs - 1) / (size_t)runs);
+        while (end < n && end > at && sorted[end].chunk == sorted[end - 1].chunk) end++;
+        const uint32_t base = sorted[at].chunk;
+        for (size_t i = at; i < end; i++) sorted[i].chunk -= base;
+        rr.push_back({rec + at, end - at, base});
+        at = end;
+    }
+    std::vector<adsb_msg> msgs;
+    ParallelReplay pr;
+    bool parallel = pr.plan(filter, crc, rr, parts);
+    if (parallel) {
+        auto fan_out = [&](void (ParallelReplay::*stage)(int)) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; t++)
+                th.emplace_back([&, t] {
+                    for (int i = t; i < pr.parts(); i += threads) (pr.*stage)(i);
+                });
+            for (auto &x : th) x.join();
+        };
+        fan_out(&ParallelReplay::scan_part);
+        parallel = pr.merge();
+        if (parallel) {
+            fan_out(&ParallelReplay::score_part);
+            pr.finish(filter, msgs);
+        }
+    }
+    if (!parallel)
+        for (const RecordRun &r : rr) replay_sorted(filter, crc, r.rec, r.n, r.chunk_offset, msgs);
+    if (went_parallel) *went_parallel = parallel ? 1 : 0;
+    filter.store(filter_table);
+    const size_t k = std::min(cap, msgs.size());
+    if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
+    if (n_out) *n_out = msgs.size();
+    return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
 }
 
 int adsb_selftest_crc_table(uint32_t *out256)

@@ -18,8 +18,76 @@ namespace host {
 void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset,
             std::vector<adsb_msg> &out, uint64_t *host_sorts = nullptr);
 
+// ... records known to be in replay order (no check)
+void replay_sorted(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t n, uint64_t chunk_offset, std::vector<adsb_msg> &out);
+
 bool replay_order(const TrialRecord *rec, size_t n, std::vector<uint32_t> &order_out);
 bool sort_records(const TrialRecord *rec, size_t n, std::vector<TrialRecord> &sorted_out);
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same replay by several threads at once (adsb_multi's collector: a busy sky leaves tens of thousands of records
+// per capture and the ordered replay was its one serial stage).
+//
+// Scoring reads and writes the filter (src/mode_s/mod.rs:71,80-84,97-104,115,130), but between two flushes the filter only
+// grows, and WHEN a value enters it is a property of the records alone: a value is added by the first record in replay
+// order that can add it -- a DF17 or a DF11 / IID 0 with a clean CRC adds its address whenever the filter does not
+// hold it, whether or not the trial wins its position (the reference scores all five phases, mod.rs is called from
+// demod_2400.rs:158-182).  So "is address a in the filter when the record at position p is scored" is
+//     a was in the filter when the capture began   OR   first_adder(a) < p
+// and with the first adders known every record can be scored independently of every other:
+//   plan        the runs (each in replay order, ascending) are cut into parts at position boundaries
+//   scan_part   every part finds the first adder of each value it can add                    (parallel)
+//   merge       the parts' tables into one; refuses when two records share a position, or the 4096-slot table could fill up (then add() gives up,
+//               src/icao_filter.rs:46-62, and membership is no longer a set's: the caller replays serially)
+//   score_part  every part scores its records against (filter as it was, first adders)        (parallel)
+//   finish      the parts' messages in order; the new values enter the filter in the order of their first adders,
+//               which is the order the serial replay inserts them in (same table, slot for slot)
+// DF18 adds address | 1 << 25 (mod.rs:100-104), which no test ever asks for: it only takes a slot, when its first
+// DF18 record finds the plain address unknown.
+struct RecordRun {
+    const TrialRecord *rec;
+    size_t n;
+    uint64_t chunk_offset;
+};
+
+class ParallelReplay {
+  public:
+    // false: not worth it or not possible (too few records, a run out of order): replay serially
+    // (runs_in_order: the caller has checked every run's own order already)
+    bool plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order = false);
+    int parts() const { return (int)part_.size(); }
+    void scan_part(int i);
+    bool merge();
+    void score_part(int i);
+    void finish(IcaoFilter &filter, std::vector<adsb_msg> &out);
+    // the parts' messages, for a caller that copies them out itself (in order: part 0, 1, ...)
+    const std::vector<adsb_msg> &messages(int i) const { return part_[(size_t)i].out; }
+    void apply_adds(IcaoFilter &filter) const;
+
+    typedef unsigned __int128 Pos;   // (chunk_offset + chunk) << 32 | j << 8 | try_phase
+    struct FirstAdds {               // open addressing, value -> position of its first adder
+        std::vector<uint32_t> key;   // value + 1 (0: empty)
+        std::vector<Pos> pos;
+        uint32_t mask = 0, used = 0;
+        void reset(uint32_t capacity_pow2);
+        void put_min(uint32_t value, Pos p);
+        Pos get(uint32_t value) const;   // ~0 when absent
+    };
+
+  private:
+    struct Part {
+        std::vector<RecordRun> runs;
+        FirstAdds adds;
+        std::vector<adsb_msg> out;
+        bool twice = false;   // two records with one position: the plan is refused
+    };
+    const IcaoFilter *filter_ = nullptr;
+    const Crc24 *crc_ = nullptr;
+    std::vector<Part> part_;
+    FirstAdds all_;
+    size_t n_records_ = 0;
+    std::vector<std::pair<Pos, uint32_t>> new_values_;   // (first adder, value as added), in insertion order
+};
 
 // The sorted union of several sorted, duplicate-free address lists (the shards' learned addresses), appended to
 // `out` (cleared first); what is already in `known` (sorted, duplicate-free) is left out.

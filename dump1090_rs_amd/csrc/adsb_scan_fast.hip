@@ -633,7 +633,15 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitF
                 }
             }
         } else {
-            if (learn) bitmap_set(p.bitmap, p.bitmap_lg, trial_addr(tr));
+            if (learn) {
+                const uint32_t addr = trial_addr(tr);
+                // (a shard of an adsb_multi lists the addresses it is the first to see on this device: ScanParams::fresh)
+                if (bitmap_set(p.bitmap, p.bitmap_lg, addr) && p.fresh) {
+                    const uint32_t k = atomicAdd(&p.ctr->n_fresh, 1u);
+                    atomicAdd(&p.ctr->fresh_sum, addr);
+                    if (k < p.fresh_cap) p.fresh[k] = addr;
+                }
+            }
         }
     }
 }

@@ -50,6 +50,10 @@ int shard_chunk_pass(adsb_ctx *c, Slot &sl, ScanParams p, uint64_t ch, bool with
     p.hits_cap = kWorstPerChunk;
     p.dap = c->fb.d_dap;
     p.dap_cap = kWorstPerChunk;
+    p.fresh = nullptr;           // (the reference-shaped kernel's passes: host-ordered records, addresses read out of them)
+    p.order_cnt = p.order_base = nullptr;
+    p.order_tmp = nullptr;
+    p.hit_fields = nullptr;
     sl.seq = next_seq(c);
     sl.h_sum->seq = 0;
     p.seq = sl.seq;
@@ -80,7 +84,7 @@ int drain_for_chunk_path(adsb_ctx *c, const adsb_ctx::ShardJob &job)
 namespace adsb {
 namespace host {
 
-int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
+int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool fresh_list)
 {
     Slot &sl = c->slot[k];
     adsb_ctx::ShardJob &job = c->shard[k];
@@ -91,6 +95,14 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
         HIP_TRY(c, hipHostMalloc((void **)&job.h_addrs, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_addrs_dev, job.h_addrs, 0));
     }
+    // (adsb_multi's shards on full bitmaps, where bit a IS address a: the scan lists the addresses whose bit it set --
+    // all the exchange needs -- and phase 1 is the scan alone; adsb_device.h: ScanParams::fresh)
+    fresh_list = fresh_list && c->bitmap_lg == kFullBitmapLg;
+    if (fresh_list && !job.h_fresh) {
+        HIP_TRY(c, hipHostMalloc((void **)&job.h_fresh, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_fresh_dev, job.h_fresh, 0));
+    }
+    job.fresh_list = fresh_list;
     ScanParams p{};
     p.src = d_iq;
     p.n_samples = n_samples;
@@ -125,6 +137,19 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
     p.ctr = sl.d_ctr;
     p.summary = sl.h_sum_dev;
     p.keep_counters = 1;
+    if (fresh_list) {
+        p.fresh = job.h_fresh_dev;
+        p.fresh_cap = c->shard_fresh_cap ? std::min<uint32_t>(c->shard_fresh_cap, (uint32_t)kShardAddrCap) : (uint32_t)kShardAddrCap;
+        // a dense stream's shards: hits straight into their buffers' buckets, the second phase's records in replay
+        // order (enqueue_pass has the rules; only where phase 1 has no records kernel of its own to disturb the buckets)
+        if (c->shard_dense && n_chunks > kInlineTailChunks && sl.hits_cap == c->hits_cap) {
+            p.order_cnt = sl.d_order_cnt;
+            p.order_base = sl.d_order_base;
+            p.order_tmp = sl.d_order_tmp;
+            p.hit_fields = sl.d_hit_fields;
+            c->shard_device_ordered++;
+        }
+    }
     sl.seq = next_seq(c);
     sl.h_sum->seq = 0;
     p.seq = sl.seq;
@@ -165,7 +190,11 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples)
     if (fresh)
         if (int e = launch_reset(sl.d_ctr, p.bitmap, p.bitmap_lg, ss)) return fail(c, (hipError_t)e, "launch_reset");
     if (int e = launch_scan(p, false, ss)) return fail(c, (hipError_t)e, "launch_scan");
-    if (int e = launch_records(p, false, sl.h_rec_dev, ss)) return fail(c, (hipError_t)e, "launch_records");
+    if (fresh_list) {
+        if (int e = launch_shard_summary(p, ss)) return fail(c, (hipError_t)e, "launch_shard_summary");
+    } else {
+        if (int e = launch_records(p, false, sl.h_rec_dev, ss)) return fail(c, (hipError_t)e, "launch_records");
+    }
     HIP_TRY(c, hipEventRecord(sl.scanned, ss));   // (the second phase, on the tail stream, orders itself behind this launch)
     job.waiting = true;
     return ADSB_OK;
@@ -200,7 +229,8 @@ int shard_phase_wait(adsb_ctx *c, int k)
     return ADSB_ERR_HIP;
 }
 
-// after phase 1 has landed: the addresses this shard's replay can add, sorted, no duplicates
+// after phase 1 has landed: the addresses this shard's replay can add (or, from a fresh list, those of them this
+// device had not seen: what the other devices may lack), sorted, no duplicates
 int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
 {
     Slot &sl = c->slot[k];
@@ -210,17 +240,51 @@ int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
     const ScanParams &p = job.p;
     if (!p.n_chunks) return ADSB_OK;
     job.by_chunk = sl.h_sum->overflow != 0;
-    const size_t n_hits = sl.h_sum->n_hits;
-    if (!job.by_chunk) {
+    bool from_records = !job.fresh_list;
+    if (!job.by_chunk && job.fresh_list) {
+        const size_t n_fresh = sl.h_sum->n_dap;   // (k_shard_summary: count in n_dap, sum of the addresses in rec_sum_lo)
+        if (n_fresh <= p.fresh_cap) {
+            // the list and the summary are separate posted writes: the list is whole when it adds up
+            bool whole = false;
+            for (int attempt = 0; attempt < 200 && !whole; attempt++) {
+                uint32_t sum = 0;
+                for (size_t i = 0; i < n_fresh; i++) sum += __atomic_load_n(&job.h_fresh[i], __ATOMIC_RELAXED);
+                whole = sum == sl.h_sum->rec_sum_lo;
+                if (!whole)
+                    for (volatile int spin = 0; spin < 2000; spin++) {}
+            }
+            if (!whole) {
+                c->last_error = "shard: the fresh addresses in host memory do not add up to the sum of the scan that listed them";
+                return ADSB_ERR_HIP;
+            }
+            addrs.assign(job.h_fresh, job.h_fresh + n_fresh);
+        } else {
+            // more new addresses than the list holds (a capture that teaches tens of thousands): the records of the
+            // self-validating hits after all, behind the scan, and the addresses out of those
+            c->shard_fresh_fallbacks++;
+            sl.seq = next_seq(c);
+            sl.h_sum->seq = 0;
+            job.p.seq = sl.seq;
+            if (int e = launch_order_hits(job.p, job.scan_q)) return fail(c, (hipError_t)e, "launch_order_hits");   // (device-ordered: the buckets' places)
+            if (int e = launch_records(job.p, false, sl.h_rec_dev, job.scan_q)) return fail(c, (hipError_t)e, "launch_records");
+            HIP_TRY(c, hipEventRecord(sl.scanned, job.scan_q));
+            job.waiting = true;
+            if (int rc = shard_phase_wait(c, k)) return rc;
+            from_records = true;
+        }
+    }
+    if (!job.by_chunk && from_records) {
+        const size_t n_hits = sl.h_sum->n_hits;
         if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n_hits)) return rc;
         learned_addresses(c->crc, sl.h_rec, n_hits, addrs);
-    } else {
+    } else if (job.by_chunk) {
         // Far denser than the fast scan's lists are sized for: zero this pass's counters (the
-        // records kernel does that on its way out), then both phases go buffer by buffer
-        // through the reference-shaped kernel, whose lists hold a buffer's worst case.
+        // records kernel does that on its way out; a device-ordered pass's bucket counts: k_order_prefix), then both
+        // phases go buffer by buffer through the reference-shaped kernel, whose lists hold a buffer's worst case.
         if (int rc = drain_for_chunk_path(c, job)) return rc;
         ScanParams q = p;
         q.keep_counters = 0;
+        if (int e = launch_order_hits(q, c->stream)) return fail(c, (hipError_t)e, "launch_order_hits");
         if (int e = launch_records(q, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (uint64_t ch = 0; ch < p.n_chunks; ch++) {
@@ -279,6 +343,7 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
         // block counter this phase's records kernel counts in)
         HIP_TRY(c, hipStreamWaitEvent(ts, sl.scanned, 0));
         if (int e = launch_match(p, ts)) return fail(c, (hipError_t)e, "launch_match");
+        if (int e = launch_order_hits(p, ts)) return fail(c, (hipError_t)e, "launch_order_hits");   // (device-ordered shards only)
         if (int e = launch_records(p, false, sl.h_rec_dev, ts)) return fail(c, (hipError_t)e, "launch_records");
         HIP_TRY(c, hipEventRecord(sl.recorded, ts));
         job.ran = true;
@@ -321,6 +386,11 @@ int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
             c->stats = st;
             *rec = sl.h_rec;
             *n_out = n;
+            // (density = records per buffer, with the single stream's thresholds and hysteresis: adsb_collect.cpp)
+            if (p.n_chunks > kInlineTailChunks) {
+                if (n >= 8u * (size_t)p.n_chunks) c->shard_dense = true;
+                else if (n < 2u * (size_t)p.n_chunks) c->shard_dense = false;
+            }
             return ADSB_OK;
         }
     }

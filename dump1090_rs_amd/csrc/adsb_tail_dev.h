@@ -194,7 +194,7 @@ __device__ __forceinline__ void records_block(const ScanParams &p, TrialRecord *
             }
             tpre[T] = at;
         }
-        if (threadIdx.x < T) p.order_cnt[c * T + threadIdx.x] = 0;
+        if (threadIdx.x < T && !p.keep_counters) p.order_cnt[c * T + threadIdx.x] = 0;   // (a shard's first phase: its second still appends)
         __syncthreads();
         const uint32_t bn = tpre[T];
         uint64_t mine[kOrderBucket / 256];

@@ -109,7 +109,10 @@ struct Score {
 // 14 bytes for DF >= 16, else 7) is already known.
 // `hash`: icao_hash of the value this message's DF asks the filter about (the residual for the
 // address/parity DFs, the address for DF11/17/18) when the device supplied it, else -1.
-inline Score score_modes_message(IcaoFilter &filter, uint32_t residual, const uint8_t msg[14], int hash = -1)
+// `Filter`: IcaoFilter, or a stand-in with the same test(addr, start) / add(addr, start) (the position-aware view of
+// the parallel replay, adsb_replay_host.cpp).
+template <class Filter>
+inline Score score_modes_message(Filter &filter, uint32_t residual, const uint8_t msg[14], int hash = -1)
 {
     const uint32_t df = msg[0] >> 3;                            // :41
     const int len = (df & 0x10) ? 14 : 7;                       // :42-46
@@ -166,7 +169,8 @@ inline Score score_modes_message(IcaoFilter &filter, uint32_t residual, const ui
 }
 
 // ... computing the residual here (src/crc.rs:263-282)
-inline Score score_modes_message(IcaoFilter &filter, const Crc24 &crc, const uint8_t msg[14])
+template <class Filter>
+inline Score score_modes_message(Filter &filter, const Crc24 &crc, const uint8_t msg[14])
 {
     return score_modes_message(filter, crc.residual(msg, (msg[0] & 0x80) ? 14 : 7), msg);
 }

@@ -393,6 +393,26 @@ int adsb_selftest_gate_stages(adsb_ctx *ctx, const void *device_iq_re_im, size_t
  * run the second look on purpose; results never depend on the value.  ADSB_ERR_BUSY while passes are pending. */
 int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
 
+/* Test hooks for adsb_multi (0 = the default; results never depend on either; ADSB_ERR_BUSY while captures are in flight):
+ * fresh_cap     a shard's scan lists the addresses it is the first to see on its device, at most this many (16384); a
+ *               capture that teaches more falls back to reading them out of its trial records -- a small value lets a
+ *               test take that fallback on purpose;
+ * parallel_min  captures of at least this many trial records (8192) are scored by several host threads at once. */
+int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min);
+/* ... and what the shards did so far: out4[0] shards (of more than 96 records) whose records the host had to put in
+ * order, [1] shards that took the fallback above, [2] shards whose second phase ordered its records on the device
+ * (a dense stream's), [3] captures whose records were scored by several host threads at once. */
+int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out4);
+
+/* Host only, no context: the ordered replay done by several threads at once, as adsb_multi_collect does it for captures
+ * of tens of thousands of records (csrc/adsb_replay_host.h: ParallelReplay) -- the records are put in order, cut into
+ * `runs` runs at buffer boundaries (the shards), planned into `parts` parts and scanned / scored by `threads` threads.
+ * Same arguments and results as adsb_replay_records; *went_parallel = 0 when the plan was refused (too few records, a
+ * filter table that could fill up) and the records were replayed serially.  For the tests that pin it to the serial
+ * replay and to the oracle. */
+int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *records, size_t n, int runs, int parts, int threads,
+                                  adsb_msg *out, size_t cap, size_t *n_out, int *went_parallel);
+
 /* The 256-entry CRC-24 table the host replay scores with (src/crc.rs:3-260 CRC_TABLE): for the test that
  * pins it against the reference's constants.  Host only, no context. */
 int adsb_selftest_crc_table(uint32_t *out256);

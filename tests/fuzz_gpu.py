@@ -279,6 +279,8 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
 
     caps = [capture() for _ in range(int(rng.integers(2, 6)))]
     multi = MultiContext(devices, per)
+    if rng.random() < 0.5:   # half of the sequences: every capture scored by several host threads, whatever its size
+        multi.selftest_tune(parallel_min=1)
     orc = Oracle()
     steps = int(rng.integers(4, 12))
     plan = []
@@ -345,6 +347,7 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
         check(multi.collect(cap=1 << 18), pending.pop(0), "drain")
     modes[("multi", False)] = modes.get(("multi", False), 0) + 1
     modes[("multi:captures", False)] = modes.get(("multi:captures", False), 0) + steps
+    modes[("multi:parallel_replays", False)] = modes.get(("multi:parallel_replays", False), 0) + int(multi.selftest_counters()["parallel_scored_captures"])
     modes[("multi:host_submits", False)] = modes.get(("multi:host_submits", False), 0) + sum(f in ("submit_host", "submit_pinned") for _, _, f, _ in plan)
     multi.close()
 

@@ -210,6 +210,127 @@ def test_host_captures_in_flight_from_pinned_and_from_ordinary_memory(hip_lib, o
         # (the other two blocks go with the MultiContext)
 
 
+def dense_capture(seed, n_buffers, bursts_per_buffer, n_icao=40):
+    return synth.make_iq(n_buffers * CHUNK - 4321, n_bursts=n_buffers * bursts_per_buffer, seed=seed, n_icao=n_icao, df11_every=5)
+
+
+def test_dense_shards_order_their_records_on_the_device_and_sparse_ones_do_not(hip_lib, oracle_mod):
+    """A busy sky leaves tens of records per buffer: from the second dense capture on, a shard's second phase hands
+    its records over in replay order (buckets per buffer and tile, rank sort in the records kernel -- what dense
+    single-stream passes do) and the host sorts nothing; a sparse capture switches back.  Dense, dense, flush + dense,
+    sparse, sparse, dense, four in flight over three contexts of 24 buffers: every capture equal to one oracle stream."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    plan = [("dense", 5101, False), ("dense", 5102, False), ("dense", 5103, True), ("dense", 5104, False),
+            ("sparse", 5105, False), ("sparse", 5106, False), ("sparse", 5107, True), ("dense", 5108, False), ("dense", 5109, False)]
+    caps = [dense_capture(seed, 66, 6) if kind == "dense" else synth.make_iq(66 * CHUNK - 999, n_bursts=30, seed=seed, n_icao=12)
+            for kind, seed, _ in plan]
+    orc = oracle_mod.Oracle()
+    wants = []
+    for (kind, seed, flush), iq in zip(plan, caps):
+        if flush:
+            orc.icao_flush()
+        wants.append(orc.demod_iq(iq)[0])
+    assert len(wants[0]) > 66 * 4 and len(wants[4]) < 66
+    with MultiContext([0] * 3, 24) as multi:
+        resident = [to_devices(iq, multi, torch) for iq in caps]
+        gots = []
+        for i, (kind, seed, flush) in enumerate(plan):
+            if multi.pending() == multi.max_in_flight():
+                gots.append(multi.collect(cap=1 << 16))
+            if flush:
+                multi.icao_flush()
+            multi.submit_iq_device(resident[i][1], resident[i][2])
+        while multi.pending():
+            gots.append(multi.collect(cap=1 << 16))
+        for i, (g, w) in enumerate(zip(gots, wants)):
+            assert [key(m) for m in g] == [want_key(x) for x in w], f"capture {i}"
+        ctr = multi.selftest_counters()
+        assert ctr["device_ordered_shards"] >= 3 and ctr["fresh_list_fallbacks"] == 0
+        # one at a time now (the density of capture i is known when capture i + 1 starts): dense ones after the first
+        # arrive in order, nothing is sorted on the host for them
+        before = multi.selftest_counters()
+        for i in (0, 1, 2):
+            multi.icao_flush()
+            got = multi.demod_iq_device(resident[i][1], resident[i][2], cap=1 << 16)
+            orc2 = oracle_mod.Oracle()
+            assert [key(m) for m in got] == [want_key(x) for x in orc2.demod_iq(caps[i])[0]]
+        after = multi.selftest_counters()
+        assert after["device_ordered_shards"] - before["device_ordered_shards"] >= 6
+        assert after["shards_sorted_on_host"] - before["shards_sorted_on_host"] <= 3
+
+
+def test_captures_scored_by_several_host_threads_equal_the_serial_replay(hip_lib, oracle_mod):
+    """adsb_multi_collect scores a capture of many records with several threads at once: every record against the filter
+    as it was plus the positions at which the capture's new addresses enter it (csrc/adsb_replay_host.h).  With the
+    threshold at 1 every capture goes that way -- the coupled ones (an address taught in one shard that frames in
+    three others need, a pre-loaded filter), dense ones, with flushes, pipelined: same messages as the oracle's one
+    stream, same filter table slot for slot."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    caps = [coupled_capture8(4401), dense_capture(4402, 60, 6), coupled_capture8(4403)[: 30 * CHUNK + 999], dense_capture(4404, 64, 9, n_icao=300),
+            dense_capture(4405, 64, 2, n_icao=25), coupled_capture8(4406)]
+    flush_before = {0, 3, 5}
+    orc = oracle_mod.Oracle()
+    wants = []
+    for i, iq in enumerate(caps):
+        if i in flush_before:
+            orc.icao_flush()
+        wants.append([want_key(x) for x in orc.demod_iq(iq)[0]])
+    want_table = list(orc.filter.a)
+    for devices in ([0] * 8, [0] * 3, [0]):
+        per = -(-max(len(c) for c in caps) // CHUNK // len(devices)) + 1
+        with MultiContext(devices, max(per, 17)) as multi:
+            multi.selftest_tune(parallel_min=1)
+            resident = [to_devices(iq, multi, torch) for iq in caps]
+            gots = []
+            for i in range(len(caps)):
+                if multi.pending() == 3:
+                    gots.append(multi.collect(cap=1 << 16))
+                if i in flush_before:
+                    multi.icao_flush()
+                multi.submit_iq_device(resident[i][1], resident[i][2])
+            while multi.pending():
+                gots.append(multi.collect(cap=1 << 16))
+            for i, (g, w) in enumerate(zip(gots, wants)):
+                assert [key(m) for m in g] == w, f"capture {i} over {len(devices)} contexts"
+            assert list(multi.filter_table()) == list(want_table)
+            assert multi.selftest_counters()["parallel_scored_captures"] == len(caps)
+
+
+def test_a_capture_that_teaches_more_addresses_than_the_fresh_list_holds(hip_lib, oracle_mod):
+    """A shard's scan lists the addresses it is the first to see on its device (all the exchange needs); a capture
+    with more new aircraft than the list holds reads them out of its trial records instead.  With the list cut to
+    three entries every shard of these captures takes that path, sparse and dense (device-ordered) ones, pipelined,
+    with and without a flush: equal to the oracle, and to the same captures with the list at its full size."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    caps = [dense_capture(5201 + i, 60, 5 if i % 2 == 0 else 1, n_icao=30) for i in range(5)]
+    orc = oracle_mod.Oracle()
+    wants = []
+    for i, iq in enumerate(caps):
+        if i == 3:
+            orc.icao_flush()
+        wants.append([want_key(x) for x in orc.demod_iq(iq)[0]])
+    for cap_n in (3, 0):
+        with MultiContext([0] * 3, 20) as multi:
+            multi.selftest_tune(fresh_cap=cap_n)
+            resident = [to_devices(iq, multi, torch) for iq in caps]
+            gots = []
+            for i in range(len(caps)):
+                if multi.pending() == 2:
+                    gots.append(multi.collect(cap=1 << 16))
+                if i == 3:
+                    multi.icao_flush()
+                multi.submit_iq_device(resident[i][1], resident[i][2])
+            while multi.pending():
+                gots.append(multi.collect(cap=1 << 16))
+            for i, (g, w) in enumerate(zip(gots, wants)):
+                assert [key(m) for m in g] == w, f"capture {i}, fresh list of {cap_n or 16384}"
+            ctr = multi.selftest_counters()
+            assert (ctr["fresh_list_fallbacks"] >= 6) == (cap_n == 3), ctr
+
+
 def test_small_ragged_and_empty_captures(hip_lib, oracle_mod):
     """Fewer buffers than devices, a capture shorter than one buffer, an empty capture: shards without samples
     still take part in the exchange (their superset must learn what the others taught)."""

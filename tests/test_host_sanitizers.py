@@ -35,6 +35,18 @@ H.adsb_format_raw.argtypes = [vp, C.c_char_p, sz]
 H.adsb_selftest_learned_union.argtypes = [vp, sz, vp, sz, vp, sz, C.POINTER(sz)]
 H.adsb_selftest_crc_table.argtypes = [vp]
 H.adsb_strerror.restype = C.c_char_p
+H.adsb_selftest_parallel_replay.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp, sz, C.POINTER(sz), C.POINTER(C.c_int)]
+went_parallel = {0: 0, 1: 0}
+
+def parallel(recs, table_words, runs, parts, threads):
+    """the same records through ParallelReplay (csrc/adsb_replay_host.h): `runs` shards, `parts` parts, `threads` threads"""
+    table = (C.c_uint32 * 4096)(*(table_words if table_words is not None else [0] * 4096))
+    cap = len(recs) + 8
+    out, n, par = (AdsbMsg * cap)(), sz(), C.c_int(-1)
+    st = H.adsb_selftest_parallel_replay(table, as_array(recs), len(recs), runs, parts, threads, out, cap, C.byref(n), C.byref(par))
+    assert st == 0 and par.value in (0, 1)
+    went_parallel[par.value] += 1
+    return [(bytes(m.msg), m.len, m.try_phase, m.score, m.j, m.chunk, m.signal_level) for m in out[:n.value]], list(table), par.value
 
 def trials_of(iq):
     out = []
@@ -91,6 +103,12 @@ def check(recs, table_words=None, what=""):
     want = reference(recs, filt)
     assert got == want, (what, len(got), len(want))
     assert list(table) == list(filt.a), what     # the filter ends where the oracle's does
+    # ... and by several threads at once: same messages, same table slot for slot, however the records are cut
+    for runs, parts, threads in ((1, 2, 2), (3, 7, 3), (8, 8, 4), (2, 33, 5)):
+        pgot, ptable, par = parallel(recs, table_words, runs, parts, threads)
+        assert pgot == want and ptable == list(filt.a), (what, runs, parts, threads, par, len(pgot), len(want))
+        if what in ("nearly full table", "full table"):
+            assert par == 0, what                # add() can give up: membership is no set's any more, the plan is refused
     return got
 
 # 1. every trial of the three reference captures -> the golden frames
@@ -127,7 +145,7 @@ def crc_fix(msg, nbytes):
     c = O.orc_modes_checksum(body, nbytes * 8)
     return list(body[:nbytes - 3]) + [(c >> 16) & 255, (c >> 8) & 255, c & 255] + list(msg[nbytes:])
 
-def random_records(n, chunks, seed):
+def random_records(n, chunks, seed, dups=True):
     r = random.Random(seed)
     addrs = [r.randrange(1, 1 << 24) for _ in range(12)]
     out = []
@@ -151,16 +169,18 @@ def random_records(n, chunks, seed):
         if r.random() < 0.02:
             msg = [0] * 14                            # the reference's None
         out.append(rec(r.choice(chunks), r.randrange(0, 131072), r.randrange(4, 9), msg, power=r.randrange(1 << 38)))
-    out += [r.choice(out) for _ in range(n // 5)] if out else []   # exact duplicates
+    if dups:
+        out += [r.choice(out) for _ in range(n // 5)] if out else []   # exact duplicates
     r.shuffle(out)
     return out
 
 emitted, scores = 0, set()
 for n in (0, 1, 2, 96, 97, 98, 500, 5000):
     for chunks in ([0], [0, 1, 2, 3], [0, 0xFFFFFFFF, 0xFFFFFFFE, 0x80000000, 7]):
-        got = check(random_records(n, chunks, 1000 * n + len(chunks)), what=("random", n, len(chunks)))
-        emitted += len(got)
-        scores |= {m[3] for m in got}
+        for dups in (True, False):   # (with duplicates the parallel plan is refused: two records of one position)
+            got = check(random_records(n, chunks, 1000 * n + len(chunks), dups), what=("random", n, len(chunks), dups))
+            emitted += len(got)
+            scores |= {m[3] for m in got}
 assert emitted > 1000 and scores == {750, 1000, 1400, 1600, 1800}, (emitted, scores)   # every score of mode_s/mod.rs:56-135 occurs
 
 # 4. a filter table at its 4096 entries: icao_filter_add gives up (src/icao_filter.rs:46-62), test() walks the whole table
@@ -232,6 +252,7 @@ assert H.adsb_selftest_learned_union(None, 0, None, 0, None, 0, C.byref(cnt)) ==
 t = (C.c_uint32 * 256)()
 assert H.adsb_selftest_crc_table(t) == 0 and list(t) == [O.orc_crc_table_entry(i) for i in range(256)]
 assert b"no CPU fallback" in H.adsb_strerror(-2) and H.adsb_strerror(12345) == b"unknown status"
+assert went_parallel[1] > 60 and went_parallel[0] >= 8, went_parallel
 print("sanitized host-only code ok")
 '''
 
@@ -243,7 +264,7 @@ def test_host_only_code_under_address_and_ub_sanitizers(oracle_mod):
     hdrs = [SRC.parent / n for n in ("adsb_replay_host.h", "adsb_record.h", "mode_s_host.hpp")] + [ROOT / "include" / "adsb_hip.h"]
     if not OUT.exists() or OUT.stat().st_mtime < max(p.stat().st_mtime for p in [SRC, *hdrs]):
         subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined",
-                        "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-shared", "-fPIC", str(SRC), "-o", str(OUT)],
+                        "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-shared", "-fPIC", "-pthread", str(SRC), "-o", str(OUT)],
                        check=True)
     code = CHILD % {"root": str(ROOT), "lib": str(OUT), "golden": str(GOLDEN / "reference_frames.json"), "gdir": str(GOLDEN)}
     env = dict(__import__("os").environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",

@@ -16,6 +16,7 @@ ap.add_argument("--contexts", type=int, default=8)
 ap.add_argument("--chunks", type=int, default=512, help="buffers in the whole capture")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--pipelined", action="store_true")
+ap.add_argument("--bursts", type=int, default=64, help="injected bursts per 512 buffers (64 = the sparse bench workload, 5000 = the dense one)")
 ap.add_argument("--host", action="store_true", help="also time adsb_multi_demod_iq over the same capture in pageable host memory (the PCIe-inclusive rate)")
 a = ap.parse_args()
 CHUNK = 131072
@@ -23,7 +24,7 @@ n_dev = torch.cuda.device_count()
 devices = [k % n_dev for k in range(a.contexts)]
 multi = MultiContext(devices, -(-a.chunks // a.contexts))
 ranges = multi.shard_ranges(a.chunks * CHUNK)
-parts = [synth.make_iq_torch(n, n_bursts=max(1, 64 * (n // CHUNK) // 512), seed=synth.SEED_DEFAULT + 31 * r,
+parts = [synth.make_iq_torch(n, n_bursts=max(1, a.bursts * (n // CHUNK) // 512), seed=synth.SEED_DEFAULT + 31 * r,
                              device=torch.device("cuda", devices[r])) for r, (_, n) in enumerate(ranges)]
 torch.cuda.synchronize()
 ptrs = (C.c_void_p * a.contexts)(*[C.c_void_p(t.data_ptr()) for t in parts])
@@ -56,7 +57,7 @@ t0 = time.perf_counter()
 run(a.steps, acc)
 wall = time.perf_counter() - t0
 time.sleep(0.06)
-res = {"contexts": a.contexts, "devices": devices, "chunks": a.chunks, "steps": a.steps, "pipelined": a.pipelined,
+res = {"bursts_per_512_buffers": a.bursts, "last_capture": {k: multi.stats()[k] for k in ("n_records", "n_messages", "n_addrs_exchanged", "retries")}, "contexts": a.contexts, "devices": devices, "chunks": a.chunks, "steps": a.steps, "pipelined": a.pipelined,
        "ms_per_step_wall": round(wall / a.steps * 1e3, 4), "stats_mean": {k: round(v / a.steps, 4) for k, v in acc.items()}}
 res["stats_mean"]["ms_overhead_host_clock"] = round(res["stats_mean"]["ms_wall"] - res["stats_mean"]["ms_phase1_span"] - res["stats_mean"]["ms_phase2_span"], 4)
 if a.host:
