@@ -68,14 +68,60 @@ struct Step {
     double t_submit = 0, t_exchange0 = 0, t_exchange1 = 0, t_done = 0;
 };
 
+// The thread of a device onto the host cores of that device's NUMA node (sysfs; best effort: a box without the
+// entries, or a process already confined elsewhere, is left alone).  Eight threads that each spend a step in
+// launches and polling must not pile onto one socket.
+void pin_to_device_numa(int device)
+{
+    char bus[32] = {};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return;
+    for (char &ch : bus)
+        if (ch >= 'A' && ch <= 'F') ch = (char)(ch - 'A' + 'a');
+    char path[128];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    const int got = std::fscanf(f, "%d", &node);
+    std::fclose(f);
+    if (got != 1 || node < 0) return;
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = std::fopen(path, "r");
+    if (!f) return;
+    char list[4096] = {};
+    const bool ok = std::fgets(list, sizeof(list), f) != nullptr;
+    std::fclose(f);
+    if (!ok) return;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    int n_want = 0;
+    for (const char *s = list; *s;) {   // the kernel's cpulist format: "0-3,8,10-11"
+        char *end = nullptr;
+        const long a = std::strtol(s, &end, 10);
+        if (end == s) break;
+        long b = a;
+        if (*end == '-') b = std::strtol(end + 1, &end, 10);
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++)
+            if (cpu >= 0 && CPU_ISSET(cpu, &allowed)) {
+                CPU_SET(cpu, &want);
+                n_want++;
+            }
+        s = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    if (n_want > 0) (void)sched_setaffinity(0, sizeof(want), &want);
+}
+
 // The threads that score a capture's records side by side (adsb_replay_host.h: ParallelReplay).  A job is a stage of
 // one capture's replay -- parts handed out by a counter to whoever is awake, the caller included -- and is done when
 // every part is; a thread that wakes up late finds the counter of ITS job used up and goes back to waiting.
 class ReplayPool {
   public:
-    explicit ReplayPool(int workers)
+    // (worker k runs on the host cores of devices[k % n]'s NUMA node: the records it reads sit in that node's memory)
+    ReplayPool(int workers, const std::vector<int> &devices)
     {
-        for (int k = 0; k < workers; k++) th_.emplace_back([this] { work(); });
+        for (int k = 0; k < workers; k++) th_.emplace_back([this, k, dev = devices[(size_t)k % devices.size()]] { work(k, dev); });
     }
     ~ReplayPool()
     {
@@ -94,13 +140,15 @@ class ReplayPool {
         job->pr = &pr;
         job->stage = stage;
         job->parts = pr.parts();
+        job->claimed.reset(new std::atomic<uint8_t>[(size_t)job->parts]);
+        for (int i = 0; i < job->parts; i++) job->claimed[(size_t)i].store(0, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(mu_);
             job_ = job;
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        take(*job);
+        take(*job, (int)th_.size());
         while (job->done.load(std::memory_order_acquire) < job->parts) __builtin_ia32_pause();
     }
 
@@ -109,19 +157,26 @@ class ReplayPool {
         ParallelReplay *pr = nullptr;
         void (ParallelReplay::*stage)(int) = nullptr;
         int parts = 0;
-        std::atomic<int> next{0}, done{0};
+        std::unique_ptr<std::atomic<uint8_t>[]> claimed;
+        std::atomic<int> done{0};
     };
-    static void take(Job &job)
+    // Thread `me` of T takes parts me, me + T, ... first -- the same ones in both stages of a capture, so the second
+    // stage finds its records in the cache the first left them in -- and then whatever nobody has claimed (a thread
+    // that woke up late, or is not running at all, holds nobody up).
+    void take(Job &job, int me) const
     {
-        for (;;) {
-            const int i = job.next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= job.parts) return;
+        const int T = threads();
+        auto claim = [&](int i) {
+            if (job.claimed[(size_t)i].exchange(1, std::memory_order_acq_rel)) return;
             (job.pr->*job.stage)(i);
             job.done.fetch_add(1, std::memory_order_release);
-        }
+        };
+        for (int i = me; i < job.parts; i += T) claim(i);
+        for (int i = 0; i < job.parts; i++) claim(i);
     }
-    void work()
+    void work(int me, int device)
     {
+        pin_to_device_numa(device);
         uint64_t seen = 0;
         for (;;) {
             // a capture's second stage follows its first within microseconds, a busy stream's next capture within a
@@ -137,7 +192,7 @@ class ReplayPool {
                 if (stop_) return;
                 job = job_;
             }
-            if (job) take(*job);
+            if (job) take(*job, me);
         }
     }
     std::vector<std::thread> th_;
@@ -190,54 +245,12 @@ struct adsb_multi {
     ParallelReplay parallel;
     uint64_t parallel_scored = 0;
     size_t parallel_min = kParallelReplayMin;
+#ifdef ADSB_TUNING
+    double t_stage[5] = {};   // plan, scan, merge, score, finish (ADSB_HOST_TIMES=1: printed at destroy)
+#endif
 };
 
 namespace {
-
-// The thread of a device onto the host cores of that device's NUMA node (sysfs; best effort: a box without the
-// entries, or a process already confined elsewhere, is left alone).  Eight threads that each spend a step in
-// launches and polling must not pile onto one socket.
-void pin_to_device_numa(int device)
-{
-    char bus[32] = {};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return;
-    for (char &ch : bus)
-        if (ch >= 'A' && ch <= 'F') ch = (char)(ch - 'A' + 'a');
-    char path[128];
-    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
-    FILE *f = std::fopen(path, "r");
-    if (!f) return;
-    int node = -1;
-    const int got = std::fscanf(f, "%d", &node);
-    std::fclose(f);
-    if (got != 1 || node < 0) return;
-    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
-    f = std::fopen(path, "r");
-    if (!f) return;
-    char list[4096] = {};
-    const bool ok = std::fgets(list, sizeof(list), f) != nullptr;
-    std::fclose(f);
-    if (!ok) return;
-    cpu_set_t allowed, want;
-    CPU_ZERO(&want);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
-    int n_want = 0;
-    for (const char *s = list; *s;) {   // the kernel's cpulist format: "0-3,8,10-11"
-        char *end = nullptr;
-        const long a = std::strtol(s, &end, 10);
-        if (end == s) break;
-        long b = a;
-        if (*end == '-') b = std::strtol(end + 1, &end, 10);
-        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++)
-            if (cpu >= 0 && CPU_ISSET(cpu, &allowed)) {
-                CPU_SET(cpu, &want);
-                n_want++;
-            }
-        s = *end == ',' ? end + 1 : end;
-        if (*end != ',') break;
-    }
-    if (n_want > 0) (void)sched_setaffinity(0, sizeof(want), &want);
-}
 
 void push_cmd(adsb_multi::Dev &d, Cmd c)
 {
@@ -461,7 +474,9 @@ int submit_capture(adsb_multi *m, const void *const *device_iq, const int16_t *h
     return ADSB_OK;
 }
 
-int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out)
+// (direct: the caller's own array -- a capture scored by several threads goes straight into it when it fits, *direct_n then
+// says how many messages it got and `out` stays empty)
+int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct = nullptr, size_t direct_cap = 0, size_t *direct_n = nullptr)
 {
     if (m->collected == m->submitted) return ADSB_ERR_INVALID;
     Step &s = m->step[m->collected % kMultiSteps];
@@ -501,6 +516,7 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out)
         p2_max = std::max(p2_max, sd.t_p2_done - sd.t_p2_issue);
     }
     const double tr0 = now_s();
+    bool direct_done = false;
     if (rc == ADSB_OK) {
         // the shards are contiguous ascending buffer ranges, each in replay order (its device thread saw to that):
         // device by device IS global (buffer, j, try_phase) order
@@ -510,21 +526,49 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out)
             // filter as it was plus the positions at which the capture's new addresses enter it (adsb_replay_host.h)
             if (!m->pool) {
                 const unsigned hw = std::thread::hardware_concurrency();
-                m->pool.reset(new ReplayPool((int)std::min(6u, std::max(1u, hw / 4))));
+                std::vector<int> devs;
+                for (auto &d : m->dev) devs.push_back(d->device);
+                int workers = (int)std::min(6u, std::max(1u, hw / 4));
+                if (const char *e = tuning_env("ADSB_POOL_WORKERS")) workers = std::max(1, std::atoi(e));   // (tuning build only)
+                m->pool.reset(new ReplayPool(workers, devs));
             }
             std::vector<RecordRun> runs;
             for (int k = 0; k < m->n; k++)
                 if (s.dev[(size_t)k].n_rec) runs.push_back({s.dev[(size_t)k].rec, s.dev[(size_t)k].n_rec, s.dev[(size_t)k].chunk_base});
             ParallelReplay &pr = m->parallel;
+#ifdef ADSB_TUNING
+            double t[6] = {now_s()};
+#define STAGE(k) t[k] = now_s()
+#else
+#define STAGE(k) (void)0
+#endif
             if (pr.plan(m->filter, m->crc, runs, 4 * m->pool->threads(), true)) {
+                STAGE(1);
                 m->pool->run(pr, &ParallelReplay::scan_part);
+                STAGE(2);
                 if (pr.merge()) {
+                    STAGE(3);
                     m->pool->run(pr, &ParallelReplay::score_part);
-                    pr.finish(m->filter, out);
+                    STAGE(4);
+                    const size_t n_msgs = pr.message_count();
+                    if (direct && direct_n && out.empty() && n_msgs <= direct_cap) {
+                        pr.copy_to(direct);
+                        m->pool->run(pr, &ParallelReplay::copy_part);
+                        pr.apply_adds(m->filter);
+                        *direct_n = n_msgs;
+                        direct_done = true;
+                    } else {
+                        pr.finish(m->filter, out);
+                    }
+                    STAGE(5);
                     m->parallel_scored++;
                     done = true;
+#ifdef ADSB_TUNING
+                    for (int k = 0; k < 5; k++) m->t_stage[k] += t[k + 1] - t[k];
+#endif
                 }
             }
+#undef STAGE
         }
         if (!done)
             for (int k = 0; k < m->n; k++) {
@@ -533,7 +577,7 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out)
             }
     }
     const double tr1 = now_s();
-    st.n_messages = out.size();
+    st.n_messages = direct_done ? *direct_n : out.size();
     st.ms_wall = (float)((s.t_done - s.t_submit) * 1e3);
     st.ms_phase1_max = (float)(p1_max * 1e3);
     st.ms_phase2_max = (float)(p2_max * 1e3);
@@ -579,7 +623,13 @@ int adsb_multi_create(adsb_multi **out, const int *devices, int n_devices, size_
         auto d = std::make_unique<adsb_multi::Dev>();
         d->index = k;
         d->device = devices[k];
-        const int rc = adsb_create(&d->ctx, devices[k], max_chunks_per_device);
+        // (created by a thread on the device's NUMA node: the context's pinned host memory -- where its records land and
+        // the replay reads them -- is then that node's, whichever node the caller runs on)
+        int rc = ADSB_ERR_HIP;
+        std::thread([&] {
+            pin_to_device_numa(devices[k]);
+            rc = adsb_create(&d->ctx, devices[k], max_chunks_per_device);
+        }).join();
         if (rc != ADSB_OK) {
             for (auto &e : m->dev) adsb_destroy(e->ctx);
             delete m;
@@ -603,6 +653,12 @@ void adsb_multi_destroy(adsb_multi *m)
         drop.clear();
         (void)collect_capture(m, drop);
     }
+#ifdef ADSB_TUNING
+    if (tuning_env("ADSB_HOST_TIMES") && m->parallel_scored)
+        std::fprintf(stderr, "adsb_multi parallel replay: %llu captures; us per capture: plan %.1f, scan %.1f, merge %.1f, score %.1f, finish %.1f\n",
+                     (unsigned long long)m->parallel_scored, m->t_stage[0] / m->parallel_scored * 1e6, m->t_stage[1] / m->parallel_scored * 1e6,
+                     m->t_stage[2] / m->parallel_scored * 1e6, m->t_stage[3] / m->parallel_scored * 1e6, m->t_stage[4] / m->parallel_scored * 1e6);
+#endif
     for (auto &d : m->dev) push_cmd(*d, Cmd{Cmd::kStop, 0});
     for (auto &d : m->dev)
         if (d->th.joinable()) d->th.join();
@@ -694,7 +750,14 @@ int adsb_multi_collect(adsb_multi *m, adsb_msg *out, size_t cap, size_t *n_out)
 {
     if (!m || (!out && cap)) return ADSB_ERR_INVALID;
     m->msgs.clear();
-    if (int rc = collect_capture(m, m->msgs)) return rc;
+    size_t direct_n = ~(size_t)0;
+    if (int rc = collect_capture(m, m->msgs, out, cap, &direct_n)) return rc;
+    if (direct_n != ~(size_t)0) {   // (the messages are in `out` already)
+        if (n_out) *n_out = direct_n;
+        m->has_undelivered = false;
+        m->undelivered.clear();
+        return ADSB_OK;
+    }
     return deliver_multi(m, m->msgs, out, cap, n_out);
 }
 
@@ -705,7 +768,14 @@ int adsb_multi_demod_iq_device(adsb_multi *m, const void *const *device_iq, cons
     if (m->submitted != m->collected) return ADSB_ERR_BUSY;
     if (int rc = submit_capture(m, device_iq, nullptr, false, n_samples)) return rc;
     m->msgs.clear();
-    if (int rc = collect_capture(m, m->msgs)) return rc;
+    size_t direct_n = ~(size_t)0;
+    if (int rc = collect_capture(m, m->msgs, out, cap, &direct_n)) return rc;
+    if (direct_n != ~(size_t)0) {   // (the messages are in `out` already)
+        if (n_out) *n_out = direct_n;
+        m->has_undelivered = false;
+        m->undelivered.clear();
+        return ADSB_OK;
+    }
     return deliver_multi(m, m->msgs, out, cap, n_out);
 }
 

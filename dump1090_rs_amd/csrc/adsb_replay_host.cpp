@@ -4,6 +4,8 @@
 // adsb_selftest_crc_table, adsb_strerror).  No HIP in this unit: besides the library build it is compiled by plain
 // g++ with -fsanitize=address,undefined and fed every trial the CPU checker slices plus adversarial records
 // (tests/test_host_sanitizers.py) -- the GPU pool offers no device sanitizer, the host side needs none.
+#include <immintrin.h>
+
 #include <thread>
 
 #include "adsb_replay_host.h"
@@ -140,9 +142,10 @@ inline uint32_t record_residual(const Crc24 &crc, const TrialRecord &r)
     return (r.pad & 1) ? (uint32_t)(r.power >> 40) : crc.residual(r.msg, (r.msg[0] & 0x80) ? 14 : 7);
 }
 
-inline ParallelReplay::Pos global_pos(const TrialRecord &r, uint64_t chunk_offset)
+// (chunk_offset + chunk, j, try_phase) of a record, for comparing the end of one run with the start of the next
+inline unsigned __int128 global_key(const TrialRecord &r, uint64_t chunk_offset)
 {
-    return (ParallelReplay::Pos)(chunk_offset + r.chunk) << 32 | (uint32_t)((r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24));
+    return (unsigned __int128)(chunk_offset + r.chunk) << 32 | (uint32_t)((r.j_tp & 0xFFFFFFu) << 8 | (r.j_tp >> 24));
 }
 
 // the filter as it was when the capture began + the first adders: what score_modes_message asks at `now`
@@ -177,7 +180,7 @@ void replay(IcaoFilter &filter, const Crc24 &crc, const TrialRecord *rec, size_t
 void ParallelReplay::FirstAdds::reset(uint32_t capacity_pow2)
 {
     key.assign(capacity_pow2, 0u);
-    pos.assign(capacity_pow2, ~(Pos)0);
+    pos.assign(capacity_pow2, ~(Pos)0);   // (what get() answers for an absent value)
     mask = capacity_pow2 - 1;
     used = 0;
 }
@@ -200,11 +203,20 @@ void ParallelReplay::FirstAdds::put_min(uint32_t value, Pos p)
     if (p < pos[h]) pos[h] = p;
 }
 
+bool ParallelReplay::FirstAdds::put_first(uint32_t value, Pos p)
+{
+    uint32_t h = (value * 2654435761u) >> 7 & mask;
+    while (key[h] && key[h] != value + 1) h = (h + 1) & mask;
+    if (key[h]) return false;
+    put_min(value, p);   // (may grow the table)
+    return true;
+}
+
 ParallelReplay::Pos ParallelReplay::FirstAdds::get(uint32_t value) const
 {
     uint32_t h = (value * 2654435761u) >> 7 & mask;
     while (key[h] && key[h] != value + 1) h = (h + 1) & mask;
-    return key[h] ? pos[h] : ~(Pos)0;
+    return pos[h];   // (an empty slot holds ~0)
 }
 
 bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order)
@@ -218,7 +230,7 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
     }
     new_values_.clear();
     size_t total = 0;
-    Pos last = 0;
+    unsigned __int128 last = 0;
     bool first = true;
     for (const RecordRun &r : runs) {
         total += r.n;
@@ -226,8 +238,8 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
         // in replay order throughout: inside every run (unless the caller has seen to that), and from one run to the next
         for (size_t i = 1; i < r.n && !runs_in_order; i++)
             if (replay_key(r.rec[i - 1]) > replay_key(r.rec[i])) return false;
-        if (!first && global_pos(r.rec[0], r.chunk_offset) < last) return false;
-        last = global_pos(r.rec[r.n - 1], r.chunk_offset);
+        if (!first && global_key(r.rec[0], r.chunk_offset) < last) return false;
+        last = global_key(r.rec[r.n - 1], r.chunk_offset);
         first = false;
     }
     if (parts < 2 || total < (size_t)parts) return false;
@@ -235,6 +247,7 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
     n_records_ = total;
     const size_t per = (total + (size_t)parts - 1) / (size_t)parts;
     size_t k = 0, in_part = 0;
+    Pos number = 0;
     for (const RecordRun &r : runs) {
         size_t at = 0;
         while (at < r.n) {
@@ -242,7 +255,8 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
             // a position's trial phases stay together: the cut moves to the next (chunk, j)
             size_t end = at + take;
             while (end < r.n && (replay_key(r.rec[end]) >> 8) == (replay_key(r.rec[end - 1]) >> 8)) end++;
-            part_[k].runs.push_back({r.rec + at, end - at, r.chunk_offset});
+            part_[k].runs.push_back({{r.rec + at, end - at, r.chunk_offset}, number});
+            number += end - at;
             in_part += end - at;
             at = end;
             if (in_part >= per && k + 1 < part_.size()) {
@@ -257,36 +271,44 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
 void ParallelReplay::scan_part(int i)
 {
     Part &p = part_[(size_t)i];
-    p.adds.reset(1024);
-    p.twice = false;
-    for (const RecordRun &run : p.runs)
-        for (size_t q = 0; q < run.n; q++) {
-            const TrialRecord &r = run.rec[q];
-            // (two records of one (buffer, j, try_phase): the device never makes them -- a trial is one hit -- but a
-            // caller's own records may; the second would find what the first added, and a position cannot say that)
-            if (q && replay_key(run.rec[q - 1]) == replay_key(r)) p.twice = true;
+    // (worked on in locals and handed back at the end: the vectors' own size fields are written on every insertion)
+    FirstAdds adds = std::move(p.adds);
+    std::vector<std::pair<uint32_t, Pos>> found = std::move(p.found);
+    adds.reset(256);
+    found.clear();
+    uint32_t last_value = ~0u;   // (a frame leaves a record per trial phase that decodes it: the same value several times running)
+    for (const Piece &piece : p.runs)
+        for (size_t q = 0; q < piece.run.n; q++) {
+            const TrialRecord &r = piece.run.rec[q];
             const uint32_t df = r.msg[0] >> 3;
             if (df != 17 && df != 18 && df != 11) continue;
             if (record_residual(*crc_, r) != 0) continue;   // mod.rs:80-84 (IID 0: the whole residual is zero), :97-99
             const uint32_t addr = uint32_t(r.msg[1]) << 16 | uint32_t(r.msg[2]) << 8 | r.msg[3];
-            p.adds.put_min(df == 18 ? (addr | IcaoFilter::kAdsbNt) : addr, global_pos(r, run.chunk_offset));
+            const uint32_t value = df == 18 ? (addr | IcaoFilter::kAdsbNt) : addr;
+            if (value == last_value) continue;
+            last_value = value;
+            if (adds.put_first(value, piece.first + q)) found.push_back({value, piece.first + q});   // (in order: the first seen is the part's first adder)
         }
+    p.adds = std::move(adds);
+    p.found = std::move(found);
 }
 
 bool ParallelReplay::merge()
 {
     uint32_t total = 0;
-    for (const Part &p : part_) {
-        if (p.twice) return false;
-        total += p.adds.used;
-    }
-    uint32_t cap = 1024;
+    for (const Part &p : part_) total = std::max(total, (uint32_t)p.found.size());   // (the parts mostly find the same values)
+    uint32_t cap = 256;
     while (cap < 4 * total) cap <<= 1;
-    all_.reset(cap);
+    all_.reset(cap);   // (grows by itself)
     for (const Part &p : part_)
-        for (uint32_t i = 0; i <= p.adds.mask; i++)
-            if (p.adds.key[i]) all_.put_min(p.adds.key[i] - 1, p.adds.pos[i]);
+        for (const auto &f : p.found) all_.put_min(f.first, f.second);
     // what will newly enter the table, and when
+    size_t held = 0;
+    std::vector<uint32_t> tagged;   // the DF18 values the table holds already
+    for (uint32_t v : filter_->table()) {
+        held += v != 0;
+        if (v & IcaoFilter::kAdsbNt) tagged.push_back(v);
+    }
     new_values_.clear();
     for (uint32_t i = 0; i <= all_.mask; i++) {
         if (!all_.key[i]) continue;
@@ -297,16 +319,12 @@ bool ParallelReplay::merge()
             // knowledge only grows, so that is its first record or none
             const uint32_t addr = value & 0xFFFFFFu;
             if (filter_->test(addr) || all_.get(addr) < at) continue;
-            bool held = false;   // (the tagged value itself may be in the table from an earlier capture)
-            for (uint32_t v : filter_->table()) held = held || v == value;
-            if (!held) new_values_.push_back({at, value});
+            if (std::find(tagged.begin(), tagged.end(), value) == tagged.end()) new_values_.push_back({at, value});
         } else if (!filter_->test(value)) {
             new_values_.push_back({at, value});
         }
     }
     std::sort(new_values_.begin(), new_values_.end());
-    size_t held = 0;
-    for (uint32_t v : filter_->table()) held += v != 0;
     // add() gives up on a full table and test() then walks all of it: membership stops being a set's
     return held + new_values_.size() + 64 < IcaoFilter::kSize;
 }
@@ -314,16 +332,48 @@ bool ParallelReplay::merge()
 void ParallelReplay::score_part(int i)
 {
     Part &p = part_[(size_t)i];
-    p.out.clear();
+    std::vector<adsb_msg> out = std::move(p.out);   // (see scan_part)
+    out.clear();
     size_t mine = 0;
-    for (const RecordRun &run : p.runs) mine += run.n;
-    p.out.reserve(mine / 2);   // (a frame leaves ~3 records)
+    for (const Piece &piece : p.runs) mine += piece.run.n;
+    out.reserve(mine / 2);   // (a frame leaves ~3 records)
     FilterView view{*filter_, all_};
-    for (const RecordRun &run : p.runs) {
-        const TrialRecord *rec = run.rec;
-        replay_in_order(view, *crc_, run.n, run.chunk_offset, p.out, [&](size_t q) -> const TrialRecord & { return rec[q]; },
-                        [&](const TrialRecord &r) { view.now = global_pos(r, run.chunk_offset); });
+    for (const Piece &piece : p.runs) {
+        const TrialRecord *rec = piece.run.rec;
+        replay_in_order(view, *crc_, piece.run.n, piece.run.chunk_offset, out, [&](size_t q) -> const TrialRecord & { return rec[q]; },
+                        [&](const TrialRecord &r) { view.now = piece.first + (Pos)(&r - rec); });
     }
+    p.out = std::move(out);
+}
+
+size_t ParallelReplay::message_count() const
+{
+    size_t n = 0;
+    for (const Part &p : part_) n += p.out.size();
+    return n;
+}
+
+void ParallelReplay::copy_to(adsb_msg *dst)
+{
+    dst_ = dst;
+    size_t at = 0;
+    for (Part &p : part_) {
+        p.out_at = at;
+        at += p.out.size();
+    }
+}
+
+void ParallelReplay::copy_part(int i)
+{
+    const Part &p = part_[(size_t)i];
+    static_assert(sizeof(adsb_msg) % 8 == 0 && alignof(adsb_msg) >= 8, "messages are copied as 8-byte words");
+    // (not through the cache: the destination's lines are in the reader's, and taking them over one by one is what a
+    // plain copy from here would spend its time on)
+    const long long *src = reinterpret_cast<const long long *>(p.out.data());
+    long long *dst = reinterpret_cast<long long *>(dst_ + p.out_at);
+    const size_t words = p.out.size() * (sizeof(adsb_msg) / 8);
+    for (size_t w = 0; w < words; w++) _mm_stream_si64(dst + w, src[w]);
+    _mm_sfence();
 }
 
 void ParallelReplay::apply_adds(IcaoFilter &filter) const
@@ -486,6 +536,15 @@ int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *reco
         parallel = pr.merge();
         if (parallel) {
             fan_out(&ParallelReplay::score_part);
+            if (pr.message_count() <= cap && (n & 1)) {   // (either way out: straight into the caller's array, or through a list)
+                pr.copy_to(out);
+                fan_out(&ParallelReplay::copy_part);
+                pr.apply_adds(filter);
+                if (went_parallel) *went_parallel = 1;
+                if (n_out) *n_out = pr.message_count();
+                filter.store(filter_table);
+                return ADSB_OK;
+            }
             pr.finish(filter, msgs);
         }
     }

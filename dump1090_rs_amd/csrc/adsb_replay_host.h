@@ -32,12 +32,12 @@ bool sort_records(const TrialRecord *rec, size_t n, std::vector<TrialRecord> &so
 // grows, and WHEN a value enters it is a property of the records alone: a value is added by the first record in replay
 // order that can add it -- a DF17 or a DF11 / IID 0 with a clean CRC adds its address whenever the filter does not
 // hold it, whether or not the trial wins its position (the reference scores all five phases, mod.rs is called from
-// demod_2400.rs:158-182).  So "is address a in the filter when the record at position p is scored" is
+// demod_2400.rs:158-182).  So "is address a in the filter when record number p (in replay order) is scored" is
 //     a was in the filter when the capture began   OR   first_adder(a) < p
 // and with the first adders known every record can be scored independently of every other:
 //   plan        the runs (each in replay order, ascending) are cut into parts at position boundaries
 //   scan_part   every part finds the first adder of each value it can add                    (parallel)
-//   merge       the parts' tables into one; refuses when two records share a position, or the 4096-slot table could fill up (then add() gives up,
+//   merge       the parts' tables into one; refuses when the 4096-slot table could fill up (then add() gives up,
 //               src/icao_filter.rs:46-62, and membership is no longer a set's: the caller replays serially)
 //   score_part  every part scores its records against (filter as it was, first adders)        (parallel)
 //   finish      the parts' messages in order; the new values enter the filter in the order of their first adders,
@@ -60,32 +60,46 @@ class ParallelReplay {
     bool merge();
     void score_part(int i);
     void finish(IcaoFilter &filter, std::vector<adsb_msg> &out);
+    // ... or, instead of finish: the parts' messages straight to where they are wanted, every part by whoever holds it in
+    // its cache (message_count() of them from dst on; streaming stores: the destination is somebody else's to read),
+    // then apply_adds
+    size_t message_count() const;
+    void copy_to(adsb_msg *dst);
+    void copy_part(int i);
     // the parts' messages, for a caller that copies them out itself (in order: part 0, 1, ...)
     const std::vector<adsb_msg> &messages(int i) const { return part_[(size_t)i].out; }
     void apply_adds(IcaoFilter &filter) const;
 
-    typedef unsigned __int128 Pos;   // (chunk_offset + chunk) << 32 | j << 8 | try_phase
-    struct FirstAdds {               // open addressing, value -> position of its first adder
+    typedef uint64_t Pos;            // a record's number in replay order over all runs (two records of one (buffer, j,
+                                     // try_phase) -- the device never makes them, a caller's own records may -- keep theirs)
+    struct FirstAdds {               // open addressing, value -> number of its first adder
         std::vector<uint32_t> key;   // value + 1 (0: empty)
         std::vector<Pos> pos;
         uint32_t mask = 0, used = 0;
         void reset(uint32_t capacity_pow2);
         void put_min(uint32_t value, Pos p);
+        bool put_first(uint32_t value, Pos p);   // only when absent (records scanned in order: the first seen is the first)
         Pos get(uint32_t value) const;   // ~0 when absent
     };
 
   private:
-    struct Part {
-        std::vector<RecordRun> runs;
+    struct Piece {
+        RecordRun run;
+        Pos first;            // the number of run.rec[0]
+    };
+    struct alignas(128) Part {   // (a part has one writer at a time: no two parts in one cache line)
+        std::vector<Piece> runs;
         FirstAdds adds;
+        std::vector<std::pair<uint32_t, Pos>> found;   // what `adds` holds, as a list (for the merge)
         std::vector<adsb_msg> out;
-        bool twice = false;   // two records with one position: the plan is refused
+        size_t out_at = 0;    // copy_to: where the part's messages go
     };
     const IcaoFilter *filter_ = nullptr;
     const Crc24 *crc_ = nullptr;
     std::vector<Part> part_;
     FirstAdds all_;
     size_t n_records_ = 0;
+    adsb_msg *dst_ = nullptr;
     std::vector<std::pair<Pos, uint32_t>> new_values_;   // (first adder, value as added), in insertion order
 };
 

@@ -7,5 +7,5 @@ trap 'cp /tmp/rel.so dump1090_rs_amd/libadsb_hip.so' EXIT
 cp variants/lib_tune.so dump1090_rs_amd/libadsb_hip.so
 for n in 1 8; do for b in 64 5000 20000; do
   echo "== contexts $n, $b bursts per 512 buffers"
-  ADSB_HOST_TIMES=1 python tools/multi_steps.py --contexts $n --chunks 4096 --steps 12 --pipelined --bursts $b 2>&1 | grep -v amdgpu.ids | grep "device thread [07]:\|^{" | cut -c1-640
+  ADSB_HOST_TIMES=1 python tools/multi_steps.py --contexts $n --chunks 4096 --steps 12 --pipelined --bursts $b 2>&1 | grep -v amdgpu.ids | grep "device thread [07]:\|parallel replay\|^{" | cut -c1-640
 done; done
