@@ -232,8 +232,9 @@ struct adsb_ctx {
         hipStream_t scan_q = nullptr;
         uint32_t *h_addrs = nullptr, *h_addrs_dev = nullptr;   // the other shards' addresses, in mapped host memory
                                                                // (k_set_addresses reads them in place: no copy command)
-        bool fresh_list = false;  // phase 1 is the scan alone: it lists the addresses whose bit it set (ScanParams::fresh)
+        bool fresh_list = false;  // phase 1 is the scan alone: it lists the addresses its trials can add (ScanParams::fresh)
         uint32_t *h_fresh = nullptr, *h_fresh_dev = nullptr;   // ... here (mapped host memory, kShardAddrCap of them)
+        uint32_t *d_fresh_seen = nullptr;                      // ... each once: 2^24 bits, cleared in front of the scan
     } shard[kSlots];
     uint64_t shard_jobs = 0;      // shards begun (their scans alternate between the first two scan streams)
     uint32_t shard_fresh_cap = 0; // how many fresh addresses a shard may list before it falls back to reading them out of

@@ -101,7 +101,7 @@ struct Counters {
     uint32_t unordered;      // one-launch pass: a workgroup gave up waiting for the tiles before its own (bounded wait)
     uint32_t t_start[2];     // one-launch pass: the 100 MHz wall clock when its first workgroup started
     uint32_t bitmap_ready;   // one-launch pass behind an icao_flush: its first workgroup has cleared the (folded) bitmap
-    uint32_t n_fresh;        // shard phase 1 (ScanParams::fresh): address bits this scan found clear and set ...
+    uint32_t n_fresh;        // shard phase 1 (ScanParams::fresh): distinct addresses this scan's trials can add ...
     uint32_t fresh_sum;      // ... and the sum of those addresses (the host checks the list it reads against it)
     uint32_t tile_done[kFusedMaxTiles];  // one-launch pass: tile t's address bits and list entries are published
     uint32_t seg_ap[kApWaveSegs];    // entries in each wave's AP segment
@@ -213,13 +213,15 @@ struct ScanParams {
     int debug_stop;         // profiling only (ADSB_DEBUG_STOP): leave the fast scan after phase N
     unsigned long long *timeline;  // profiling only (ADSB_TIMELINE): per-phase clock stamps, or null
     uint32_t keep_counters; // records kernel: leave the counters and lists as they are (first phase of a shard)
-    // first phase of a shard of an adsb_multi (full bitmaps only: bit a IS address a): every address whose bit this
-    // scan finds clear and sets is appended here (mapped host memory) -- what the OTHER devices' supersets may lack.
-    // An address whose bit was set already has been handed to every device before (it was learned in an earlier
-    // capture, or came from the exchange), so the list is all the exchange needs: no records kernel, no per-record
-    // work on the host in the first phase.  Null everywhere else.
+    // first phase of a shard of an adsb_multi: every address a trial of this scan can add to the filter is appended
+    // here (mapped host memory), once -- fresh_seen, 2^24 bits of the shard's own, all clear when the scan starts, says
+    // which have been.  That list is all the exchange needs: no records kernel and no per-record work on the host in
+    // the first phase.  (Not "whose bit in `bitmap` was clear": the scans of consecutive captures overlap on two
+    // streams, and the later one may set an address's bit first -- the earlier capture's list would then lack an address
+    // its own second phase on the OTHER devices needs; found by the soak, tests/fuzz_gpu.py --multi.)  Null elsewhere.
     uint32_t *fresh;
     uint32_t fresh_cap;
+    uint32_t *fresh_seen;
     // carry-over mode (opt-in, not the reference's semantics): the 326-sample lead-in of a
     // buffer holds the samples that preceded it.  Buffers after the first take them from src
     // itself; the first takes them from `carry` (kCarrySamples IQ samples, the end of the

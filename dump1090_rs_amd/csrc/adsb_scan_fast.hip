@@ -635,11 +635,20 @@ __device__ __forceinline__ void trial_pass(const ScanParams &p, FastLds &s, HitF
         } else {
             if (learn) {
                 const uint32_t addr = trial_addr(tr);
-                // (a shard of an adsb_multi lists the addresses it is the first to see on this device: ScanParams::fresh)
-                if (bitmap_set(p.bitmap, p.bitmap_lg, addr) && p.fresh) {
-                    const uint32_t k = atomicAdd(&p.ctr->n_fresh, 1u);
-                    atomicAdd(&p.ctr->fresh_sum, addr);
-                    if (k < p.fresh_cap) p.fresh[k] = addr;
+                const bool bit_was_clear = bitmap_set(p.bitmap, p.bitmap_lg, addr);
+                // (a shard of an adsb_multi lists the addresses its trials can add, each once: ScanParams::fresh)
+                if (p.fresh) {
+                    const uint32_t bit = 1u << (addr & 31u);
+#ifdef ADSB_FRESH_BY_BITMAP   // the first version, kept to show the soak finds its hole (adsb_device.h: ScanParams::fresh)
+                    if (bit_was_clear) {
+#else
+                    (void)bit_was_clear;
+                    if ((atomicOr(&p.fresh_seen[addr >> 5], bit) & bit) == 0) {
+#endif
+                        const uint32_t k = atomicAdd(&p.ctr->n_fresh, 1u);
+                        atomicAdd(&p.ctr->fresh_sum, addr);
+                        if (k < p.fresh_cap) p.fresh[k] = addr;
+                    }
                 }
             }
         }

@@ -95,12 +95,14 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
         HIP_TRY(c, hipHostMalloc((void **)&job.h_addrs, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_addrs_dev, job.h_addrs, 0));
     }
-    // (adsb_multi's shards on full bitmaps, where bit a IS address a: the scan lists the addresses whose bit it set --
-    // all the exchange needs -- and phase 1 is the scan alone; adsb_device.h: ScanParams::fresh)
+    // (adsb_multi's shards in contexts of more than 16 buffers: the scan lists the addresses its trials can add -- all the
+    // exchange needs -- and phase 1 is the scan alone; adsb_device.h: ScanParams::fresh.  Contexts for passes of a few
+    // buffers read them out of their handful of records.)
     fresh_list = fresh_list && c->bitmap_lg == kFullBitmapLg;
     if (fresh_list && !job.h_fresh) {
         HIP_TRY(c, hipHostMalloc((void **)&job.h_fresh, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_fresh_dev, job.h_fresh, 0));
+        HIP_TRY(c, hipMalloc((void **)&job.d_fresh_seen, (size_t(1) << 24) / 8));
     }
     job.fresh_list = fresh_list;
     ScanParams p{};
@@ -139,6 +141,7 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
     p.keep_counters = 1;
     if (fresh_list) {
         p.fresh = job.h_fresh_dev;
+        p.fresh_seen = job.d_fresh_seen;
         p.fresh_cap = c->shard_fresh_cap ? std::min<uint32_t>(c->shard_fresh_cap, (uint32_t)kShardAddrCap) : (uint32_t)kShardAddrCap;
         // a dense stream's shards: hits straight into their buffers' buckets, the second phase's records in replay
         // order (enqueue_pass has the rules; only where phase 1 has no records kernel of its own to disturb the buckets)
@@ -189,6 +192,7 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
     if (job.ran) HIP_TRY(c, hipStreamWaitEvent(ss, sl.recorded, 0));
     if (fresh)
         if (int e = launch_reset(sl.d_ctr, p.bitmap, p.bitmap_lg, ss)) return fail(c, (hipError_t)e, "launch_reset");
+    if (fresh_list) HIP_TRY(c, hipMemsetAsync(job.d_fresh_seen, 0, (size_t(1) << 24) / 8, ss));
     if (int e = launch_scan(p, false, ss)) return fail(c, (hipError_t)e, "launch_scan");
     if (fresh_list) {
         if (int e = launch_shard_summary(p, ss)) return fail(c, (hipError_t)e, "launch_shard_summary");
@@ -229,8 +233,8 @@ int shard_phase_wait(adsb_ctx *c, int k)
     return ADSB_ERR_HIP;
 }
 
-// after phase 1 has landed: the addresses this shard's replay can add (or, from a fresh list, those of them this
-// device had not seen: what the other devices may lack), sorted, no duplicates
+// after phase 1 has landed: the addresses this shard's replay can add (from the list its scan made, or out of its
+// records), sorted, no duplicates
 int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
 {
     Slot &sl = c->slot[k];
@@ -259,8 +263,8 @@ int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
             }
             addrs.assign(job.h_fresh, job.h_fresh + n_fresh);
         } else {
-            // more new addresses than the list holds (a capture that teaches tens of thousands): the records of the
-            // self-validating hits after all, behind the scan, and the addresses out of those
+            // more aircraft than the list holds: the records of the self-validating hits after all, behind the scan, and
+            // the addresses out of those
             c->shard_fresh_fallbacks++;
             sl.seq = next_seq(c);
             sl.h_sum->seq = 0;

@@ -394,8 +394,8 @@ int adsb_selftest_gate_stages(adsb_ctx *ctx, const void *device_iq_re_im, size_t
 int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
 
 /* Test hooks for adsb_multi (0 = the default; results never depend on either; ADSB_ERR_BUSY while captures are in flight):
- * fresh_cap     a shard's scan lists the addresses it is the first to see on its device, at most this many (16384); a
- *               capture that teaches more falls back to reading them out of its trial records -- a small value lets a
+ * fresh_cap     a shard's scan lists the addresses its trials can add to the filter, at most this many (16384); a
+ *               capture with more aircraft falls back to reading them out of its trial records -- a small value lets a
  *               test take that fallback on purpose;
  * parallel_min  captures of at least this many trial records (8192) are scored by several host threads at once. */
 int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min);

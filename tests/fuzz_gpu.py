@@ -249,6 +249,12 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
     k = int(rng.choice([1, 2, 3, 5, 8]))
     devices = [int(rng.integers(0, n_dev)) if n_dev > 1 else 0 for _ in range(k)]
     per = int(rng.integers(1, 7))
+    big = rng.random() < 0.3
+    if big:   # contexts of more than 16 buffers: full bitmaps -- shards that list their fresh addresses as they scan, and hand
+        #       their records over in replay order once a capture has been dense (up to 11 bursts per buffer here)
+        k = int(rng.choice([1, 2, 3]))
+        devices = [int(rng.integers(0, n_dev)) if n_dev > 1 else 0 for _ in range(k)]
+        per = int(rng.integers(17, 21))
     icaos = [int(x) for x in rng.integers(1, 1 << 24, size=int(rng.integers(2, 24)))]
 
     def capture():
@@ -279,8 +285,9 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
 
     caps = [capture() for _ in range(int(rng.integers(2, 6)))]
     multi = MultiContext(devices, per)
-    if rng.random() < 0.5:   # half of the sequences: every capture scored by several host threads, whatever its size
-        multi.selftest_tune(parallel_min=1)
+    # half of the sequences: every capture scored by several host threads, whatever its size; some: a fresh-address list of
+    # two entries, so that shards fall back to reading the addresses out of their records
+    multi.selftest_tune(fresh_cap=2 if rng.random() < 0.25 else 0, parallel_min=1 if rng.random() < 0.5 else 0)
     orc = Oracle()
     steps = int(rng.integers(4, 12))
     plan = []
@@ -347,6 +354,9 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
         check(multi.collect(cap=1 << 18), pending.pop(0), "drain")
     modes[("multi", False)] = modes.get(("multi", False), 0) + 1
     modes[("multi:captures", False)] = modes.get(("multi:captures", False), 0) + steps
+    ctr = multi.selftest_counters()
+    for name in ("device_ordered_shards", "fresh_list_fallbacks"):
+        modes[("multi:" + name, False)] = modes.get(("multi:" + name, False), 0) + int(ctr[name])
     modes[("multi:parallel_replays", False)] = modes.get(("multi:parallel_replays", False), 0) + int(multi.selftest_counters()["parallel_scored_captures"])
     modes[("multi:host_submits", False)] = modes.get(("multi:host_submits", False), 0) + sum(f in ("submit_host", "submit_pinned") for _, _, f, _ in plan)
     multi.close()

@@ -299,8 +299,8 @@ def test_captures_scored_by_several_host_threads_equal_the_serial_replay(hip_lib
 
 
 def test_a_capture_that_teaches_more_addresses_than_the_fresh_list_holds(hip_lib, oracle_mod):
-    """A shard's scan lists the addresses it is the first to see on its device (all the exchange needs); a capture
-    with more new aircraft than the list holds reads them out of its trial records instead.  With the list cut to
+    """A shard's scan lists the addresses its trials can add to the filter (all the exchange needs); a capture
+    with more aircraft than the list holds reads them out of its trial records instead.  With the list cut to
     three entries every shard of these captures takes that path, sparse and dense (device-ordered) ones, pipelined,
     with and without a flush: equal to the oracle, and to the same captures with the list at its full size."""
     import torch

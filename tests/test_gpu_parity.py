@@ -1358,6 +1358,23 @@ def test_randomised_soak_all_entry_points(hip_lib, oracle_mod):
     assert "300 cases identical" in r.stdout and "dense_pipeline=20" in r.stdout and "mixed_pipeline=40" in r.stdout and "multi=30" in r.stdout
 
 
+def test_soak_seed_that_found_the_overlapping_scans_hole(hip_lib, oracle_mod):
+    """Round 5: a shard's scan first listed "the addresses whose bit in the superset bitmap it set".  The scans of
+    consecutive captures overlap on two streams, so the LATER capture's scan could set an address's bit first, the
+    earlier capture's list then lacked it, and the other device's second phase of that earlier capture missed the
+    address/parity frames for it.  tests/fuzz_gpu.py --multi found it with this seed (sequence 45: two contexts of 20
+    buffers, four captures in flight); the list now has a seen-bitmap of its own per shard.  The first 60 sequences of
+    that seed, among them contexts of 17-20 buffers whose shards list their addresses while they scan, order their
+    records on the device once a capture was dense, and take the list-overflow fallback."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "4", "--seed", "27182", "--dense", "0", "--mixed", "0", "--multi", "60"],
+                       capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "4 cases identical" in r.stdout and "multi=60" in r.stdout and "multi:device_ordered_shards=" in r.stdout
+
+
 def test_four_host_threads_each_with_its_own_context(hip_lib, oracle_mod):
     """Contexts are independent streams (a context itself is not thread-safe): four host threads, each
     with its own context on the one GPU, run blocking and pipelined passes over different captures at
