@@ -1068,7 +1068,74 @@ def run_shard_single_process(env: Env, args):
         "shard_merge_equals_single_stream": bool(same), "parity_frames": len(want),
     }
     multi.close()
+    del parts
+    torch.cuda.empty_cache()
+    if not args.no_also:
+        result["busy_sky"] = busy_sky_leg(env, args, devices, ranges, per, total_chunks)
+        if result["busy_sky"]["shard_merge_equals_single_stream"] is False:
+            result["shard_merge_equals_single_stream"] = False
     return result
+
+
+def busy_sky_leg(env: Env, args, devices, ranges, per, total_chunks):
+    """The same capture size at config 5's density (5000 bursts per 512 buffers: ~180 frames a second of signal) through
+    adsb_multi_*: the shards list their addresses while they scan, order their records on the device, and the collector
+    scores a capture with several host threads at once -- checked against one context's single stream."""
+    torch = env.torch
+    from dump1090_rs_amd import Context, synth
+    from dump1090_rs_amd._lib import AdsbMsg
+    from dump1090_rs_amd.multi import MultiContext
+    import ctypes as C
+    shards = len(devices)
+    parts = [synth.make_iq_torch((b - a) * CHUNK, n_bursts=max(1, 5000 * (b - a) // 512), seed=synth.SEED_DEFAULT + 77 * r + 5,
+                                 device=torch.device("cuda", devices[r])) for r, (a, b) in enumerate(ranges)]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    cap = 1 << 20
+    out = (AdsbMsg * cap)()
+    with MultiContext(devices, per) as multi:
+        ptrs = (C.c_void_p * shards)(*[C.c_void_p(t.data_ptr()) for t in parts])
+        ns = (C.c_size_t * shards)(*[t.shape[0] for t in parts])
+        depth = multi.max_in_flight()
+
+        def run_steps(count):
+            frames, done = 0, 0
+            for i in range(count):
+                multi.icao_flush()
+                multi.submit_raw(ptrs, ns)
+                if i - done >= depth - 1:
+                    frames += multi.collect_raw(out, cap)
+                    done += 1
+            while done < count:
+                frames += multi.collect_raw(out, cap)
+                done += 1
+            return frames
+
+        run_steps(12)   # (the density of capture i is known when capture i + 1 starts; clocks are up from the sparse leg)
+        env.fence()
+        t0 = time.perf_counter()
+        frames = run_steps(args.steps)
+        env.fence()
+        elapsed = time.perf_counter() - t0
+        stats = multi.stats()
+        multi.icao_flush()
+        merged = multi.demod_iq_device([t.data_ptr() for t in parts], [t.shape[0] for t in parts], cap=cap)
+        counters = multi.selftest_counters()
+    whole = torch.cat([t.to(env.dev) for t in parts]) if shards > 1 else parts[0]
+    with Context(device=env.local_rank, max_chunks=min(512, total_chunks)) as solo:
+        solo.icao_flush()
+        want = solo.demod_iq_device(whole.data_ptr(), total_chunks * CHUNK, cap=cap)
+    key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
+    same = [key(m) for m in merged] == [key(m) for m in want]
+    n = total_chunks * CHUNK
+    return {"workload": f"the capture of {total_chunks} buffers with 5000 bursts per 512 buffers (config 5's density), {shards} shard(s), "
+                        f"{depth} captures in flight, an icao_flush per capture",
+            "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "steps": args.steps,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "frames_per_step": frames // max(1, args.steps),
+            "records_per_step": int(stats["n_records"]), "ms_replay_last_step": round(float(stats["ms_replay"]), 4),
+            "device_ordered_shards": int(counters["device_ordered_shards"]), "parallel_scored_captures": int(counters["parallel_scored_captures"]),
+            "shards_sorted_on_host": int(counters["shards_sorted_on_host"]),
+            "shard_merge_equals_single_stream": bool(same), "parity_frames": len(want)}
 
 
 # ------------------------------------------------------------------------------------------------
