@@ -113,96 +113,6 @@ void pin_to_device_numa(int device)
     if (n_want > 0) (void)sched_setaffinity(0, sizeof(want), &want);
 }
 
-// The threads that score a capture's records side by side (adsb_replay_host.h: ParallelReplay).  A job is a stage of
-// one capture's replay -- parts handed out by a counter to whoever is awake, the caller included -- and is done when
-// every part is; a thread that wakes up late finds the counter of ITS job used up and goes back to waiting.
-class ReplayPool {
-  public:
-    // (worker k runs on the host cores of devices[k % n]'s NUMA node: the records it reads sit in that node's memory)
-    ReplayPool(int workers, const std::vector<int> &devices)
-    {
-        for (int k = 0; k < workers; k++) th_.emplace_back([this, k, dev = devices[(size_t)k % devices.size()]] { work(k, dev); });
-    }
-    ~ReplayPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-            gen_.fetch_add(1, std::memory_order_release);
-        }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    int threads() const { return (int)th_.size() + 1; }
-    void run(ParallelReplay &pr, void (ParallelReplay::*stage)(int))
-    {
-        auto job = std::make_shared<Job>();
-        job->pr = &pr;
-        job->stage = stage;
-        job->parts = pr.parts();
-        job->claimed.reset(new std::atomic<uint8_t>[(size_t)job->parts]);
-        for (int i = 0; i < job->parts; i++) job->claimed[(size_t)i].store(0, std::memory_order_relaxed);
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            job_ = job;
-            gen_.fetch_add(1, std::memory_order_release);
-        }
-        cv_.notify_all();
-        take(*job, (int)th_.size());
-        while (job->done.load(std::memory_order_acquire) < job->parts) __builtin_ia32_pause();
-    }
-
-  private:
-    struct Job {
-        ParallelReplay *pr = nullptr;
-        void (ParallelReplay::*stage)(int) = nullptr;
-        int parts = 0;
-        std::unique_ptr<std::atomic<uint8_t>[]> claimed;
-        std::atomic<int> done{0};
-    };
-    // Thread `me` of T takes parts me, me + T, ... first -- the same ones in both stages of a capture, so the second
-    // stage finds its records in the cache the first left them in -- and then whatever nobody has claimed (a thread
-    // that woke up late, or is not running at all, holds nobody up).
-    void take(Job &job, int me) const
-    {
-        const int T = threads();
-        auto claim = [&](int i) {
-            if (job.claimed[(size_t)i].exchange(1, std::memory_order_acq_rel)) return;
-            (job.pr->*job.stage)(i);
-            job.done.fetch_add(1, std::memory_order_release);
-        };
-        for (int i = me; i < job.parts; i += T) claim(i);
-        for (int i = 0; i < job.parts; i++) claim(i);
-    }
-    void work(int me, int device)
-    {
-        pin_to_device_numa(device);
-        uint64_t seen = 0;
-        for (;;) {
-            // a capture's second stage follows its first within microseconds, a busy stream's next capture within a
-            // millisecond: stay hot that long, then sleep
-            const auto t0 = std::chrono::steady_clock::now();
-            while (gen_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500))
-                __builtin_ia32_pause();
-            std::shared_ptr<Job> job;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_.load(std::memory_order_relaxed) != seen; });
-                seen = gen_.load(std::memory_order_relaxed);
-                if (stop_) return;
-                job = job_;
-            }
-            if (job) take(*job, me);
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::atomic<uint64_t> gen_{0};
-    bool stop_ = false;
-    std::shared_ptr<Job> job_;
-};
-
 constexpr size_t kParallelReplayMin = 8192;   // records in a capture from which its replay is worth fanning out
 
 }  // namespace
@@ -530,7 +440,8 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
                 for (auto &d : m->dev) devs.push_back(d->device);
                 int workers = (int)std::min(6u, std::max(1u, hw / 4));
                 if (const char *e = tuning_env("ADSB_POOL_WORKERS")) workers = std::max(1, std::atoi(e));   // (tuning build only)
-                m->pool.reset(new ReplayPool(workers, devs));
+                // (worker k on the host cores of devices[k % n]'s NUMA node: the records it reads sit in that node's memory)
+                m->pool.reset(new ReplayPool(workers, [devs](int k) { pin_to_device_numa(devs[(size_t)k % devs.size()]); }));
             }
             std::vector<RecordRun> runs;
             for (int k = 0; k < m->n; k++)

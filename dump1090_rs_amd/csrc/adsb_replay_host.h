@@ -3,6 +3,13 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/adsb_hip.h"
@@ -101,6 +108,96 @@ class ParallelReplay {
     size_t n_records_ = 0;
     adsb_msg *dst_ = nullptr;
     std::vector<std::pair<Pos, uint32_t>> new_values_;   // (first adder, value as added), in insertion order
+};
+
+// The threads that score a capture's records side by side (adsb_replay_host.h: ParallelReplay).  A job is a stage of
+// one capture's replay -- parts handed out by a counter to whoever is awake, the caller included -- and is done when
+// every part is; a thread that wakes up late finds the counter of ITS job used up and goes back to waiting.
+class ReplayPool {
+  public:
+    // (on_start(k): run by worker k before anything else -- adsb_multi places it on a device's NUMA node)
+    explicit ReplayPool(int workers, std::function<void(int)> on_start = {})
+    {
+        for (int k = 0; k < workers; k++) th_.emplace_back([this, k, on_start] { work(k, on_start); });
+    }
+    ~ReplayPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int threads() const { return (int)th_.size() + 1; }
+    void run(ParallelReplay &pr, void (ParallelReplay::*stage)(int))
+    {
+        auto job = std::make_shared<Job>();
+        job->pr = &pr;
+        job->stage = stage;
+        job->parts = pr.parts();
+        job->claimed.reset(new std::atomic<uint8_t>[(size_t)job->parts]);
+        for (int i = 0; i < job->parts; i++) job->claimed[(size_t)i].store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = job;
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        take(*job, (int)th_.size());
+        while (job->done.load(std::memory_order_acquire) < job->parts) __builtin_ia32_pause();
+    }
+
+  private:
+    struct Job {
+        ParallelReplay *pr = nullptr;
+        void (ParallelReplay::*stage)(int) = nullptr;
+        int parts = 0;
+        std::unique_ptr<std::atomic<uint8_t>[]> claimed;
+        std::atomic<int> done{0};
+    };
+    // Thread `me` of T takes parts me, me + T, ... first -- the same ones in both stages of a capture, so the second
+    // stage finds its records in the cache the first left them in -- and then whatever nobody has claimed (a thread
+    // that woke up late, or is not running at all, holds nobody up).
+    void take(Job &job, int me) const
+    {
+        const int T = threads();
+        auto claim = [&](int i) {
+            if (job.claimed[(size_t)i].exchange(1, std::memory_order_acq_rel)) return;
+            (job.pr->*job.stage)(i);
+            job.done.fetch_add(1, std::memory_order_release);
+        };
+        for (int i = me; i < job.parts; i += T) claim(i);
+        for (int i = 0; i < job.parts; i++) claim(i);
+    }
+    void work(int me, const std::function<void(int)> &on_start)
+    {
+        if (on_start) on_start(me);
+        uint64_t seen = 0;
+        for (;;) {
+            // a capture's second stage follows its first within microseconds, a busy stream's next capture within a
+            // millisecond: stay hot that long, then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500))
+                __builtin_ia32_pause();
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_relaxed) != seen; });
+                seen = gen_.load(std::memory_order_relaxed);
+                if (stop_) return;
+                job = job_;
+            }
+            if (job) take(*job, me);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    bool stop_ = false;
+    std::shared_ptr<Job> job_;
 };
 
 // The sorted union of several sorted, duplicate-free address lists (the shards' learned addresses), appended to

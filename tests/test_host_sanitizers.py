@@ -272,3 +272,26 @@ def test_host_only_code_under_address_and_ub_sanitizers(oracle_mod):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0 and "sanitized host-only code ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_replay_pool_under_thread_sanitizer():
+    """The threads of the host replay (csrc/adsb_replay_host.h: ReplayPool + ParallelReplay -- jobs handed out by claim
+    flags, late wakers, parts handed back to the thread that had them, streamed copy-out) under -fsanitize=thread:
+    tests/replay_pool_tsan.cpp replays 300 random captures serially and through ONE pool, filters carried over and flushed,
+    2-41 parts on six threads; same messages, same table, no report.  CPU only, no oracle needed (serial against parallel;
+    the serial replay is pinned to the oracle above)."""
+    tsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    if not tsan or not Path(tsan).exists() or shutil.which("g++") is None:
+        pytest.skip("no libtsan / g++ in this environment")
+    exe = ROOT / "tests" / "replay_pool_tsan"
+    src = [ROOT / "tests" / "replay_pool_tsan.cpp", SRC]
+    hdrs = [SRC.parent / n for n in ("adsb_replay_host.h", "adsb_record.h", "mode_s_host.hpp")] + [ROOT / "include" / "adsb_hip.h"]
+    if not exe.exists() or exe.stat().st_mtime < max(p.stat().st_mtime for p in [*src, *hdrs]):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fsanitize=thread", "-pthread",
+                        *map(str, src), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), "300"], capture_output=True, text=True, timeout=900,
+                       env=dict(__import__("os").environ, TSAN_OPTIONS="halt_on_error=1"))
+    if "unexpected memory mapping" in r.stderr:   # (a kernel whose address-space layout this libtsan does not know)
+        pytest.skip("ThreadSanitizer cannot run on this kernel")
+    assert r.returncode == 0 and "replay pool ok: 300 captures" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
