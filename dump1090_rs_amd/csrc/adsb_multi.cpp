@@ -438,7 +438,9 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
                 const unsigned hw = std::thread::hardware_concurrency();
                 std::vector<int> devs;
                 for (auto &d : m->dev) devs.push_back(d->device);
-                int workers = (int)std::min(6u, std::max(1u, hw / 4));
+                // six threads beside the caller, two per device from four devices on (the records to score grow with the
+                // devices that found them), never more than a quarter of the host's cores
+                int workers = (int)std::min<unsigned>(std::max(6u, std::min(16u, 2u * (unsigned)m->dev.size())), std::max(1u, hw / 4));
                 if (const char *e = tuning_env("ADSB_POOL_WORKERS")) workers = std::max(1, std::atoi(e));   // (tuning build only)
                 // (worker k on the host cores of devices[k % n]'s NUMA node: the records it reads sit in that node's memory)
                 m->pool.reset(new ReplayPool(workers, [devs](int k) { pin_to_device_numa(devs[(size_t)k % devs.size()]); }));

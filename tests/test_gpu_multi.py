@@ -387,6 +387,37 @@ def test_a_shard_denser_than_the_lists_goes_buffer_by_buffer_and_stays_exact(hip
         assert [key(m) for m in multi.demod_iq(iq, cap=1 << 18)] == [want_key(w) for w in want]
 
 
+def test_a_dense_shard_with_one_overfull_buffer_bucket_goes_buffer_by_buffer(hip_lib, oracle_mod):
+    """Contexts of 20 buffers (full bitmaps: the scan lists the shard's addresses, a dense stream's shards put their hits
+    into per-buffer buckets): one buffer packed with back-to-back frames holds more hits than its bucket of 1024 while
+    no other list is anywhere near full.  That shard must be flagged and go through both phases buffer by buffer while
+    the other shard and the captures in flight around it go the usual way -- every capture equal to the oracle's stream."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    n = 40 * CHUNK
+    host = [synth.make_iq(n, n_bursts=3000, seed=6200 + k, n_icao=40) for k in range(4)]
+    packed = synth.noise_numpy(CHUNK, seed=78)
+    synth.add_bursts(packed, [synth.Burst(5 * (200 + 300 * q) + q % 5, 14000 + 10 * q, q % 16,
+                                          synth.df17_frame(0xA00000 + 0x101 * (q % 40), q)) for q in range(430)])
+    host[2][25 * CHUNK:26 * CHUNK] = packed               # shard 1 of the third capture
+    orc = oracle_mod.Oracle()
+    wants = [[want_key(x) for x in orc.demod_iq(h)[0]] for h in host]
+    with MultiContext([0] * 2, 20) as multi:
+        resident = [to_devices(h, multi, torch) for h in host]
+        multi.icao_flush()
+        gots = [multi.demod_iq_device(resident[0][1], resident[0][2], cap=1 << 16)]    # (tells the contexts how dense the stream is)
+        retries = []
+        for i in (1, 2, 3):
+            multi.submit_iq_device(resident[i][1], resident[i][2])
+        for i in (1, 2, 3):
+            gots.append(multi.collect(cap=1 << 16))
+            retries.append(multi.stats()["retries"])
+        assert retries == [0, 1, 0], retries                 # the overfull bucket did overflow, and only that shard
+        for i, (g, w) in enumerate(zip(gots, wants)):
+            assert [key(m) for m in g] == w, f"capture {i}"
+        assert multi.selftest_counters()["device_ordered_shards"] >= 5
+
+
 def test_output_array_too_small_and_misuse(hip_lib, oracle_mod):
     """ADSB_ERR_CAPACITY hands out the first `cap` messages and keeps the list (the capture is consumed: the
     filter has moved on); bad arguments are refused, never crash."""
