@@ -68,6 +68,21 @@ struct Step {
     double t_submit = 0, t_exchange0 = 0, t_exchange1 = 0, t_done = 0;
 };
 
+// CPUs this process can really use: its affinity mask, cut by the cgroup's CPU quota where there is one (cpu.max)
+int usable_cpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            n = std::min<long long>(n, std::max<long long>(1, quota / period));
+        std::fclose(f);
+    }
+    return std::max(1, n);
+}
+
 // The thread of a device onto the host cores of that device's NUMA node (sysfs; best effort: a box without the
 // entries, or a process already confined elsewhere, is left alone).  Eight threads that each spend a step in
 // launches and polling must not pile onto one socket.
@@ -441,6 +456,10 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
                 // six threads beside the caller, two per device from four devices on (the records to score grow with the
                 // devices that found them), never more than a quarter of the host's cores
                 int workers = (int)std::min<unsigned>(std::max(6u, std::min(16u, 2u * (unsigned)m->dev.size())), std::max(1u, hw / 4));
+                // ... nor more than the CPUs this process may use leave beside the device threads and the caller (a
+                // container's quota: threads beyond it only get the whole process throttled)
+                const int room = usable_cpus() - (int)m->dev.size() - 2;
+                workers = std::max(1, std::min(workers, room));
                 if (const char *e = tuning_env("ADSB_POOL_WORKERS")) workers = std::max(1, std::atoi(e));   // (tuning build only)
                 // (worker k on the host cores of devices[k % n]'s NUMA node: the records it reads sit in that node's memory)
                 m->pool.reset(new ReplayPool(workers, [devs](int k) { pin_to_device_numa(devs[(size_t)k % devs.size()]); }));
