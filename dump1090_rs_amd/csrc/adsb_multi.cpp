@@ -50,6 +50,8 @@ struct StepDev {   // one device's share of one capture
     const TrialRecord *rec = nullptr;
     size_t n_rec = 0;
     std::vector<TrialRecord> sorted;    // the shard's records in replay order (sorted by its device thread), when they were not
+    ParallelReplay::Adders adders;      // the first record of the shard that can add each value (the device thread's pass over
+    bool has_adders = false;            // its records, for shards of up to kDeviceThreadScanMax: the replay's scan stage, done)
     int rc = 0;
     adsb_stats st{};
     double t_p1_issue = 0, t_p1_done = 0, t_p2_issue = 0, t_p2_done = 0;
@@ -128,6 +130,9 @@ void pin_to_device_numa(int device)
     if (n_want > 0) (void)sched_setaffinity(0, sizeof(want), &want);
 }
 
+// a device thread scans its own shard for first adders up to this many records (~5 ns each, between two polls of its
+// device); a larger shard -- one device with a busy sky to itself -- is left to the pool's threads
+constexpr size_t kDeviceThreadScanMax = 49152;
 constexpr size_t kParallelReplayMin = 8192;   // records in a capture from which its replay is worth fanning out
 
 }  // namespace
@@ -313,6 +318,10 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
                 // (in replay order before they are handed over: the shards' sorts then run side by side, on the device
                 // threads, instead of one after the other on the caller's)
                 if (sd.rc == ADSB_OK && sd.n_rec > 1) SPENT(sort, if (sort_records(sd.rec, sd.n_rec, sd.sorted)) { sd.rec = sd.sorted.data(); m->shards_sorted_on_host.fetch_add(1, std::memory_order_relaxed); });
+                if (sd.rc == ADSB_OK && sd.n_rec <= kDeviceThreadScanMax) {
+                    SPENT(sort, first_adders(c->crc, sd.rec, sd.n_rec, sd.adders));
+                    sd.has_adders = true;
+                }
 #ifdef ADSB_TUNING
                 spent.captures++;
                 spent.n_rec += sd.n_rec;
@@ -465,8 +474,13 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
                 m->pool.reset(new ReplayPool(workers, [devs](int k) { pin_to_device_numa(devs[(size_t)k % devs.size()]); }));
             }
             std::vector<RecordRun> runs;
-            for (int k = 0; k < m->n; k++)
-                if (s.dev[(size_t)k].n_rec) runs.push_back({s.dev[(size_t)k].rec, s.dev[(size_t)k].n_rec, s.dev[(size_t)k].chunk_base});
+            std::vector<const ParallelReplay::Adders *> adders;
+            for (int k = 0; k < m->n; k++) {
+                const StepDev &sd = s.dev[(size_t)k];
+                if (!sd.n_rec) continue;
+                runs.push_back({sd.rec, sd.n_rec, sd.chunk_base});
+                adders.push_back(sd.has_adders ? &sd.adders : nullptr);
+            }
             ParallelReplay &pr = m->parallel;
 #ifdef ADSB_TUNING
             double t[6] = {now_s()};
@@ -474,9 +488,9 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
 #else
 #define STAGE(k) (void)0
 #endif
-            if (pr.plan(m->filter, m->crc, runs, 4 * m->pool->threads(), true)) {
+            if (pr.plan(m->filter, m->crc, runs, 4 * m->pool->threads(), true, &adders)) {
                 STAGE(1);
-                m->pool->run(pr, &ParallelReplay::scan_part);
+                if (pr.scan_needed()) m->pool->run(pr, &ParallelReplay::scan_part);
                 STAGE(2);
                 if (pr.merge()) {
                     STAGE(3);

@@ -219,7 +219,27 @@ ParallelReplay::Pos ParallelReplay::FirstAdds::get(uint32_t value) const
     return pos[h];   // (an empty slot holds ~0)
 }
 
-bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order)
+void first_adders(const Crc24 &crc, const TrialRecord *rec, size_t n, ParallelReplay::Adders &out)
+{
+    out.clear();
+    ParallelReplay::FirstAdds seen;
+    seen.reset(256);
+    uint32_t last_value = ~0u;
+    for (size_t q = 0; q < n; q++) {
+        const TrialRecord &r = rec[q];
+        const uint32_t df = r.msg[0] >> 3;
+        if (df != 17 && df != 18 && df != 11) continue;
+        if (record_residual(crc, r) != 0) continue;
+        const uint32_t addr = uint32_t(r.msg[1]) << 16 | uint32_t(r.msg[2]) << 8 | r.msg[3];
+        const uint32_t value = df == 18 ? (addr | IcaoFilter::kAdsbNt) : addr;
+        if (value == last_value) continue;
+        last_value = value;
+        if (seen.put_first(value, q)) out.push_back({value, (uint64_t)q});
+    }
+}
+
+bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order,
+                          const std::vector<const Adders *> *run_adders)
 {
     filter_ = &filter;
     crc_ = &crc;
@@ -229,6 +249,7 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
         p.out.clear();
     }
     new_values_.clear();
+    run_adders_.clear();
     size_t total = 0;
     unsigned __int128 last = 0;
     bool first = true;
@@ -245,6 +266,15 @@ bool ParallelReplay::plan(const IcaoFilter &filter, const Crc24 &crc, const std:
     if (parts < 2 || total < (size_t)parts) return false;
     part_.resize((size_t)parts);
     n_records_ = total;
+    if (run_adders && run_adders->size() == runs.size()) {
+        bool all = true;
+        for (size_t k = 0; k < runs.size(); k++) all = all && (runs[k].n == 0 || (*run_adders)[k] != nullptr);
+        Pos first_number = 0;
+        for (size_t k = 0; k < runs.size() && all; k++) {
+            if (runs[k].n) run_adders_.push_back({(*run_adders)[k], first_number});
+            first_number += runs[k].n;
+        }
+    }
     const size_t per = (total + (size_t)parts - 1) / (size_t)parts;
     size_t k = 0, in_part = 0;
     Pos number = 0;
@@ -296,12 +326,21 @@ void ParallelReplay::scan_part(int i)
 bool ParallelReplay::merge()
 {
     uint32_t total = 0;
-    for (const Part &p : part_) total = std::max(total, (uint32_t)p.found.size());   // (the parts mostly find the same values)
+    if (scan_needed()) {
+        for (const Part &p : part_) total = std::max(total, (uint32_t)p.found.size());   // (the parts mostly find the same values)
+    } else {
+        for (const auto &ra : run_adders_) total = std::max(total, (uint32_t)ra.first->size());
+    }
     uint32_t cap = 256;
     while (cap < 4 * total) cap <<= 1;
     all_.reset(cap);   // (grows by itself)
-    for (const Part &p : part_)
-        for (const auto &f : p.found) all_.put_min(f.first, f.second);
+    if (scan_needed()) {
+        for (const Part &p : part_)
+            for (const auto &f : p.found) all_.put_min(f.first, f.second);
+    } else {
+        for (const auto &ra : run_adders_)
+            for (const auto &f : *ra.first) all_.put_min(f.first, ra.second + f.second);
+    }
     // what will newly enter the table, and when
     size_t held = 0;
     std::vector<uint32_t> tagged;   // the DF18 values the table holds already
@@ -522,7 +561,16 @@ int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *reco
     }
     std::vector<adsb_msg> msgs;
     ParallelReplay pr;
-    bool parallel = pr.plan(filter, crc, rr, parts);
+    // (every other size: the runs bring their first adders along, as a device thread of adsb_multi hands them over)
+    std::vector<ParallelReplay::Adders> adders(rr.size());
+    std::vector<const ParallelReplay::Adders *> adders_of;
+    if (n & 2)
+        for (size_t k = 0; k < rr.size(); k++) {
+            first_adders(crc, rr[k].rec, rr[k].n, adders[k]);
+            adders_of.push_back(&adders[k]);
+        }
+    bool parallel = pr.plan(filter, crc, rr, parts, false, adders_of.empty() ? nullptr : &adders_of);
+    if (parallel && (n & 2) && pr.scan_needed()) return ADSB_ERR_INVALID;   // (the lists were complete: they must have been taken)
     if (parallel) {
         auto fan_out = [&](void (ParallelReplay::*stage)(int)) {
             std::vector<std::thread> th;
@@ -532,7 +580,7 @@ int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *reco
                 });
             for (auto &x : th) x.join();
         };
-        fan_out(&ParallelReplay::scan_part);
+        if (pr.scan_needed()) fan_out(&ParallelReplay::scan_part);
         parallel = pr.merge();
         if (parallel) {
             fan_out(&ParallelReplay::score_part);

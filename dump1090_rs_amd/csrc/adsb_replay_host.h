@@ -60,9 +60,13 @@ struct RecordRun {
 class ParallelReplay {
   public:
     // false: not worth it or not possible (too few records, a run out of order): replay serially
-    // (runs_in_order: the caller has checked every run's own order already)
-    bool plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order = false);
+    // (runs_in_order: the caller has checked every run's own order already.  run_adders: per run, what first_adders()
+    // found in it -- whoever had the run in its cache before has done the scan stage's work already, scan_needed() says no)
+    typedef std::vector<std::pair<uint32_t, uint64_t>> Adders;   // (value as added, index in the run of its first adder)
+    bool plan(const IcaoFilter &filter, const Crc24 &crc, const std::vector<RecordRun> &runs, int parts, bool runs_in_order = false,
+              const std::vector<const Adders *> *run_adders = nullptr);
     int parts() const { return (int)part_.size(); }
+    bool scan_needed() const { return run_adders_.empty(); }
     void scan_part(int i);
     bool merge();
     void score_part(int i);
@@ -107,8 +111,13 @@ class ParallelReplay {
     FirstAdds all_;
     size_t n_records_ = 0;
     adsb_msg *dst_ = nullptr;
+    std::vector<std::pair<const Adders *, Pos>> run_adders_;   // (the run's list, the number of the run's first record)
     std::vector<std::pair<Pos, uint32_t>> new_values_;   // (first adder, value as added), in insertion order
 };
+
+// The first record (by index) of a run in replay order that can add each value: what ParallelReplay's scan stage finds,
+// for one whole run (mode_s/mod.rs:80-84 DF11 / IID 0, :97-104 DF17 / DF18 with a clean CRC).
+void first_adders(const Crc24 &crc, const TrialRecord *rec, size_t n, ParallelReplay::Adders &out);
 
 // The threads that score a capture's records side by side (adsb_replay_host.h: ParallelReplay).  A job is a stage of
 // one capture's replay -- parts handed out by a counter to whoever is awake, the caller included -- and is done when

@@ -76,9 +76,16 @@ int main(int argc, char **argv)
         std::vector<adsb_msg> want, got;
         for (const RecordRun &r : runs) replay_sorted(serial, crc, r.rec, r.n, r.chunk_offset, want);
         const int parts = 2 + (int)(rng() % 40);
-        bool ok = pr.plan(parallel, crc, runs, parts, rng() & 1);
+        std::vector<ParallelReplay::Adders> adders(runs.size());
+        std::vector<const ParallelReplay::Adders *> adders_of;
+        if (rng() % 3 == 0)   // the runs bring their first adders along (a device thread's work in adsb_multi)
+            for (size_t k = 0; k < runs.size(); k++) {
+                first_adders(crc, runs[k].rec, runs[k].n, adders[k]);
+                adders_of.push_back(&adders[k]);
+            }
+        bool ok = pr.plan(parallel, crc, runs, parts, rng() & 1, adders_of.empty() ? nullptr : &adders_of);
         if (ok) {
-            pool.run(pr, &ParallelReplay::scan_part);
+            if (pr.scan_needed()) pool.run(pr, &ParallelReplay::scan_part);
             ok = pr.merge();
         }
         if (ok) {
