@@ -103,6 +103,29 @@ static int run_multi(int n_dev, int argc, char **argv)
     if (adsb_multi_get_stats(m, &ms) != ADSB_OK || ms.n_devices != (uint32_t)n_dev || ms.n_messages != n) rc = 1;
     printf("multi: %d devices, %zu frames, %llu records, %llu addresses exchanged\n", n_dev, n,
            (unsigned long long)ms.n_records, (unsigned long long)ms.n_addrs_exchanged);
+    /* the asynchronous host form out of pinned memory: the same capture three times in flight behind one flush each --
+     * adsb_multi_host_alloc / adsb_multi_submit_iq / adsb_multi_collect; every collect gives the blocking call's list */
+    {
+        void *pinned = NULL;
+        const size_t bytes = per * 2 * sizeof(int16_t) * (size_t)n_dev;
+        adsb_msg *again = malloc(sizeof(adsb_msg) * 256 * (size_t)n_dev);
+        if (!again || adsb_multi_host_alloc(m, bytes, &pinned) != ADSB_OK) rc = 1;
+        else {
+            memcpy(pinned, iq, bytes);
+            for (int k = 0; k < 3 && rc == 0; k++)
+                if (adsb_multi_icao_flush(m) != ADSB_OK || adsb_multi_submit_iq(m, pinned, per * (size_t)n_dev) != ADSB_OK) rc = 1;
+            if (rc == 0 && (adsb_multi_pending(m) != 3 || adsb_multi_host_free(m, pinned) != ADSB_ERR_BUSY)) rc = 1;
+            for (int k = 0; k < 3 && rc == 0; k++) {
+                size_t n2 = 0;
+                if (adsb_multi_collect(m, again, 256 * (size_t)n_dev, &n2) != ADSB_OK || n2 != n ||
+                    memcmp(again, msgs, n * sizeof(adsb_msg)) != 0)
+                    rc = 1;
+            }
+            if (rc == 0 && adsb_multi_host_free(m, pinned) != ADSB_OK) rc = 1;
+            if (rc == 0) printf("multi: three pinned host captures in flight, each equal to the blocking call\n");
+        }
+        free(again);
+    }
 out:
     free(iq);
     free(msgs);
