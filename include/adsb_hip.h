@@ -402,7 +402,7 @@ int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
  *               test take that fallback on purpose;
  * parallel_min  captures of at least this many trial records (8192) are scored by several host threads at once. */
 int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min);
-/* ... and what the shards did so far: out4[0] shards (of more than 96 records) whose records the host had to put in
+/* ... and what the shards did so far: out4[0] shards whose records the host had to put in
  * order, [1] shards that took the fallback above, [2] shards whose second phase ordered its records on the device
  * (a dense stream's), [3] captures whose records were scored by several host threads at once. */
 int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out4);
