@@ -14,9 +14,12 @@
 // capture, so the result is the single-stream one.
 //
 // The phases are written per slot and do not block: shard_begin enqueues phase 1 of a shard into
-// slot k (scan and the records of its self-validating hits on one of the two scan streams) and
+// slot k on one of the two scan streams -- the scan, which lists the addresses its trials can add
+// itself (adsb_multi's shards in contexts of more than 16 buffers: ScanParams::fresh), or the scan
+// and the records of its self-validating hits, out of which the host reads them -- and
 // returns; the host sees the phase finish by its summary landing in mapped memory
-// (shard_phase_landed); shard_match enqueues phase 2 on the tail stream.  Shards of consecutive
+// (shard_phase_landed); shard_match enqueues phase 2 on the tail stream (a dense stream's shards
+// hand their records over in replay order: device-side ordering, as dense single-stream passes do).  Shards of consecutive
 // captures sit in consecutive slots, so the scan of capture i + 1 runs while capture i is being
 // exchanged and matched -- that is what adsb_multi.cpp (one process, N GPUs, a thread per device)
 // is built on.  adsb_shard_scan / adsb_shard_finish are the same phases, blocking, in slot 0.
