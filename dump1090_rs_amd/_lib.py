@@ -168,7 +168,7 @@ def lib() -> C.CDLL:
     L.adsb_multi_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.adsb_multi_host_free.argtypes = [vp, vp]
     L.adsb_multi_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
-    L.adsb_multi_selftest_tune.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.adsb_multi_selftest_tune.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.adsb_multi_selftest_tune.restype = C.c_int
     L.adsb_multi_selftest_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.adsb_multi_selftest_counters.restype = C.c_int

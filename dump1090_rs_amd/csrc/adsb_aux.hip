@@ -215,6 +215,7 @@ __device__ __forceinline__ bool score_in_filter(const ScoreDev &sd, uint32_t v, 
 {
     if (v == 0) return true;
     if ((sd.exact[v >> 5] >> (v & 31)) & 1u) return true;
+    if (sd.earlier && ((sd.earlier[v >> 5] >> (v & 31)) & 1u)) return true;
     return score_hash_first(sd, v) < i;
 }
 

@@ -373,6 +373,9 @@ void adsb_destroy(adsb_ctx *c)
         if (j.h_addrs) (void)hipHostFree(j.h_addrs);
         if (j.h_fresh) (void)hipHostFree(j.h_fresh);
         if (j.d_fresh_seen) (void)hipFree(j.d_fresh_seen);
+        if (j.h_earlier) (void)hipHostFree(j.h_earlier);
+        for (hipEvent_t e : j.addr_read)
+            if (e) (void)hipEventDestroy(e);
     }
     if (c->d_carry_next) (void)hipFree(c->d_carry_next);
     if (c->d_timeline && tuning_env("ADSB_TIMELINE") && std::atoi(tuning_env("ADSB_TIMELINE")) == 3) {

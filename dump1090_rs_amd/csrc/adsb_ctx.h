@@ -235,11 +235,22 @@ struct adsb_ctx {
         bool fresh_list = false;  // phase 1 is the scan alone: it lists the addresses its trials can add (ScanParams::fresh)
         uint32_t *h_fresh = nullptr, *h_fresh_dev = nullptr;   // ... here (mapped host memory, kShardAddrCap of them)
         uint32_t *d_fresh_seen = nullptr;                      // ... each once: 2^24 bits, cleared in front of the scan
+        // device-side scoring of a dense stream's shards (adsb_multi): the second phase ends with k_score / k_emit against
+        // the context's exact bitmap + `earlier` (d_fresh_seen again, refilled with what the shards before this one add)
+        bool scored = false;          // k_score / k_emit follow this shard's records kernel
+        bool wait_score = false;      // ... and have been launched: the second phase ends with k_emit's summary
+        bool result_scored = false;   // ... and took the shard (ScoreSummary::scored): its records stayed in device memory
+        bool exact_flush = false;     // an icao_flush precedes the shard: its second phase starts from the other, cleared, exact bitmap
+        uint32_t *exact = nullptr;    // the exact bitmap the shard scores against and its capture's additions go into
+        uint32_t *h_earlier = nullptr, *h_earlier_dev = nullptr;   // the earlier shards' additions, in mapped host memory
+        int addr_half = 0;            // h_addrs holds two lists: the commit of one use may still read while the next is written
+        hipEvent_t addr_read[2] = {nullptr, nullptr};   // ... recorded behind the commit that reads half h (score stream)
     } shard[kSlots];
     uint64_t shard_jobs = 0;      // shards begun (their scans alternate between the first two scan streams)
     uint32_t shard_fresh_cap = 0; // how many fresh addresses a shard may list before it falls back to reading them out of
                                   // its records (0: kShardAddrCap; smaller only in tests of that fallback)
-    uint64_t shard_fresh_fallbacks = 0, shard_device_ordered = 0;   // (counters for the tests: adsb_multi_selftest_counters)
+    uint64_t shard_fresh_fallbacks = 0, shard_device_ordered = 0, shard_device_scored = 0;   // (counters for the tests: adsb_multi_selftest_counters)
+    bool shard_scoring = false;   // adsb_multi's contexts: dense shards are scored on the device (off: adsb_multi_selftest_tune)
     bool shard_dense = false;     // the shards of this context leave >= 8 records per buffer: their second phase hands the
                                   // records over in replay order (device-side ordering, as dense single-stream passes do)
     uint32_t *d_addrs = nullptr;
@@ -391,7 +402,14 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
 bool shard_phase_landed(adsb_ctx *c, int k);
 int shard_phase_wait(adsb_ctx *c, int k);
 int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs);
-int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra);
+int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra, const uint32_t *earlier = nullptr, size_t n_earlier = 0);
+// after phase 2 has landed, a shard the device scored: its messages (chunk = buffer index within the shard) and the values
+// its replay hands to icao_filter_add, in order -- in the slot's mapped memory, valid until its next shard_begin.
+// false: the shard was not scored (or its result cannot be used): take its records.
+bool shard_scored_result(adsb_ctx *c, int k, adsb_msg **msgs, size_t *n_msgs, const uint32_t **adds, size_t *n_adds);
+// ... and, when a scored shard's result cannot be used after all (a filter table about to fill up): its records out of
+// device memory into the slot's host buffer (blocking)
+int shard_fetch_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out);
 int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n);
 
 }  // namespace host

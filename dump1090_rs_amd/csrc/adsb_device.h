@@ -175,6 +175,9 @@ struct ScoreDev {
     uint32_t *slot;                // per hit: the hash slot its key sits in (adders), else 0xFFFFFFFF
     uint32_t *blk;                 // per k_score block: emits, adds
     uint32_t *exact;               // 2^24 bits: the filter as it stands before this pass
+    const uint32_t *earlier;       // a shard of an adsb_multi: 2^24 bits, the addresses the shards BEFORE this one (lower
+                                   // buffer ranges of the same capture) add to the filter -- in it for every trial of this
+                                   // shard, whichever adds them first over there; null everywhere else
     uint32_t *exact_retired;       // after an icao_flush: the bitmap the passes before it used, for k_emit to
                                    // clear (the next flush switches back to it), else null
     ScoreState *state;

@@ -50,6 +50,12 @@ struct StepDev {   // one device's share of one capture
     const TrialRecord *rec = nullptr;
     size_t n_rec = 0;
     std::vector<TrialRecord> sorted;    // the shard's records in replay order (sorted by its device thread), when they were not
+    // a shard the device scored (a dense stream's; adsb_shard.cpp): its messages (chunk already the capture's) and the
+    // values its replay hands to icao_filter_add, in order -- in the slot's mapped memory
+    bool scored = false;
+    adsb_msg *msgs = nullptr;
+    size_t n_msgs = 0, n_adds = 0, n_hits = 0;
+    const uint32_t *adds = nullptr;
     ParallelReplay::Adders adders;      // the first record of the shard that can add each value (the device thread's pass over
     bool has_adders = false;            // its records, for shards of up to kDeviceThreadScanMax: the replay's scan stage, done)
     int rc = 0;
@@ -66,6 +72,7 @@ struct Step {
     std::vector<StepDev> dev;
     std::atomic<int> p1_left{0}, p2_left{0};
     std::vector<uint32_t> fresh;   // what phase 2 hands every device
+    std::vector<std::vector<uint32_t>> earlier;   // per device: what the shards BEFORE it add (for a scored shard: ScoreDev::earlier)
     uint64_t n_samples = 0;
     double t_submit = 0, t_exchange0 = 0, t_exchange1 = 0, t_done = 0;
 };
@@ -173,8 +180,10 @@ struct adsb_multi {
     std::atomic<uint64_t> shards_sorted_on_host{0};
     std::unique_ptr<ReplayPool> pool;   // (created with the first capture that is large enough to want it)
     ParallelReplay parallel;
-    uint64_t parallel_scored = 0;
+    uint64_t parallel_scored = 0, scored_shards_used = 0, scored_shards_refused = 0;
     size_t parallel_min = kParallelReplayMin;
+    int score_mode = 0;   // 0: dense shards are scored on their devices; 1: never; 2: scored, and the result refused (tests)
+    size_t held_before = 0;   // (collect_capture: values in the filter table when the capture's replay began)
 #ifdef ADSB_TUNING
     double t_stage[5] = {};   // plan, scan, merge, score, finish (ADSB_HOST_TIMES=1: printed at destroy)
 #endif
@@ -213,6 +222,15 @@ void dispatch_ready(adsb_multi *m)
             std::vector<uint32_t> merged(m->known.size() + s.fresh.size());
             std::merge(m->known.begin(), m->known.end(), s.fresh.begin(), s.fresh.end(), merged.begin());
             m->known.swap(merged);
+        }
+        // (for the shards the devices score themselves: what is in the filter for every trial of shard k whoever adds it
+        // first = the additions of shards 0 .. k - 1, whole lists, not only what is new to the devices)
+        s.earlier.assign((size_t)m->n, {});
+        for (int k = 1; k < m->n; k++) {
+            const std::vector<uint32_t> &before = s.earlier[(size_t)k - 1], &add = s.dev[(size_t)k - 1].learned;
+            std::vector<uint32_t> &u = s.earlier[(size_t)k];
+            u.resize(before.size() + add.size());
+            u.erase(std::set_union(before.begin(), before.end(), add.begin(), add.end(), u.begin()), u.end());
         }
         s.p2_left.store(m->n, std::memory_order_relaxed);
         s.state.store(kPhase2Out, std::memory_order_release);
@@ -288,7 +306,7 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
                     w1.push_back(cmd.step);
                 } else {
                     sd.t_p2_issue = now_s();
-                    if (sd.rc == ADSB_OK) SPENT(issue2, sd.rc = shard_match(c, k, s.fresh.data(), s.fresh.size()));
+                    if (sd.rc == ADSB_OK) SPENT(issue2, sd.rc = shard_match(c, k, s.fresh.data(), s.fresh.size(), s.earlier[(size_t)d->index].data(), s.earlier[(size_t)d->index].size()));
                     w2.push_back(cmd.step);
                 }
             }
@@ -315,10 +333,19 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d)
             StepDev &sd = s.dev[(size_t)d->index];
             if (sd.rc != ADSB_OK || shard_phase_landed(c, k)) {
                 if (sd.rc == ADSB_OK) SPENT(records, sd.rc = shard_records(c, k, &sd.rec, &sd.n_rec));
+                if (sd.rc == ADSB_OK && c->shard[k].result_scored) {
+                    sd.n_hits = c->stats.n_records;
+                    if (shard_scored_result(c, k, &sd.msgs, &sd.n_msgs, &sd.adds, &sd.n_adds)) {
+                        sd.scored = true;
+                        for (size_t i = 0; i < sd.n_msgs; i++) sd.msgs[i].chunk += sd.chunk_base;
+                    } else {
+                        SPENT(records, sd.rc = shard_fetch_records(c, k, &sd.rec, &sd.n_rec));   // (a result that did not add up)
+                    }
+                }
                 // (in replay order before they are handed over: the shards' sorts then run side by side, on the device
                 // threads, instead of one after the other on the caller's)
                 if (sd.rc == ADSB_OK && sd.n_rec > 1) SPENT(sort, if (sort_records(sd.rec, sd.n_rec, sd.sorted)) { sd.rec = sd.sorted.data(); m->shards_sorted_on_host.fetch_add(1, std::memory_order_relaxed); });
-                if (sd.rc == ADSB_OK && sd.n_rec <= kDeviceThreadScanMax) {
+                if (sd.rc == ADSB_OK && !sd.scored && sd.n_rec <= kDeviceThreadScanMax) {
                     SPENT(sort, first_adders(c->crc, sd.rec, sd.n_rec, sd.adders));
                     sd.has_adders = true;
                 }
@@ -431,6 +458,7 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
     st.n_addrs_exchanged = s.fresh.size();
     if (s.flush_before) m->filter.flush();   // icao_flush() took effect before this capture
     double p1_first = 0, p1_last = 0, p2_first = 0, p2_last = 0, p1_max = 0, p2_max = 0;
+    bool any_scored = false;
     for (int k = 0; k < m->n; k++) {
         const StepDev &sd = s.dev[(size_t)k];
         if (sd.rc != ADSB_OK && rc == ADSB_OK) {
@@ -440,8 +468,9 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
         st.n_chunks += sd.st.n_chunks;
         st.n_candidates += sd.st.n_candidates;
         st.n_ap_entries += sd.st.n_ap_entries;
-        st.n_records += sd.n_rec;
+        st.n_records += sd.scored ? sd.n_hits : sd.n_rec;
         st.retries += sd.st.retries;
+        any_scored = any_scored || sd.scored;
         p1_first = k ? std::min(p1_first, sd.t_p1_issue) : sd.t_p1_issue;
         p1_last = std::max(p1_last, sd.t_p1_done);
         p2_first = k ? std::min(p2_first, sd.t_p2_issue) : sd.t_p2_issue;
@@ -455,7 +484,61 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
         // the shards are contiguous ascending buffer ranges, each in replay order (its device thread saw to that):
         // device by device IS global (buffer, j, try_phase) order
         bool done = false;
-        if (st.n_records >= m->parallel_min) {
+        if (any_scored) {
+            // Shards the devices scored themselves (a dense stream's): their messages and additions are taken as they are,
+            // shard by shard in order; a shard that was not scored (sparse, overflowed, empty) is replayed here in its
+            // place.  A scored shard's result stands on the filter being a SET -- k_score asks "was it there, or added
+            // before me" -- which ends where the 4096-slot table could fill up (add() gives up, src/icao_filter.rs:46-62):
+            // then its records are fetched from its device and replayed here like anyone's.
+            size_t held = 0;
+            for (uint32_t v : m->filter.table()) held += v != 0;
+            m->held_before = held;
+            const uint64_t before = m->filter.inserts();
+            bool all_direct = direct && direct_n && out.empty();
+            size_t total = 0;
+            for (int k = 0; k < m->n && all_direct; k++) {
+                const StepDev &sd = s.dev[(size_t)k];
+                all_direct = sd.scored ? true : sd.n_rec == 0;
+                total += sd.n_msgs;
+                held += sd.n_adds;
+            }
+            all_direct = all_direct && total <= direct_cap && held + 64 < IcaoFilter::kSize && m->score_mode != 2;
+            if (all_direct) {   // every shard scored: straight into the caller's array
+                size_t at = 0;
+                for (int k = 0; k < m->n; k++) {
+                    const StepDev &sd = s.dev[(size_t)k];
+                    if (sd.n_msgs) std::memcpy(direct + at, sd.msgs, sd.n_msgs * sizeof(adsb_msg));
+                    at += sd.n_msgs;
+                    for (size_t i = 0; i < sd.n_adds; i++) m->filter.add(sd.adds[i], IcaoFilter::hash(sd.adds[i] & 0xFFFFFFu));
+                }
+                *direct_n = total;
+                direct_done = true;
+                m->scored_shards_used += (uint64_t)m->n;
+            } else {
+                for (int k = 0; k < m->n && rc == ADSB_OK; k++) {
+                    StepDev &sd = s.dev[(size_t)k];
+                    const size_t now_held = (size_t)(m->filter.inserts() - before) + m->held_before;
+                    if (sd.scored && now_held + sd.n_adds + 64 < IcaoFilter::kSize && m->score_mode != 2) {
+                        out.insert(out.end(), sd.msgs, sd.msgs + sd.n_msgs);
+                        for (size_t i = 0; i < sd.n_adds; i++) m->filter.add(sd.adds[i], IcaoFilter::hash(sd.adds[i] & 0xFFFFFFu));
+                        m->scored_shards_used++;
+                    } else if (sd.scored) {
+                        // (the chunk offsets already put into the messages do not matter: they are dropped)
+                        adsb_multi::Dev &d = *m->dev[(size_t)k];
+                        DeviceGuard on_device(d.device);
+                        const TrialRecord *rec = nullptr;
+                        size_t n = 0;
+                        rc = shard_fetch_records(d.ctx, (int)(m->collected % kMultiSteps), &rec, &n);
+                        if (rc == ADSB_OK && n) replay(m->filter, m->crc, rec, n, sd.chunk_base, out);
+                        m->scored_shards_refused++;
+                    } else if (sd.n_rec) {
+                        replay_sorted(m->filter, m->crc, sd.rec, sd.n_rec, sd.chunk_base, out);
+                    }
+                }
+            }
+            done = true;
+        }
+        if (!done && st.n_records >= m->parallel_min) {
             // a busy sky: tens of thousands of records -- scored by several threads at once, each record against the
             // filter as it was plus the positions at which the capture's new addresses enter it (adsb_replay_host.h)
             if (!m->pool) {
@@ -583,6 +666,7 @@ int adsb_multi_create(adsb_multi **out, const int *devices, int n_devices, size_
         }
         // (the context's own per-pass timing is not read here: no events on the shards' streams)
         (void)adsb_set_profiling(d->ctx, 0);
+        d->ctx->shard_scoring = true;   // (a dense stream's shards are scored on their devices: adsb_shard.cpp)
         m->dev.push_back(std::move(d));
     }
     for (auto &d : m->dev) d->th = std::thread(device_thread, m, d.get());
@@ -784,26 +868,33 @@ int adsb_multi_filter_table(const adsb_multi *m, uint32_t *out4096)
     return ADSB_OK;
 }
 
-int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min)
+int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min, uint32_t score_mode)
 {
-    if (!m) return ADSB_ERR_INVALID;
+    if (!m || score_mode > 2) return ADSB_ERR_INVALID;
     if (m->submitted != m->collected) return ADSB_ERR_BUSY;
-    for (auto &d : m->dev) d->ctx->shard_fresh_cap = fresh_cap;   // (the device threads are idle: nothing in flight)
+    for (auto &d : m->dev) {   // (the device threads are idle: nothing in flight)
+        d->ctx->shard_fresh_cap = fresh_cap;
+        d->ctx->shard_scoring = score_mode != 1;
+    }
     m->parallel_min = parallel_min ? parallel_min : kParallelReplayMin;
+    m->score_mode = (int)score_mode;
     return ADSB_OK;
 }
 
-int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out4)
+int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out8)
 {
-    if (!m || !out4) return ADSB_ERR_INVALID;
+    if (!m || !out8) return ADSB_ERR_INVALID;
     if (m->submitted != m->collected) return ADSB_ERR_BUSY;
-    out4[0] = m->shards_sorted_on_host.load(std::memory_order_relaxed);
-    out4[1] = out4[2] = 0;
+    for (int k = 0; k < 8; k++) out8[k] = 0;
+    out8[0] = m->shards_sorted_on_host.load(std::memory_order_relaxed);
     for (auto &d : m->dev) {
-        out4[1] += d->ctx->shard_fresh_fallbacks;
-        out4[2] += d->ctx->shard_device_ordered;
+        out8[1] += d->ctx->shard_fresh_fallbacks;
+        out8[2] += d->ctx->shard_device_ordered;
+        out8[4] += d->ctx->shard_device_scored;
     }
-    out4[3] = m->parallel_scored;
+    out8[3] = m->parallel_scored;
+    out8[5] = m->scored_shards_used;
+    out8[6] = m->scored_shards_refused;
     return ADSB_OK;
 }
 

@@ -57,6 +57,7 @@ int shard_chunk_pass(adsb_ctx *c, Slot &sl, ScanParams p, uint64_t ch, bool with
     p.order_cnt = p.order_base = nullptr;
     p.order_tmp = nullptr;
     p.hit_fields = nullptr;
+    p.score = ScoreDev{};
     sl.seq = next_seq(c);
     sl.h_sum->seq = 0;
     p.seq = sl.seq;
@@ -94,8 +95,8 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
     if (job.active || sl.busy || sl.parked) return ADSB_ERR_BUSY;
     const uint64_t n_chunks = (n_samples + kChunkSamples - 1) / kChunkSamples;
     if (n_chunks > c->max_chunks || n_chunks > kMaxChunks) return ADSB_ERR_INVALID;
-    if (!job.h_addrs) {
-        HIP_TRY(c, hipHostMalloc((void **)&job.h_addrs, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    if (!job.h_addrs) {   // (two lists: ShardJob::addr_half)
+        HIP_TRY(c, hipHostMalloc((void **)&job.h_addrs, 2 * kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_addrs_dev, job.h_addrs, 0));
     }
     // (adsb_multi's shards in contexts of more than 16 buffers: the scan lists the addresses its trials can add -- all the
@@ -105,7 +106,9 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
     if (fresh_list && !job.h_fresh) {
         HIP_TRY(c, hipHostMalloc((void **)&job.h_fresh, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_fresh_dev, job.h_fresh, 0));
-        HIP_TRY(c, hipMalloc((void **)&job.d_fresh_seen, (size_t(1) << 24) / 8));
+        HIP_TRY(c, hipMalloc((void **)&job.d_fresh_seen, kBitmapAllocWords * sizeof(uint32_t)));   // (also the `earlier` set of a scored shard)
+        HIP_TRY(c, hipHostMalloc((void **)&job.h_earlier, kShardAddrCap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&job.h_earlier_dev, job.h_earlier, 0));
     }
     job.fresh_list = fresh_list;
     ScanParams p{};
@@ -130,6 +133,12 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
         c->exact_valid = false;
         ++c->score_epoch;
     }
+    // (adsb_multi's contexts keep their exact bitmap themselves -- every capture's additions are committed to it behind
+    // the capture's scoring, shard_match -- and an icao_flush switches to the other one, cleared in the second phase)
+    job.exact_flush = fresh_list && c->score.si && (job.retired != nullptr);
+    if (job.exact_flush) c->cur_exact ^= 1;
+    job.exact = fresh_list && c->score.si ? c->exact_bm[c->cur_exact] : nullptr;
+    job.scored = job.wait_score = job.result_scored = false;
     p.bitmap = c->d_bitmap[c->cur_bitmap];
     p.hits = sl.d_hits;
     p.hits_cap = sl.hits_cap;
@@ -154,6 +163,18 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool f
             p.order_tmp = sl.d_order_tmp;
             p.hit_fields = sl.d_hit_fields;
             c->shard_device_ordered++;
+            // ... and scored on the device: k_score / k_emit behind the second phase's records kernel, against the
+            // context's exact bitmap and the additions of the shards before this one (ScoreDev::earlier)
+            if (c->shard_scoring && c->score.si) {
+                job.scored = true;
+                p.score = sl.score;
+                p.score.exact = job.exact;
+                p.score.exact_retired = nullptr;
+                p.score.earlier = job.d_fresh_seen;
+                p.score.out_msgs = sl.h_msgs_dev;
+                p.score.out_adds = sl.h_adds_dev;
+                p.score.summary = sl.h_ssum_dev;
+            }
         }
     }
     sl.seq = next_seq(c);
@@ -212,6 +233,8 @@ bool shard_phase_landed(adsb_ctx *c, int k)
     adsb_ctx::ShardJob &job = c->shard[k];
     if (!job.waiting) return true;
     if (!summary_landed(c->slot[k].h_sum, c->slot[k].seq)) return false;
+    // (a scored shard's second phase ends with k_emit's summary)
+    if (job.wait_score && __atomic_load_n(&c->slot[k].h_ssum->seq, __ATOMIC_ACQUIRE) != c->slot[k].seq) return false;
     job.waiting = false;
     return true;
 }
@@ -228,6 +251,7 @@ int shard_phase_wait(adsb_ctx *c, int k)
     }
     if (job.scan_q) HIP_TRY(c, hipStreamSynchronize(job.scan_q));
     HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+    if (job.wait_score) HIP_TRY(c, hipStreamSynchronize(c->score_stream));
     for (int attempt = 0; attempt < 200; attempt++) {
         if (shard_phase_landed(c, k)) return ADSB_OK;
         for (volatile int spin = 0; spin < 2000; spin++) {}
@@ -272,8 +296,10 @@ int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
             sl.seq = next_seq(c);
             sl.h_sum->seq = 0;
             job.p.seq = sl.seq;
-            if (int e = launch_order_hits(job.p, job.scan_q)) return fail(c, (hipError_t)e, "launch_order_hits");   // (device-ordered: the buckets' places)
-            if (int e = launch_records(job.p, false, sl.h_rec_dev, job.scan_q)) return fail(c, (hipError_t)e, "launch_records");
+            ScanParams q1 = job.p;
+            q1.score = ScoreDev{};   // (the first phase's records go to the host, whoever scores the second's)
+            if (int e = launch_order_hits(q1, job.scan_q)) return fail(c, (hipError_t)e, "launch_order_hits");   // (device-ordered: the buckets' places)
+            if (int e = launch_records(q1, false, sl.h_rec_dev, job.scan_q)) return fail(c, (hipError_t)e, "launch_records");
             HIP_TRY(c, hipEventRecord(sl.scanned, job.scan_q));
             job.waiting = true;
             if (int rc = shard_phase_wait(c, k)) return rc;
@@ -291,6 +317,9 @@ int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
         if (int rc = drain_for_chunk_path(c, job)) return rc;
         ScanParams q = p;
         q.keep_counters = 0;
+        q.score = ScoreDev{};
+        job.scored = false;
+        job.p.score = ScoreDev{};
         if (int e = launch_order_hits(q, c->stream)) return fail(c, (hipError_t)e, "launch_order_hits");
         if (int e = launch_records(q, false, sl.h_rec_dev, c->stream)) return fail(c, (hipError_t)e, "launch_records");
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -305,21 +334,31 @@ int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
     return ADSB_OK;
 }
 
-int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
+int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra, const uint32_t *earlier, size_t n_earlier)
 {
     Slot &sl = c->slot[k];
     adsb_ctx::ShardJob &job = c->shard[k];
     if (!job.active || job.waiting) return ADSB_ERR_INVALID;
     ScanParams &p = job.p;
-    hipStream_t ts = c->tail_stream;
+    hipStream_t ts = c->tail_stream, qs = c->score_stream;
     p.keep_counters = 0;
     p.clean_bitmap = job.retired;
+    job.wait_score = job.result_scored = false;
     // the other shards' addresses join this shard's superset: read by the kernel from the slot's mapped host
-    // buffer, no copy command (a capture teaches a few hundred at most; the buffer is the slot's own, free again
-    // when the shard has been collected)
+    // buffer, no copy command (a capture teaches a few hundred at most).  The buffer holds two lists, used in turn: the
+    // same list is committed to the exact bitmap behind this shard's scoring, on the score stream, and that launch may
+    // still be reading when the slot's next shard writes its own (the one after that is behind it in stream order).
+    const uint32_t *d_list = nullptr;
+    int used_half = -1;
     if (n_extra && n_extra <= kShardAddrCap) {
-        std::memcpy(job.h_addrs, extra, n_extra * sizeof(uint32_t));
-        if (int e = launch_set_addresses(job.h_addrs_dev, (uint32_t)n_extra, p.bitmap, p.bitmap_lg, ts))
+        const int half = job.addr_half;
+        uint32_t *h_list = job.h_addrs + (size_t)half * kShardAddrCap;
+        d_list = job.h_addrs_dev + (size_t)half * kShardAddrCap;
+        job.addr_half ^= 1;
+        if (job.addr_read[half]) HIP_TRY(c, hipEventSynchronize(job.addr_read[half]));   // (two uses ago: long done)
+        used_half = half;
+        std::memcpy(h_list, extra, n_extra * sizeof(uint32_t));
+        if (int e = launch_set_addresses(d_list, (uint32_t)n_extra, p.bitmap, p.bitmap_lg, ts))
             return fail(c, (hipError_t)e, "launch_set_addresses");
     } else if (n_extra) {
         // (more than a capture can teach: a caller's own union through adsb_shard_finish -- a device buffer, blocking)
@@ -330,16 +369,54 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
             HIP_TRY(c, hipMalloc((void **)&c->d_addrs, n_extra * sizeof(uint32_t)));
             c->addrs_cap = n_extra;
         }
-        HIP_TRY(c, hipStreamSynchronize(ts));   // (d_addrs may still be read by an earlier shard's launch)
+        HIP_TRY(c, hipStreamSynchronize(ts));   // (d_addrs may still be read by an earlier shard's launches)
+        HIP_TRY(c, hipStreamSynchronize(qs));
         HIP_TRY(c, hipMemcpy(c->d_addrs, extra, n_extra * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d_list = c->d_addrs;
         if (int e = launch_set_addresses(c->d_addrs, (uint32_t)n_extra, p.bitmap, p.bitmap_lg, ts))
             return fail(c, (hipError_t)e, "launch_set_addresses");
+    }
+    // What the score stream gets, in its order = the filter's order: [an icao_flush: the exact bitmap this capture starts
+    // from, cleared] [this shard's scoring against it] [the capture's additions -- every shard's, the exchange has them --
+    // committed to it, for the captures behind this one].
+    auto exact_side = [&](bool behind_records) -> int {
+        if (!job.exact) return ADSB_OK;
+        if (behind_records) HIP_TRY(c, hipStreamWaitEvent(qs, sl.recorded, 0));
+        if (job.exact_flush) HIP_TRY(c, hipMemsetAsync(job.exact, 0, kBitmapAllocWords * sizeof(uint32_t), qs));
+        if (job.scored && behind_records) {
+            HIP_TRY(c, hipMemsetAsync(job.d_fresh_seen, 0, kBitmapAllocWords * sizeof(uint32_t), qs));
+            if (n_earlier) {
+                std::memcpy(job.h_earlier, earlier, n_earlier * sizeof(uint32_t));
+                if (int e = launch_set_addresses(job.h_earlier_dev, (uint32_t)n_earlier, job.d_fresh_seen, kFullBitmapLg, qs))
+                    return fail(c, (hipError_t)e, "launch_set_addresses");
+            }
+            sl.h_ssum->seq = 0;
+            p.score.seq = sl.seq;
+            if (int e = launch_score(p, qs)) return fail(c, (hipError_t)e, "launch_score");
+            job.wait_score = true;
+            c->shard_device_scored++;
+        }
+        if (d_list) {
+            if (int e = launch_set_addresses(d_list, (uint32_t)n_extra, job.exact, kFullBitmapLg, qs))
+                return fail(c, (hipError_t)e, "launch_set_addresses");
+            if (used_half >= 0) {
+                if (!job.addr_read[used_half])
+                    HIP_TRY(c, hipEventCreateWithFlags(&job.addr_read[used_half], hipEventDisableTiming | hipEventDisableSystemFence));
+                HIP_TRY(c, hipEventRecord(job.addr_read[used_half], qs));
+            }
+        }
+        return ADSB_OK;
+    };
+    if (job.scored && n_earlier > kShardAddrCap) {   // (more aircraft before this shard than the list holds: the host scores it)
+        job.scored = false;
+        p.score = ScoreDev{};
     }
     if (!p.n_chunks) {
         // an empty shard has no records kernel to clean the bitmap a flush retired
         if (job.retired)
             if (int e = launch_reset(sl.d_ctr, job.retired, p.bitmap_lg, ts)) return fail(c, (hipError_t)e, "launch_reset");
-        if (n_extra || job.retired) HIP_TRY(c, hipStreamSynchronize(ts));   // (h_addrs is free again; nothing else to wait for)
+        if (int rc = exact_side(false)) return rc;
+        if (n_extra || job.retired) HIP_TRY(c, hipStreamSynchronize(ts));   // (nothing else to wait for)
         return ADSB_OK;
     }
     if (!job.by_chunk) {
@@ -354,7 +431,10 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra)
         if (int e = launch_records(p, false, sl.h_rec_dev, ts)) return fail(c, (hipError_t)e, "launch_records");
         HIP_TRY(c, hipEventRecord(sl.recorded, ts));
         job.ran = true;
+        if (int rc = exact_side(true)) return rc;
         job.waiting = true;
+    } else {
+        if (int rc = exact_side(false)) return rc;
     }
     return ADSB_OK;
 }
@@ -386,13 +466,17 @@ int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
             p.clean_bitmap = nullptr;
         } else {
             const size_t n = sl.h_sum->n_hits;
-            if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+            // (a shard that k_score took has left its records in device memory: shard_scored_result has what it made of
+            // them, shard_fetch_records brings them over if that cannot be used)
+            job.result_scored = job.wait_score && sl.h_ssum->scored != 0 && n <= c->score.cap;
+            if (!job.result_scored)
+                if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
             st.n_candidates = sl.h_sum->n_cand_total;
             st.n_ap_entries = sl.h_sum->n_ap_total;
             st.n_records = n;
             c->stats = st;
-            *rec = sl.h_rec;
-            *n_out = n;
+            *rec = job.result_scored ? nullptr : sl.h_rec;
+            *n_out = job.result_scored ? 0 : n;
             // (density = records per buffer, with the single stream's thresholds and hysteresis: adsb_collect.cpp)
             if (p.n_chunks > kInlineTailChunks) {
                 if (n >= 8u * (size_t)p.n_chunks) c->shard_dense = true;
@@ -421,6 +505,47 @@ int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
     c->stats = st;
     *rec = all.data();
     *n_out = all.size();
+    return ADSB_OK;
+}
+
+bool shard_scored_result(adsb_ctx *c, int k, adsb_msg **msgs, size_t *n_msgs, const uint32_t **adds, size_t *n_adds)
+{
+    Slot &sl = c->slot[k];
+    const adsb_ctx::ShardJob &job = c->shard[k];
+    if (!job.result_scored) return false;
+    const ScoreSummary *ss = sl.h_ssum;
+    const size_t nm = ss->n_msgs, na = ss->n_adds;
+    if (nm > c->score.cap || na > c->score.cap) return false;
+    // the messages and the summary are separate posted writes: the list is whole when it adds up (adsb_collect.cpp)
+    const uint64_t want = (uint64_t)ss->msg_sum_hi << 32 | ss->msg_sum_lo;
+    bool whole = false;
+    for (int attempt = 0; attempt < 200 && !whole; attempt++) {
+        uint64_t got = 0;
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(sl.h_msgs);
+        for (size_t i = 0; i < 5 * nm; i++) got += __atomic_load_n(&w[i], __ATOMIC_RELAXED);
+        whole = got == want;
+    }
+    if (!whole) return false;
+    *msgs = sl.h_msgs;
+    *n_msgs = nm;
+    *adds = sl.h_adds;
+    *n_adds = na;
+    return true;
+}
+
+int shard_fetch_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
+{
+    Slot &sl = c->slot[k];
+    const size_t n = sl.h_sum->n_hits;
+    *rec = nullptr;
+    *n_out = 0;
+    if (n > c->score.cap) return ADSB_ERR_INVALID;
+    if (n) {
+        HIP_TRY(c, hipMemcpy(sl.h_rec, sl.score.rec, n * sizeof(TrialRecord), hipMemcpyDeviceToHost));
+        if (int rc = verify_records(c, sl.h_sum, sl.h_rec, n)) return rc;
+    }
+    *rec = sl.h_rec;
+    *n_out = n;
     return ADSB_OK;
 }
 

@@ -162,14 +162,15 @@ class MultiContext:
         self._check(self._L.adsb_multi_get_stats(self._h, C.byref(s)), "adsb_multi_get_stats")
         return {name: getattr(s, name) for name, _ in AdsbMultiStats._fields_ if name != "reserved"}
 
-    def selftest_tune(self, fresh_cap: int = 0, parallel_min: int = 0) -> None:
-        self._check(self._L.adsb_multi_selftest_tune(self._h, int(fresh_cap), int(parallel_min)), "adsb_multi_selftest_tune")
+    def selftest_tune(self, fresh_cap: int = 0, parallel_min: int = 0, score_mode: int = 0) -> None:
+        self._check(self._L.adsb_multi_selftest_tune(self._h, int(fresh_cap), int(parallel_min), int(score_mode)), "adsb_multi_selftest_tune")
 
     def selftest_counters(self) -> dict:
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         self._check(self._L.adsb_multi_selftest_counters(self._h, out), "adsb_multi_selftest_counters")
         return {"shards_sorted_on_host": out[0], "fresh_list_fallbacks": out[1], "device_ordered_shards": out[2],
-                "parallel_scored_captures": out[3]}
+                "parallel_scored_captures": out[3], "device_scored_shards": out[4], "scored_results_used": out[5],
+                "scored_results_refused": out[6]}
 
     def filter_table(self) -> np.ndarray:
         """Table A of the one ICAO filter (4096 u32, src/icao_filter.rs:8)."""

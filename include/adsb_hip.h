@@ -396,16 +396,20 @@ int adsb_selftest_gate_stages(adsb_ctx *ctx, const void *device_iq_re_im, size_t
  * run the second look on purpose; results never depend on the value.  ADSB_ERR_BUSY while passes are pending. */
 int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
 
-/* Test hooks for adsb_multi (0 = the default; results never depend on either; ADSB_ERR_BUSY while captures are in flight):
+/* Test hooks for adsb_multi (0 = the default; results never depend on any of them; ADSB_ERR_BUSY while captures are in flight):
  * fresh_cap     a shard's scan lists the addresses its trials can add to the filter, at most this many (16384); a
  *               capture with more aircraft falls back to reading them out of its trial records -- a small value lets a
  *               test take that fallback on purpose;
- * parallel_min  captures of at least this many trial records (8192) are scored by several host threads at once. */
-int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min);
-/* ... and what the shards did so far: out4[0] shards whose records the host had to put in
- * order, [1] shards that took the fallback above, [2] shards whose second phase ordered its records on the device
- * (a dense stream's), [3] captures whose records were scored by several host threads at once. */
-int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out4);
+ * parallel_min  captures of at least this many trial records (8192) are scored by several host threads at once;
+ * score_mode    0: a dense stream's shards (contexts of more than 16 buffers) are scored on their devices; 1: never;
+ *               2: scored, but the collector refuses the result and fetches the records instead (the path a filter
+ *               table about to fill up takes). */
+int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min, uint32_t score_mode);
+/* ... and what the shards did so far: out8[0] shards whose records the host had to put in order, [1] shards that took
+ * the fresh_cap fallback, [2] shards whose second phase ordered its records on the device (a dense stream's), [3] captures
+ * whose records were scored by several host threads at once, [4] shards scored on their device, [5] such results the
+ * collector used, [6] ... and refused; [7] 0. */
+int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out8);
 
 /* Host only, no context: the ordered replay done by several threads at once, as adsb_multi_collect does it for captures
  * of tens of thousands of records (csrc/adsb_replay_host.h: ParallelReplay) -- the records are put in order, cut into

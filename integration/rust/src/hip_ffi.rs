@@ -140,8 +140,8 @@ unsafe extern "C" {
     pub fn adsb_selftest_stage_lists(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, cand: *mut u64, cand_cap: usize, n_cand: *mut usize, ap: *mut u64, ap_cap: usize, n_ap: *mut usize) -> c_int;
     pub fn adsb_selftest_gate_stages(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, preamble: *mut u64, preamble_cap: usize, n_preamble: *mut usize, snr: *mut u64, snr_cap: usize, n_snr: *mut usize) -> c_int;
     pub fn adsb_selftest_set_order_polls(ctx: *mut AdsbCtx, polls: u32) -> c_int;
-    pub fn adsb_multi_selftest_tune(m: *mut AdsbMulti, fresh_cap: u32, parallel_min: u32) -> c_int;
-    pub fn adsb_multi_selftest_counters(m: *const AdsbMulti, out4: *mut u64) -> c_int;
+    pub fn adsb_multi_selftest_tune(m: *mut AdsbMulti, fresh_cap: u32, parallel_min: u32, score_mode: u32) -> c_int;
+    pub fn adsb_multi_selftest_counters(m: *const AdsbMulti, out8: *mut u64) -> c_int;
     pub fn adsb_selftest_parallel_replay(filter_table: *mut u32, records: *const AdsbTrial, n: usize, runs: c_int, parts: c_int, threads: c_int, out: *mut AdsbMsg, cap: usize, n_out: *mut usize, went_parallel: *mut c_int) -> c_int;
     pub fn adsb_selftest_crc_table(out256: *mut u32) -> c_int;
     pub fn adsb_selftest_learned_union(records: *const AdsbTrial, n: usize, known: *const u32, n_known: usize, out: *mut u32, cap: usize, n_out: *mut usize) -> c_int;

@@ -287,7 +287,9 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
     multi = MultiContext(devices, per)
     # half of the sequences: every capture scored by several host threads, whatever its size; some: a fresh-address list of
     # two entries, so that shards fall back to reading the addresses out of their records
-    multi.selftest_tune(fresh_cap=2 if rng.random() < 0.25 else 0, parallel_min=1 if rng.random() < 0.5 else 0)
+    # ... and who scores a dense stream's shards: their devices (half), the host, or the devices with the result refused
+    multi.selftest_tune(fresh_cap=2 if rng.random() < 0.25 else 0, parallel_min=1 if rng.random() < 0.5 else 0,
+                        score_mode=int(rng.choice([0, 0, 1, 2])))
     orc = Oracle()
     steps = int(rng.integers(4, 12))
     plan = []
@@ -355,7 +357,7 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
     modes[("multi", False)] = modes.get(("multi", False), 0) + 1
     modes[("multi:captures", False)] = modes.get(("multi:captures", False), 0) + steps
     ctr = multi.selftest_counters()
-    for name in ("device_ordered_shards", "fresh_list_fallbacks"):
+    for name in ("device_ordered_shards", "fresh_list_fallbacks", "device_scored_shards", "scored_results_used", "scored_results_refused"):
         modes[("multi:" + name, False)] = modes.get(("multi:" + name, False), 0) + int(ctr[name])
     modes[("multi:parallel_replays", False)] = modes.get(("multi:parallel_replays", False), 0) + int(multi.selftest_counters()["parallel_scored_captures"])
     modes[("multi:host_submits", False)] = modes.get(("multi:host_submits", False), 0) + sum(f in ("submit_host", "submit_pinned") for _, _, f, _ in plan)

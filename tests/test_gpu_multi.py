@@ -281,7 +281,7 @@ def test_captures_scored_by_several_host_threads_equal_the_serial_replay(hip_lib
     for devices in ([0] * 8, [0] * 3, [0]):
         per = -(-max(len(c) for c in caps) // CHUNK // len(devices)) + 1
         with MultiContext(devices, max(per, 17)) as multi:
-            multi.selftest_tune(parallel_min=1)
+            multi.selftest_tune(parallel_min=1, score_mode=1)   # (the host scores: no shard is scored on its device)
             resident = [to_devices(iq, multi, torch) for iq in caps]
             gots = []
             for i in range(len(caps)):
@@ -296,6 +296,52 @@ def test_captures_scored_by_several_host_threads_equal_the_serial_replay(hip_lib
                 assert [key(m) for m in g] == w, f"capture {i} over {len(devices)} contexts"
             assert list(multi.filter_table()) == list(want_table)
             assert multi.selftest_counters()["parallel_scored_captures"] == len(caps)
+
+
+def test_dense_shards_scored_on_their_devices_equal_the_ordered_replay(hip_lib, oracle_mod):
+    """A dense stream's shards are scored where they are: k_score / k_emit behind the second phase's records kernel,
+    against the context's exact bitmap (every capture's additions committed to it on every device, an icao_flush
+    switching to the cleared one) and the additions of the shards BEFORE this one in the capture (ScoreDev::earlier).
+    The collector only concatenates.  Coupled captures (an address taught in shard 1 that frames in shards 1, 6, 7 need;
+    DF11-taught; a pre-loaded filter), dense ones with 25 and 300 aircraft, sparse ones in between (host-scored), flushes,
+    four in flight, over 3 and 2 contexts: every capture equal to the oracle's ONE stream, the filter table slot for
+    slot -- with the results used, and with every result refused (the path a filter table about to fill up takes: the
+    records are fetched from the devices and replayed by the host)."""
+    import torch
+    from dump1090_rs_amd.multi import MultiContext
+    caps = [dense_capture(4501, 60, 6), coupled_capture8(4502), dense_capture(4503, 60, 9, n_icao=300), dense_capture(4504, 57, 5, n_icao=25),
+            synth.make_iq(60 * CHUNK - 999, n_bursts=30, seed=4505, n_icao=12), dense_capture(4506, 60, 7), coupled_capture8(4507)[: 33 * CHUNK + 4444],
+            dense_capture(4508, 60, 6, n_icao=60), dense_capture(4509, 60, 6, n_icao=60)]
+    flush_before = {0, 3, 7}
+    orc = oracle_mod.Oracle()
+    wants = []
+    for i, iq in enumerate(caps):
+        if i in flush_before:
+            orc.icao_flush()
+        wants.append([want_key(x) for x in orc.demod_iq(iq)[0]])
+    want_table = list(orc.filter.a)
+    for devices, mode in (([0] * 3, 0), ([0] * 2, 0), ([0] * 3, 2)):
+        with MultiContext(devices, 30) as multi:
+            multi.selftest_tune(score_mode=mode)
+            resident = [to_devices(iq, multi, torch) for iq in caps]
+            gots = []
+            for i in range(len(caps)):
+                if multi.pending() == multi.max_in_flight():
+                    gots.append(multi.collect(cap=1 << 16))
+                if i in flush_before:
+                    multi.icao_flush()
+                multi.submit_iq_device(resident[i][1], resident[i][2])
+            while multi.pending():
+                gots.append(multi.collect(cap=1 << 16))
+            for i, (g, w) in enumerate(zip(gots, wants)):
+                assert [key(m) for m in g] == w, f"capture {i} over {len(devices)} contexts, score_mode {mode}"
+            assert list(multi.filter_table()) == want_table
+            ctr = multi.selftest_counters()
+            assert ctr["device_scored_shards"] >= 2 * len(devices), ctr
+            if mode == 0:
+                assert ctr["scored_results_used"] >= 2 * len(devices) and ctr["scored_results_refused"] == 0, ctr
+            else:
+                assert ctr["scored_results_used"] == 0 and ctr["scored_results_refused"] >= 2 * len(devices), ctr
 
 
 def test_a_capture_that_teaches_more_addresses_than_the_fresh_list_holds(hip_lib, oracle_mod):
