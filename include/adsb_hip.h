@@ -274,7 +274,9 @@ int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra
  * reference's order -- over N devices: the capture is cut into contiguous ranges of 131072-sample buffers,
  * one per device; inside, a context and a host thread per device run the two shard phases above, the
  * learned addresses are united in memory between them, and the caller's thread replays all shards' trial
- * records once, in global (buffer, j, try_phase) order, through the one filter (a capture of >= 8192 records --
+ * records once, in global (buffer, j, try_phase) order, through the one filter (a dense stream's shards are scored
+ * on their devices instead -- against the filter as it stood plus what the shards before them add -- and only
+ * concatenated here; a capture of >= 8192 records that the host does score --
  * a busy sky -- with the help of up to six more threads, created when the first such capture is collected: every
  * record is scored against the filter as it was plus the record numbers at which the capture's new addresses
  * enter it, which is the ordered replay's answer, computed side by side).  No process group, no
