@@ -199,7 +199,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
             // launch each, replayed by the host in microseconds -- and carries none of this: no exact bitmaps, no
             // scoring buffers, no message slots in its pinned block)
             const bool scoring = c->n_slots != ADSB_MAX_IN_FLIGHT_SMALL;
-            cd.cap = scoring ? std::min<uint32_t>(c->hits_cap, 131072u) : 0u;
+            cd.cap = scoring ? std::min<uint32_t>(c->hits_cap, 262144u) : 0u;   // (a 2 GiB shard of a busy sky leaves 135 000)
             uint32_t hsize = 1;
             while (hsize < 2 * cd.cap) hsize <<= 1;
             cd.hash_mask = hsize - 1;
@@ -544,6 +544,6 @@ int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.19 gfx950 scan=v9-tile-buckets tail=v7-folded-supersets multi=v1"; }
+const char *adsb_version(void) { return "adsb_hip 0.20 gfx950 scan=v9-tile-buckets tail=v7-folded-supersets multi=v2-device-scored-shards"; }
 
 }  // extern "C"

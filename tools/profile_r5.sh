@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/r5_v19_* holds, in one GPU call: tools/profile_all.sh, then what round 5 added -- adsb_multi_* from one
+# Everything profiles/r5_v20_* holds, in one GPU call: tools/profile_all.sh, then what round 5 added -- adsb_multi_* from one
 # process (N = 1 and eight contexts on the one GPU), the small-pass host times with a flush per pass, the stage split of the scan
 # (needs variants/lib_tune.so of the same source).   usage: tools/profile_r5.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; T=$1; cd $R
