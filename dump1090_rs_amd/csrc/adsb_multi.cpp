@@ -513,7 +513,7 @@ int collect_capture(adsb_multi *m, std::vector<adsb_msg> &out, adsb_msg *direct 
                 }
                 *direct_n = total;
                 direct_done = true;
-                m->scored_shards_used += (uint64_t)m->n;
+                for (int k = 0; k < m->n; k++) m->scored_shards_used += s.dev[(size_t)k].scored ? 1u : 0u;
             } else {
                 for (int k = 0; k < m->n && rc == ADSB_OK; k++) {
                     StepDev &sd = s.dev[(size_t)k];
