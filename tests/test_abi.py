@@ -110,6 +110,10 @@ def test_multi_entry_points_refuse_bad_arguments_without_a_device(hip_lib):
     assert L.adsb_multi_device_count(None) == 0 and L.adsb_multi_pending(None) == 0 and L.adsb_multi_max_in_flight(None) == 0
     assert L.adsb_multi_icao_flush(None) == -1 and L.adsb_multi_collect(None, None, 0, None) == -1
     assert L.adsb_multi_last_error(None) == b""
+    p = C.c_void_p()
+    assert L.adsb_multi_submit_iq(None, None, 0) == -1 and L.adsb_multi_host_alloc(None, 16, C.byref(p)) == -1 and not p.value
+    assert L.adsb_multi_host_free(None, None) == -1
+    assert L.adsb_multi_selftest_tune(None, 0, 0, 0) == -1 and L.adsb_multi_selftest_counters(None, (C.c_uint64 * 8)()) == -1
     CHUNK = 131072
     for n_samples in (0, 1, CHUNK - 1, CHUNK, CHUNK + 1, 38 * CHUNK - 4321, 4096 * CHUNK):
         for world in (1, 2, 3, 8, 64):
