@@ -787,7 +787,7 @@ def config3_leg(env: Env, args):
                     "reads over the link in place (~36-39 GB/s); from three buffers per slot on by the copy engine (~52 GB/s)"}
 
 
-def live_leg(env: Env, args, passes: int = 160):
+def live_leg(env: Env, args, passes: int = 480):
     """The live receiver's loop as the reference runs it (dump1090_rs/src/main.rs:154-167): one read of
     131072 samples, one demodulation, for ever, the ICAO filter NEVER flushed.  `passes` DISTINCT buffers of
     one synthetic stream (a pool of 40 aircraft that keep being heard, so the filter is warm after the first
@@ -826,14 +826,45 @@ def live_leg(env: Env, args, passes: int = 160):
            [(w["chunk"], w["j"], w["try_phase"], w["score"], w["msg"], w["signal_level"]) for w in want]
     rematches = int(ctx._L.adsb_host_rematches(ctx._h))
     ctx.close()
-    return {"workload": f"live receiver loop (main.rs:154-167): {passes} distinct 131072-sample buffers of one stream through "
+    compiled = live_leg_compiled(iq, want, passes)
+    return {"compiled_host": compiled,
+            "workload": f"live receiver loop (main.rs:154-167): {passes} distinct 131072-sample buffers of one stream through "
                         f"the pinned ring, one launch per buffer, {depth} in flight, no icao_flush; the host copies every "
                         "buffer into its slot (an SDR read would land there)",
             "passes": passes, "frames": len(want), "parity_checked": bool(same), "passes_redone": rematches,
             "value": round(n / elapsed / 1e6, 1), "unit": "Msamples/s",
-            "note": "the rate includes the host's 512 KB memcpy into the slot per pass (what an SDR's DMA would do) and a Python list "
-                    "of message objects per pass; the ring's own rate with the slots already filled is "
-                    "config3_streaming_ring.slot_sweep[0]"}
+            "note": "value: this loop driven from Python -- it includes the host's 512 KB memcpy into the slot per pass (what an SDR's "
+                    "DMA would do) and a Python list of message objects per pass; compiled_host: the same loop in C "
+                    "(tests/abi_host --live), the library as a compiled caller sees it; the ring's own rate with the slots already "
+                    "filled is config3_streaming_ring.slot_sweep[0]"}
+
+
+def live_leg_compiled(iq, want, passes):
+    """The same loop from a COMPILED host (tests/abi_host --live: C over include/adsb_hip.h, built by __graft_entry__.build()):
+    no interpreter between the calls, the frames written out and compared here with the same oracle stream.  None when
+    the helper is not built."""
+    import tempfile
+    exe = ROOT / "tests" / "abi_host"
+    if not exe.exists():
+        return None
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        src, out = os.path.join(tmp, "stream.bin"), os.path.join(tmp, "frames.out")
+        iq.tofile(src)
+        best = None
+        for _ in range(3):   # (a process start each: its first passes warm the context up; the best of three loops)
+            r = subprocess.run([str(exe), "--live", src, out], capture_output=True, text=True, timeout=300)
+            if r.returncode != 0 or not r.stdout.startswith("live: "):
+                return {"error": (r.stdout + r.stderr)[-300:]}
+            secs = float(r.stdout.split(",")[2].split()[0])
+            best = secs if best is None else min(best, secs)
+        got = [ln.split() for ln in open(out).read().splitlines()]
+    import struct
+    same = [(int(g[0]), int(g[1]), int(g[2]), int(g[3]), g[4], g[5]) for g in got] == \
+           [(w["chunk"], w["j"], w["try_phase"], w["score"], w["buffer"].hex(), struct.pack(">d", w["signal_level"]).hex()) for w in want]
+    return {"value": round(passes * CHUNK / best / 1e6, 1), "unit": "Msamples/s", "seconds": round(best, 6), "frames": len(got),
+            "parity_checked": bool(same),
+            "is": "tests/abi_host --live: acquire a ring slot, memcpy 512 KB into it, submit, collect the oldest when all are out -- "
+                  "in C, best of three process runs (each starts cold); every frame compared with the oracle's stream"}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1412,7 +1443,7 @@ def main():
     if env.rank == 0:
         bad = result.get("parity_checked") is False or result.get("shard_merge_equals_single_stream") is False
         for leg in (result.get("also") or {}).values():
-            bad = bad or leg.get("parity_checked") is False
+            bad = bad or leg.get("parity_checked") is False or (leg.get("compiled_host") or {}).get("parity_checked") is False
         if bad:
             sys.exit(3)
 

@@ -17,9 +17,11 @@
  * and run by tests/test_gpu_parity.py on the GPU box with the frames of tests/golden/reference_frames.json
  * (= tests/test.rs:22-28,35-40,49-56).  What a Rust host's `extern "C"` block binds is this same header.
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c11 */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <stddef.h>
 
@@ -133,13 +135,85 @@ out:
     return rc;
 }
 
+/* abi_host --live <stream.bin> <frames.out>: the live receiver's loop (dump1090_rs/src/main.rs:154-167) from a compiled
+ * host -- one read of 131072 samples into a pinned ring slot (here: a memcpy out of the file's image, {re, im} pairs in
+ * memory order), one demodulation, for ever, the ICAO filter never flushed, every slot in flight.  Writes the frames
+ * (buffer index, j, try_phase, score, hex, signal_level bits) to frames.out and prints the loop's own time: what
+ * bench.py's live_receiver leg reports and compares with the oracle's ONE stream over the same bytes. */
+static int run_live(const char *path, const char *out_path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return 2;
+    fseek(f, 0, SEEK_END);
+    const long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    const size_t per = ADSB_MODES_MAG_BUF_SAMPLES, passes = (size_t)bytes / (per * 4);
+    int16_t *iq = malloc((size_t)bytes);
+    if (!iq || fread(iq, 1, (size_t)bytes, f) != (size_t)bytes || passes == 0) return 2;
+    fclose(f);
+    adsb_ctx *ctx = NULL;
+    int st = adsb_create(&ctx, 0, 1);
+    if (st == ADSB_OK) st = adsb_ring_create(ctx, per);
+    if (st == ADSB_OK) st = adsb_icao_flush(ctx);
+    if (st != ADSB_OK) {
+        fprintf(stderr, "%s\n", adsb_strerror(st));
+        return 3;
+    }
+    const int depth = adsb_max_in_flight(ctx);
+    const size_t cap = 4096;
+    adsb_msg *msgs = malloc(sizeof(adsb_msg) * cap), *all = malloc(sizeof(adsb_msg) * cap * 64);
+    size_t n_all = 0, done = 0;
+    int rc = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t b = 0; b <= passes && rc == 0; b++) {
+        /* finish the oldest pass when every slot is out, and everything at the end */
+        while (rc == 0 && done < b && (b == passes || b - done >= (size_t)depth)) {
+            size_t n = 0;
+            if (adsb_collect(ctx, msgs, cap, &n) != ADSB_OK || n_all + n > cap * 64) rc = 1;
+            for (size_t i = 0; i < n && rc == 0; i++) {
+                msgs[i].chunk = done;
+                all[n_all++] = msgs[i];
+            }
+            done++;
+        }
+        if (b == passes) break;
+        int16_t *slot = NULL;
+        size_t slot_cap = 0;
+        if (adsb_ring_acquire(ctx, &slot, &slot_cap) != ADSB_OK || slot_cap < per) rc = 1;
+        else {
+            memcpy(slot, iq + 2 * per * b, per * 4);   /* (an SDR driver's read would land here) */
+            if (adsb_ring_submit(ctx, per) != ADSB_OK) rc = 1;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    FILE *o = rc == 0 ? fopen(out_path, "w") : NULL;
+    if (!o) rc = 1;
+    for (size_t i = 0; i < n_all && rc == 0; i++) {
+        unsigned long long bits;
+        memcpy(&bits, &all[i].signal_level, 8);
+        fprintf(o, "%llu %u %u %d ", (unsigned long long)all[i].chunk, all[i].j, all[i].try_phase, all[i].score);
+        for (int k = 0; k < all[i].len; k++) fprintf(o, "%02x", all[i].msg[k]);
+        fprintf(o, " %016llx\n", bits);
+    }
+    if (o) fclose(o);
+    if (rc == 0) printf("live: %zu passes, %zu frames, %.6f s, %d in flight\n", passes, n_all, secs, depth);
+    adsb_destroy(ctx);
+    free(iq);
+    free(msgs);
+    free(all);
+    return rc;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s [--multi N] <capture.iq> [expected hex frames...]\n", argv[0]);
+        fprintf(stderr, "usage: %s [--multi N | --live stream.bin frames.out] <capture.iq> [expected hex frames...]\n", argv[0]);
         return 2;
     }
     if (strcmp(argv[1], "--multi") == 0) return argc < 4 ? 2 : run_multi(atoi(argv[2]), argc - 3, argv + 3);
+    if (strcmp(argv[1], "--live") == 0) return argc < 4 ? 2 : run_live(argv[2], argv[3]);
     adsb_ctx *ctx = NULL;
     int st = adsb_create(&ctx, 0, 1);
     if (st != ADSB_OK) {
