@@ -552,6 +552,30 @@ def test_compiled_c_host_runs_the_reference_test_routine(hip_lib, golden):
     assert subprocess.run([str(exe), str(GOLDEN / fx["file"]), *fx["frames"][:-1]], capture_output=True).returncode == 1
 
 
+def test_compiled_c_host_runs_the_live_receiver_loop(hip_lib, oracle_mod, tmp_path):
+    """tests/abi_host --live: the receiver's loop (dump1090_rs/src/main.rs:154-167) in C over include/adsb_hip.h -- a ring
+    slot acquired, 131072 samples copied in, submitted, the oldest pass collected when every slot is out, the ICAO
+    filter never flushed: 40 buffers of one stream that keeps teaching its aircraft; the frames it writes out are the
+    oracle's ONE stream over the same bytes, signal levels bit for bit."""
+    import struct
+    import subprocess
+    from tests.conftest import ROOT
+    exe = ROOT / "tests" / "abi_host"
+    assert exe.exists(), "tests/abi_host was not built (dump1090_rs_amd.build.build_abi_host)"
+    iq = synth.make_iq(40 * 131072, n_bursts=500, seed=9090, n_icao=30, df11_every=5)
+    orc = oracle_mod.Oracle()
+    orc.icao_flush()
+    want, _ = orc.demod_iq(iq, cap=1 << 16)
+    src, out = tmp_path / "stream.bin", tmp_path / "frames.out"
+    iq.tofile(src)
+    r = subprocess.run([str(exe), "--live", str(src), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("live: 40 passes, "), r.stdout + r.stderr
+    got = [ln.split() for ln in out.read_text().splitlines()]
+    assert [(int(g[0]), int(g[1]), int(g[2]), int(g[3]), g[4], g[5]) for g in got] == \
+           [(w["chunk"], w["j"], w["try_phase"], w["score"], w["buffer"].hex(), struct.pack(">d", w["signal_level"]).hex()) for w in want]
+    assert len(want) > 300
+
+
 def test_device_side_scoring_follows_the_filter_across_pipelined_passes(hip_lib, oracle_mod):
     """Passes of more than 16 buffers are scored on the device against its own copy of the ICAO
     filter: 750 -> 1600, 1400 -> 1800 and address/parity frames that depend on addresses learned earlier
