@@ -110,10 +110,10 @@ typedef struct {
  *            (2^19 bits, address folded: a superset is all the match needs) in a context created with
  *            max_chunks <= 16, which never scores on the device.  Per pass in flight the address/parity list, the
  *            hit list with the scan's bit fields per hit, and (large contexts) the scoring buffers: ~0.8 MB each for
- *            max_chunks = 1 (~7 MB in all, 0.6 of them bitmaps), ~101 MB each for 512 (~420 MB in all);
+ *            max_chunks = 1 (~7 MB in all, 0.6 of them bitmaps), ~109 MB each for 512 (~450 MB in all);
  *   pinned host (mapped, written by the kernels; one allocation per context)  per pass in flight 32 B per trial
  *            record (4096 + 1024 max_chunks of them) + in large contexts 44 B per scored message slot
- *            (min(that, 131072)): ~1.3 MB in all for max_chunks = 1, ~90 MB for 512; host-pointer calls of a few
+ *            (min(that, 262144)): ~1.3 MB in all for max_chunks = 1, ~115 MB for 512; host-pointer calls of a few
  *            buffers add a pinned staging buffer of their size, the ring its slots.
  * Input denser than the lists are sized for (several times a busy airspace) is still
  * demodulated exactly, buffer by buffer through worst-case lists allocated on first use
