@@ -81,7 +81,9 @@ def parse(argv=None):
                     help="leave the rank's CPU affinity alone (default: the cores of its GPU's NUMA node, from sysfs)")
     ap.add_argument("--stream-seconds", type=float, default=10.0,
                     help="--workload stream and the config-3 leg: run at least this long at the headline slot size")
-    ap.add_argument("--no-also", action="store_true", help="skip the short legs for BASELINE configs 1, 3 and 5")
+    ap.add_argument("--no-also", action="store_true", help="skip the short legs for BASELINE configs 1, 3, 4 and 5")
+    ap.add_argument("--also-only", default="",
+                    help="comma-separated subset of the `also` legs to run (config1, config3, live, config4, config5); default: all")
     ap.add_argument("--timed-profiling", type=int, default=1,
                     help="HIP-event level inside the timed region (1 = scan kernel stamped by its "
                          "own launch; 0 = none, then roofline numbers come from the untimed repeat)")
@@ -1169,6 +1171,146 @@ def busy_sky_leg(env: Env, args, devices, ranges, per, total_chunks):
             "shard_merge_equals_single_stream": bool(same), "parity_frames": len(want)}
 
 
+def _oracle_threads() -> int:
+    """threads for the checker over a whole capture: the CPUs this process may use, at most twice its cgroup's quota"""
+    n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    quota = _cpu_quota()
+    return max(1, min(n, int(2 * quota + 0.5))) if quota else n
+
+
+def config4_leg(env: Env, args, device_sets, steps: int):
+    """BASELINE config 4 in the driver's line: ONE capture of --capture-chunks buffers (4096 = 2 GiB) through
+    adsb_multi_* (one process, a context and a host thread per shard inside the library, one filter, one ordered
+    replay -- the reference's loop dump1090_rs/src/main.rs:154-167 over N devices), for every entry of `device_sets`
+    (lists of device indices: [0] = the whole capture on one context, [0] * 8 = eight shards on the one GPU, [0..N) = N
+    real devices), a sparse sky (config 2's density) and a busy one (config 5's).  Per run: `steps` pipelined captures
+    between two fences (an icao_flush each, four in flight), five blocking ones for the library's own host-clock spans,
+    and one more flushed capture compared message by message with the CPU oracle over the WHOLE capture
+    (orc_demod_iq_mt).  The capture is generated once per density on this rank's device; a shard on another device is
+    a copy of its range."""
+    torch = env.torch
+    import ctypes as C
+    from dump1090_rs_amd import sharding, synth, _lib
+    from dump1090_rs_amd._lib import AdsbMsg
+    from dump1090_rs_amd.multi import MultiContext
+    from oracle import binding
+
+    total_chunks = max(max(len(d) for d in device_sets), args.capture_chunks)
+    n = total_chunks * CHUNK
+    cap = 1 << 20
+    out = (AdsbMsg * cap)()
+    keys = ("ms_wall", "ms_phase1_max", "ms_phase2_max", "ms_phase1_span", "ms_phase2_span", "ms_exchange", "ms_replay")
+    n_thr = _oracle_threads()
+    runs = []
+    all_same = True
+    for sky, per_512 in (("sparse", 64), ("busy_sky", 5000)):
+        whole = synth.make_iq_torch(n, n_bursts=max(1, per_512 * total_chunks // 512), seed=synth.SEED_DEFAULT + 4096 + per_512, device=env.dev)
+        torch.cuda.synchronize()
+        host = whole.cpu().numpy()
+        orc = binding.Oracle()
+        orc.icao_flush()
+        with env.all_cores():
+            timing = []
+            want, _ = orc.demod_iq(host, cap=cap, threads=n_thr, timing=timing)
+        del host
+        for devices in device_sets:
+            shards = len(devices)
+            ranges = [sharding.chunk_range(total_chunks, shards, r) for r in range(shards)]
+            per = max(b - a for a, b in ranges)
+            parts = []
+            for r, (a, b) in enumerate(ranges):
+                t = whole[a * CHUNK:b * CHUNK]
+                parts.append(t if devices[r] == env.local_rank else t.to(torch.device("cuda", devices[r])))
+            for d in set(devices):
+                torch.cuda.synchronize(d)
+            with MultiContext(devices, per) as multi:
+                ptrs = (C.c_void_p * shards)(*[C.c_void_p(t.data_ptr()) for t in parts])
+                ns = (C.c_size_t * shards)(*[t.shape[0] for t in parts])
+                depth = multi.max_in_flight()
+
+                def run_steps(count, blocking=False, acc=None):
+                    frames, done = 0, 0
+                    for i in range(count):
+                        multi.icao_flush()
+                        multi.submit_raw(ptrs, ns)
+                        if blocking or i - done >= depth - 1:
+                            frames += multi.collect_raw(out, cap)
+                            done += 1
+                            if acc is not None:
+                                st = multi.stats()
+                                for k in keys:
+                                    acc[k] += st[k]
+                    while done < count:
+                        frames += multi.collect_raw(out, cap)
+                        done += 1
+                    return frames
+
+                run_steps(12)   # (clocks are up from the legs before; a stream's density is known one capture later)
+                env.torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                frames = run_steps(steps)
+                env.torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t0
+                acc = {k: 0.0 for k in keys}
+                run_steps(5, True, acc)
+                orch = {k: round(v / 5, 4) for k, v in acc.items()}
+                orch["ms_overhead"] = round(orch["ms_wall"] - orch["ms_phase1_span"] - orch["ms_phase2_span"], 4)
+                stats = multi.stats()
+                multi.icao_flush()
+                merged = multi.demod_iq_device([t.data_ptr() for t in parts], [t.shape[0] for t in parts], cap=cap)
+                counters = multi.selftest_counters()
+                wait = {_lib.ADSB_WAIT_SPIN: "spin", _lib.ADSB_WAIT_BLOCK: "block"}[multi.get_wait()]
+            same = _same(merged, want)
+            all_same = all_same and same
+            ms = elapsed / steps * 1e3
+            n_real = len(set(devices))
+            gbs = n * BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9
+            runs.append({
+                "sky": sky, "devices": devices, "shards": shards, "value": round(n * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+                "steps": steps, "ms_per_step": round(ms, 4), "frames_per_step": frames // max(1, steps),
+                "records_last_step": int(stats["n_records"]), "addresses_exchanged_last_step": int(stats["n_addrs_exchanged"]),
+                "blocking_steps_host_clock": orch, "wait": wait,
+                "device_ordered_shards": int(counters["device_ordered_shards"]), "device_scored_shards": int(counters["device_scored_shards"]),
+                "parallel_scored_captures": int(counters["parallel_scored_captures"]),
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * n_real, "unit": "GB/s",
+                             "frac": round(gbs / (HBM_PEAK_GBS * n_real), 4),
+                             "is": f"{BYTES_PER_SAMPLE} B per sample x the capture's samples / the whole step (every kernel of both shard "
+                                   f"phases, the exchange, the replay), against {n_real} x 8 TB/s; the scan kernel's own figure is the headline's"},
+                "parity_checked": bool(same), "parity_frames": len(want)})
+            del parts
+        del whole
+        torch.cuda.empty_cache()
+    return {"workload": f"one capture of {total_chunks} buffers = {n * 4 // (1 << 20)} MiB through adsb_multi_submit_iq_device / adsb_multi_collect "
+                        "(ONE process, one filter, one ordered message list; BASELINE config 4), an icao_flush per capture, 4 captures in flight; "
+                        "sparse: 64 bursts per 512 buffers, busy_sky: 5000",
+            "runs": runs, "parity_checked": bool(all_same),
+            "parity_is": f"every run's extra flushed capture against orc_demod_iq_mt over the whole capture ({n_thr} threads, "
+                         f"{timing[0]:.2f} s for the last one)",
+            "library": _lib.lib().adsb_version().decode()}
+
+
+def one_process_n_devices_leg(env: Env, args):
+    """--gpus N > 1, after the timed independent-stream region: every rank has closed its context and freed its buffers;
+    rank 0 drives ONE adsb_multi over all N devices (config4_leg) while the others wait at a HOST-side barrier (a gloo
+    group: an RCCL barrier would keep a spinning kernel on the very devices being measured).  Returns the leg on rank 0,
+    None elsewhere."""
+    torch = env.torch
+    group = env.dist.new_group(backend="gloo") if env.dist is not None else None
+    leg = None
+    if env.rank == 0:
+        try:
+            n_vis = torch.cuda.device_count()
+            devices = list(range(env.world)) if n_vis >= env.world else [k % n_vis for k in range(env.world)]
+            leg = config4_leg(env, args, [devices], args.steps)
+            leg["devices_visible_to_rank0"] = n_vis
+            leg["is"] = (f"rank 0 alone, the other {env.world - 1} rank(s) idle at a host-side barrier: adsb_multi over devices {devices}")
+        except Exception as e:   # the headline line must still come out; the failure is in it
+            leg = {"error": f"{type(e).__name__}: {e}", "parity_checked": False}
+    if group is not None:
+        env.dist.barrier(group=group)
+    return leg
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE config 1: the reference's `cargo bench` case
 # ------------------------------------------------------------------------------------------------
@@ -1385,18 +1527,8 @@ def main():
     elif args.workload == "shard":
         result = run_shard(env, args)
     else:
-        small_first = env.rank == 0 and env.world == 1 and not args.no_also and not args.sync and args.workload == "sparse"
-        if small_first:
-            # A context for passes of a few buffers made (and closed again) BEFORE this process builds its synthetic
-            # buffers with torch: measured (profiles/r5_stream_pool_ab.txt), the `also` legs' one-buffer ring then runs
-            # at 10.9-11.5 Gsample/s instead of 8.7-9.4, whatever else is done in between -- something in the order in
-            # which the runtime first sees the library's allocations; the headline leg is unaffected either way
-            # (0.096-0.098 ms per step).  Said in the line: config.small_context_first.
-            from dump1090_rs_amd import Context
-            Context(env.local_rank, 1).close()
         r = run_resident(env, args, args.workload, args.steps, args.warmup)
         result = resident_result(env, args, r, args.workload)
-        result["config"]["small_context_first"] = bool(small_first)
         if env.rank == 0 and not args.no_cpu_baseline:
             # N = 1: the CPU baseline beside the line; N > 1: the parity gate alone (rank 0's buffer 0
             # against the oracle), so that the line verifies itself wherever the driver runs it
@@ -1410,32 +1542,48 @@ def main():
         r["ctx"].close()
         del r
         env.torch.cuda.empty_cache()
-        if env.rank == 0 and env.world == 1 and not args.no_also and not args.sync and args.workload == "sparse":
-            also = {}
-            also["config1_cargo_bench_case"] = run_config1(env)
-            also["config3_streaming_ring"] = config3_leg(env, args)
-            also["live_receiver"] = live_leg(env, args)
+        only = set(x for x in args.also_only.split(",") if x)
+        want_leg = lambda name: not only or name in only   # noqa: E731
+        if env.dist is not None and not args.no_also and not args.sync and args.workload == "sparse":
+            # the reference's shape -- one process, one filter -- over all N devices, by rank 0 (every rank takes part in the barrier)
+            leg = one_process_n_devices_leg(env, args)
+            if env.rank == 0:
+                result.setdefault("also", {})["config4_one_process_n_devices"] = leg
+        if env.rank == 0 and env.dist is None and not args.no_also and not args.sync and args.workload == "sparse":
+            also = result.setdefault("also", {})
+            if want_leg("config1"):
+                also["config1_cargo_bench_case"] = run_config1(env)
+            if want_leg("config3"):
+                also["config3_streaming_ring"] = config3_leg(env, args)
+            if want_leg("live"):
+                also["live_receiver"] = live_leg(env, args)
             # (a dense pass is a longer chain -- scan, match, order, records, score, emit, replay -- so the fill and the
             # drain of the pipeline between the two fences weigh ~0.3 ms: 14 us per step in a block of 20, 1.4 in one
             # of 200.  This leg reports the steady state, over at least 200 steps, and the short block beside it.)
-            dargs = argparse.Namespace(**vars(args))
-            dargs.steps = max(args.steps, 200)
-            d = run_resident(env, dargs, "dense", dargs.steps, dargs.warmup, level2=False, short_block=args.steps)
-            dr = resident_result(env, dargs, d, "dense")
-            _, dsame, dframes = parity_leg(env, d, args.chunks, baseline=False) if not args.no_cpu_baseline else (None, None, None)
-            also["config5_dense"] = {
-                "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
-                "steps": dargs.steps, "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
-                "ms_per_step_blocks": (dr["ms_per_step_blocks"] or {}).get("all"),
-                "ms_per_step_in_a_block_of": {"steps": args.steps, "ms_per_step": round(d["short_block_ms"], 4),
-                                              "is": "the same loop over only this many steps between the fences: the "
-                                                    "pipeline's fill and drain (one pass's whole chain, ~0.3 ms) included once"},
-                "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
-                "device_ms_per_launch": dr["roofline"]["sustained"]["device_ms_per_launch"],
-                "n_records_last_step": dr["device_stats_last_step"]["n_records"],
-                "parity_checked": dsame, "parity_frames": dframes}
-            d["ctx"].close()
-            result["also"] = also
+            if want_leg("config5"):
+                dargs = argparse.Namespace(**vars(args))
+                dargs.steps = max(args.steps, 200)
+                d = run_resident(env, dargs, "dense", dargs.steps, dargs.warmup, level2=False, short_block=args.steps)
+                dr = resident_result(env, dargs, d, "dense")
+                _, dsame, dframes = parity_leg(env, d, args.chunks, baseline=False) if not args.no_cpu_baseline else (None, None, None)
+                also["config5_dense"] = {
+                    "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
+                    "steps": dargs.steps, "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
+                    "ms_per_step_blocks": (dr["ms_per_step_blocks"] or {}).get("all"),
+                    "ms_per_step_in_a_block_of": {"steps": args.steps, "ms_per_step": round(d["short_block_ms"], 4),
+                                                  "is": "the same loop over only this many steps between the fences: the "
+                                                        "pipeline's fill and drain (one pass's whole chain, ~0.3 ms) included once"},
+                    "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
+                    "device_ms_per_launch": dr["roofline"]["sustained"]["device_ms_per_launch"],
+                    "n_records_last_step": dr["device_stats_last_step"]["n_records"],
+                    "parity_checked": dsame, "parity_frames": dframes}
+                d["ctx"].close()
+                del d
+                env.torch.cuda.empty_cache()
+            if want_leg("config4"):
+                n_dev = env.torch.cuda.device_count()
+                sets = [[env.local_rank], [env.local_rank] * 8] + ([list(range(n_dev))] if n_dev > 1 else [])
+                also["config4_sharded_capture"] = config4_leg(env, args, sets, args.steps)
 
     if env.rank == 0:
         print(json.dumps(result), flush=True)

@@ -20,37 +20,7 @@ from .context import (  # noqa: F401
     ModeSMessage,
     default_context,
 )
-from . import utils  # noqa: F401
-
-
-def _crate_module(name: str, doc: str, **items):
-    """The reference's `demod_2400` and `icao_filter` modules have one public function each on this path
-    (src/demod_2400.rs:115, src/icao_filter.rs:11): the same names here, as modules of this package, without a
-    file apiece."""
-    import sys
-    import types
-    m = types.ModuleType(f"{__name__}.{name}", doc)
-    m.__dict__.update(items)
-    sys.modules[m.__name__] = m
-    return m
-
-
-def _demodulate2400(mag: MagnitudeBuffer):
-    """src/demod_2400.rs:115-212 (always Ok upstream, so the list is returned bare)."""
-    return default_context().demodulate2400(mag)
-
-
-def _icao_flush() -> None:
-    """src/icao_filter.rs:11-17, for the process-wide default context."""
-    default_context().icao_flush()
-
-
-_demodulate2400.__name__ = _demodulate2400.__qualname__ = "demodulate2400"
-_icao_flush.__name__ = _icao_flush.__qualname__ = "icao_flush"
-demod_2400 = _crate_module("demod_2400", "Mirror of the reference's `demod_2400` module (src/demod_2400.rs).",
-                           demodulate2400=_demodulate2400, ModeSMessage=ModeSMessage, MagnitudeBuffer=MagnitudeBuffer)
-icao_filter = _crate_module("icao_filter", "Mirror of the reference's `icao_filter` module's public entry (src/icao_filter.rs:11).",
-                            icao_flush=_icao_flush)
+from . import demod_2400, icao_filter, utils  # noqa: F401
 
 __all__ = [
     "MODES_MAG_BUF_SAMPLES", "MODES_LONG_MSG_BYTES", "MODES_SHORT_MSG_BYTES", "TRAILING_SAMPLES",

@@ -15,6 +15,9 @@ ADSB_ERR_TOO_LONG = -4
 ADSB_ERR_CAPACITY = -5
 ADSB_ERR_NOMEM = -6
 ADSB_ERR_BUSY = -7
+ADSB_ERR_POISONED = -8
+ADSB_WAIT_AUTO, ADSB_WAIT_SPIN, ADSB_WAIT_BLOCK = 0, 1, 2
+ADSB_FAULT_PHASE1, ADSB_FAULT_PHASE2, ADSB_FAULT_HANG, ADSB_FAULT_RECORDS = 1, 2, 3, 4
 
 
 class AdsbMsg(C.Structure):
@@ -173,6 +176,10 @@ def lib() -> C.CDLL:
     L.adsb_multi_selftest_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.adsb_multi_selftest_counters.restype = C.c_int
     L.adsb_multi_pending.argtypes = [vp]
+    L.adsb_multi_set_wait.argtypes = [vp, C.c_int]
+    L.adsb_multi_get_wait.argtypes = [vp]
+    L.adsb_multi_set_timeout_ms.argtypes = [vp, C.c_uint32]
+    L.adsb_multi_selftest_fail.argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
     L.adsb_multi_fetch_messages.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.adsb_multi_get_stats.argtypes = [vp, C.POINTER(AdsbMultiStats)]
     L.adsb_multi_filter_table.argtypes = [vp, vp]
@@ -182,7 +189,8 @@ def lib() -> C.CDLL:
                  "adsb_multi_icao_flush", "adsb_multi_demod_iq", "adsb_multi_demod_iq_device", "adsb_multi_submit_iq_device",
                  "adsb_multi_submit_iq", "adsb_multi_host_alloc", "adsb_multi_host_free",
                  "adsb_multi_collect", "adsb_multi_pending", "adsb_multi_fetch_messages", "adsb_multi_get_stats",
-                 "adsb_multi_filter_table"):
+                 "adsb_multi_filter_table", "adsb_multi_set_wait", "adsb_multi_get_wait", "adsb_multi_set_timeout_ms",
+                 "adsb_multi_selftest_fail"):
         getattr(L, name).restype = C.c_int
     L.adsb_host_replays.argtypes = [vp]
     L.adsb_host_replays.restype = C.c_uint64

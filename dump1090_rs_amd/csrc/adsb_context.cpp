@@ -42,6 +42,24 @@ struct DeviceStreams {
 std::mutex g_streams_mu;
 std::vector<DeviceStreams *> g_device_streams;   // (never freed: the streams live as long as the process)
 
+// A stream with a hardware queue of its own.  The runtime maps the streams of a process onto at most four hardware queues
+// per priority (GPU_MAX_HW_QUEUES): the fifth stream of a priority shares the queue of an earlier one -- whichever has the
+// fewest users at that moment -- and two streams on one queue run their work in order.  Which of the library's streams
+// ended up sharing therefore depended on how many streams of that priority the HOST had made before (torch's null stream,
+// the contexts' own streams): the four scan streams of a context for passes of a few buffers came out as two, three or
+// four queues, and the one-buffer ring ran at 9.0, 10.8 or 11.5 Gsample/s (profiles/r6_stream_queues.txt).  A stream
+// created with a CU mask never enters that pool -- the runtime gives it a queue of its own -- and a mask with every CU
+// enabled restricts nothing.
+hipError_t dedicated_stream(int device, hipStream_t *out)
+{
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+    if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+
 // under g_streams_mu, the device current
 int device_streams(adsb_ctx *c, int device, bool small, DeviceStreams **out)
 {
@@ -72,13 +90,15 @@ int device_streams(adsb_ctx *c, int device, bool small, DeviceStreams **out)
     }
     if (small && !d->small[0]) {
         // (measurement aid, tuning builds: 0 the two high-priority streams + two more, 1 those two + two of normal
-        // priority, 2 four of normal priority, 3 four high-priority ones of its own, 4 four of the lowest priority)
-        const int variant = tuning_env("ADSB_POOL_SMALL") ? std::atoi(tuning_env("ADSB_POOL_SMALL")) : 2;
+        // priority, 2 four of normal priority, 3 four high-priority ones of its own, 4 four of the lowest priority,
+        // 5 four streams with a hardware queue each: hipExtStreamCreateWithCUMask, every CU enabled)
+        const int variant = tuning_env("ADSB_POOL_SMALL") ? std::atoi(tuning_env("ADSB_POOL_SMALL")) : 5;
         const int mid = (d->least + d->greatest) / 2;
         for (int k = 0; k < kScanStreams; k++) {
             const bool share = (variant == 0 || variant == 1) && k < 2;
             const int prio = variant == 0 || variant == 3 ? d->greatest : (variant == 4 ? d->least : mid);
             if (share) d->small[k] = d->high[k];
+            else if (variant == 5) HIP_TRY(c, dedicated_stream(device, &d->small[k]));
             else HIP_TRY(c, hipStreamCreateWithPriority(&d->small[k], hipStreamNonBlocking, prio));
         }
     }

@@ -401,6 +401,13 @@ constexpr size_t kShardAddrCap = 16384;   // addresses per launch of k_set_addre
 int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool fresh_list = false);
 bool shard_phase_landed(adsb_ctx *c, int k);
 int shard_phase_wait(adsb_ctx *c, int k);
+// for a caller that polls (adsb_multi's device threads, once a phase has been out for a while): 1 the phase has
+// landed, 0 its launches are still running, negative: a stream reports an error, or every stream the phase ran on
+// is idle and no whole summary ever arrived (c->last_error says which)
+int shard_phase_check(adsb_ctx *c, int k);
+// every shard slot, every address superset and the device-side copy of the filter back to what adsb_create left
+// (blocking; nothing of this context may be in flight): how an adsb_multi whose capture failed starts over
+int shard_reset(adsb_ctx *c);
 int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs);
 int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra, const uint32_t *earlier = nullptr, size_t n_earlier = 0);
 // after phase 2 has landed, a shard the device scored: its messages (chunk = buffer index within the shard) and the values

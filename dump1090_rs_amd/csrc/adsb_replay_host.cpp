@@ -625,6 +625,7 @@ const char *adsb_strerror(int status)
     case ADSB_ERR_CAPACITY: return "output array too small";
     case ADSB_ERR_NOMEM: return "out of memory";
     case ADSB_ERR_BUSY: return "submissions are pending (collect them first) or too many are in flight";
+    case ADSB_ERR_POISONED: return "an earlier capture of this adsb_multi failed: adsb_multi_icao_flush starts the stream over";
     default: return "unknown status";
     }
 }

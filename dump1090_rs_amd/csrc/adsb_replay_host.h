@@ -124,8 +124,9 @@ void first_adders(const Crc24 &crc, const TrialRecord *rec, size_t n, ParallelRe
 // every part is; a thread that wakes up late finds the counter of ITS job used up and goes back to waiting.
 class ReplayPool {
   public:
-    // (on_start(k): run by worker k before anything else -- adsb_multi places it on a device's NUMA node)
-    explicit ReplayPool(int workers, std::function<void(int)> on_start = {})
+    // (on_start(k): run by worker k before anything else -- adsb_multi places it on a device's NUMA node; hot_us: how long
+    // a worker keeps spinning for the next job before it goes to sleep -- 0 for a host that is short of CPUs)
+    explicit ReplayPool(int workers, std::function<void(int)> on_start = {}, int hot_us = 1500) : hot_us_(hot_us)
     {
         for (int k = 0; k < workers; k++) th_.emplace_back([this, k, on_start] { work(k, on_start); });
     }
@@ -188,7 +189,7 @@ class ReplayPool {
             // a capture's second stage follows its first within microseconds, a busy stream's next capture within a
             // millisecond: stay hot that long, then sleep
             const auto t0 = std::chrono::steady_clock::now();
-            while (gen_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500))
+            while (gen_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(hot_us_))
                 __builtin_ia32_pause();
             std::shared_ptr<Job> job;
             {
@@ -201,6 +202,7 @@ class ReplayPool {
             if (job) take(*job, me);
         }
     }
+    const int hot_us_;
     std::vector<std::thread> th_;
     std::mutex mu_;
     std::condition_variable cv_;

@@ -260,6 +260,69 @@ int shard_phase_wait(adsb_ctx *c, int k)
     return ADSB_ERR_HIP;
 }
 
+int shard_phase_check(adsb_ctx *c, int k)
+{
+    if (shard_phase_landed(c, k)) return 1;
+    adsb_ctx::ShardJob &job = c->shard[k];
+    // the streams either phase can have launches on (the tail and score streams are shared with the other slots'
+    // shards -- and, in a process with several contexts on the device, with theirs: busy means "look again later")
+    hipStream_t qs[3] = {job.scan_q, c->tail_stream, job.wait_score ? c->score_stream : nullptr};
+    for (hipStream_t q : qs) {
+        if (!q) continue;
+        const hipError_t e = hipStreamQuery(q);
+        if (e == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        if (e != hipSuccess) return fail(c, e, "hipStreamQuery (a shard phase that has not landed)");
+    }
+    // idle streams: the summary was written before the launch retired
+    for (int attempt = 0; attempt < 200; attempt++) {
+        if (shard_phase_landed(c, k)) return 1;
+        for (volatile int spin = 0; spin < 2000; spin++) {}
+    }
+    c->last_error = "shard phase completed without publishing a whole summary";
+    return ADSB_ERR_HIP;
+}
+
+int shard_reset(adsb_ctx *c)
+{
+    for (int k = 0; k < c->n_scan_streams; k++) HIP_TRY(c, hipStreamSynchronize(c->scan_stream[k]));
+    HIP_TRY(c, hipStreamSynchronize(c->tail_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->score_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipStream_t q = c->own_stream;
+    for (int k = 0; k < c->n_bitmaps; k++)
+        if (int e = launch_reset(c->slot[0].d_ctr, c->d_bitmap[k], c->bitmap_lg, q)) return fail(c, (hipError_t)e, "launch_reset");
+    for (uint32_t *bm : c->exact_bm)
+        if (bm) HIP_TRY(c, hipMemsetAsync(bm, 0, kBitmapAllocWords * sizeof(uint32_t), q));
+    for (int si = 0; si < c->n_slots; si++) {
+        Slot &sl = c->slot[si];
+        adsb_ctx::ShardJob &job = c->shard[si];
+        // (what a phase that never ran its records kernel / k_order_prefix / k_emit leaves behind)
+        HIP_TRY(c, hipMemsetAsync(sl.d_ctr, 0, sizeof(Counters), q));
+        HIP_TRY(c, hipMemsetAsync(sl.d_order_cnt, 0, (c->max_chunks * fastgeo::kTilesPerChunk + 1) * sizeof(uint32_t), q));
+        if (sl.score.hash) HIP_TRY(c, hipMemsetAsync(sl.score.hash, 0xFF, ((size_t)sl.score.hash_mask + 1) * sizeof(unsigned long long), q));
+        if (sl.score.state) HIP_TRY(c, hipMemsetAsync(sl.score.state, 0, sizeof(ScoreState), q));
+        sl.h_sum->seq = 0;
+        if (sl.h_ssum) sl.h_ssum->seq = 0;
+        job.active = job.waiting = job.by_chunk = job.ran = false;
+        job.scored = job.wait_score = job.result_scored = job.exact_flush = false;
+        job.retired = nullptr;
+        job.exact = nullptr;
+        job.chunk_records.clear();
+    }
+    HIP_TRY(c, hipStreamSynchronize(q));
+    c->shard_active = false;
+    c->cur_exact = 0;
+    c->exact_valid = false;
+    ++c->score_epoch;
+    c->filter.flush();
+    c->flush_pending = false;   // (everything is clean: the capture behind this starts from an empty filter as it is)
+    c->shard_dense = false;
+    return ADSB_OK;
+}
+
 // after phase 1 has landed: the addresses this shard's replay can add (from the list its scan made, or out of its
 // records), sorted, no duplicates
 int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)

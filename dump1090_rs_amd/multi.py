@@ -52,7 +52,7 @@ class MultiContext:
 
     def _check(self, st: int, what: str) -> None:
         if st != _lib.ADSB_OK:
-            detail = self._L.adsb_multi_last_error(self._h).decode() if st == _lib.ADSB_ERR_HIP else ""
+            detail = self._L.adsb_multi_last_error(self._h).decode() if st in (_lib.ADSB_ERR_HIP, _lib.ADSB_ERR_NOMEM, _lib.ADSB_ERR_POISONED) else ""
             raise AdsbError(st, f"{what}: {self._L.adsb_strerror(st).decode()}", detail)
 
     # -- the reference's surface, over N devices
@@ -162,6 +162,21 @@ class MultiContext:
         self._check(self._L.adsb_multi_get_stats(self._h, C.byref(s)), "adsb_multi_get_stats")
         return {name: getattr(s, name) for name, _ in AdsbMultiStats._fields_ if name != "reserved"}
 
+    def set_wait(self, mode: int) -> None:
+        """adsb_multi_set_wait: _lib.ADSB_WAIT_AUTO / _SPIN / _BLOCK (how the handle's threads wait for their devices)."""
+        self._check(self._L.adsb_multi_set_wait(self._h, int(mode)), "adsb_multi_set_wait")
+
+    def get_wait(self) -> int:
+        return int(self._L.adsb_multi_get_wait(self._h))
+
+    def set_timeout_ms(self, ms: int) -> None:
+        self._check(self._L.adsb_multi_set_timeout_ms(self._h, int(ms)), "adsb_multi_set_timeout_ms")
+
+    def selftest_fail(self, captures_from_now: int, shard: int, kind: int) -> None:
+        """adsb_multi_selftest_fail: shard `shard` of the capture submitted `captures_from_now` submissions from now fails
+        (kind: _lib.ADSB_FAULT_PHASE1 / _PHASE2 / _HANG / _RECORDS; 0 disarms)."""
+        self._check(self._L.adsb_multi_selftest_fail(self._h, int(captures_from_now), int(shard), int(kind)), "adsb_multi_selftest_fail")
+
     def selftest_tune(self, fresh_cap: int = 0, parallel_min: int = 0, score_mode: int = 0) -> None:
         self._check(self._L.adsb_multi_selftest_tune(self._h, int(fresh_cap), int(parallel_min), int(score_mode)), "adsb_multi_selftest_tune")
 
@@ -170,7 +185,7 @@ class MultiContext:
         self._check(self._L.adsb_multi_selftest_counters(self._h, out), "adsb_multi_selftest_counters")
         return {"shards_sorted_on_host": out[0], "fresh_list_fallbacks": out[1], "device_ordered_shards": out[2],
                 "parallel_scored_captures": out[3], "device_scored_shards": out[4], "scored_results_used": out[5],
-                "scored_results_refused": out[6]}
+                "scored_results_refused": out[6], "poisoned": out[7]}
 
     def filter_table(self) -> np.ndarray:
         """Table A of the one ICAO filter (4096 u32, src/icao_filter.rs:8)."""

@@ -57,7 +57,10 @@ typedef enum {
                                 do not repeat the call -- adsb_fetch_messages hands out the whole
                                 list, which the context keeps until its next demod call */
     ADSB_ERR_NOMEM = -6,
-    ADSB_ERR_BUSY = -7       /* submissions pending where none are allowed, or too many in flight */
+    ADSB_ERR_BUSY = -7,      /* submissions pending where none are allowed, or too many in flight */
+    ADSB_ERR_POISONED = -8   /* an adsb_multi one of whose captures failed: what it computed after that capture is
+                                not the single stream's any more, so nothing further is accepted or returned until
+                                adsb_multi_icao_flush (with nothing in flight) has started the stream over */
 } adsb_status;
 
 #define ADSB_MAX_IN_FLIGHT 4
@@ -304,7 +307,19 @@ int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra
  * adsb_msg.chunk is the buffer's index in the whole capture.  Errors and ADSB_ERR_CAPACITY behave as for
  * the one-device calls (adsb_multi_fetch_messages hands out the whole list of a capture whose `out` was too
  * small).  One adsb_multi is driven by one host thread at a time.  Like every entry point of this header, these leave
- * the calling thread's current HIP device as they found it. */
+ * the calling thread's current HIP device as they found it.
+ *
+ * When a capture fails.  Every wait inside is bounded: a shard phase that has been out for 2 ms has its streams asked
+ * (a stream error fails the shard), and one that is still out after the handle's timeout (adsb_multi_set_timeout_ms,
+ * 30 s by default) fails it and gives the device up -- nothing more is enqueued on it, and adsb_multi_destroy leaks
+ * that device's context instead of waiting for a kernel that never ends.  The capture's collect (or blocking call)
+ * returns the failed shard's status, adsb_multi_last_error names the device, and the handle is POISONED: the one
+ * filter and the devices' address supersets have missed that capture's additions, so the captures in flight behind it
+ * and every later submission return ADSB_ERR_POISONED -- never a silently different frame list.  Collect what is in
+ * flight (each returns ADSB_ERR_POISONED), then adsb_multi_icao_flush: it resets every device's context, the filter
+ * and the exchange state, and the stream starts over from an empty filter, as after icao_flush().  If a device cannot
+ * be reset (it was given up, or the reset itself fails) the flush returns that error and the handle stays poisoned:
+ * destroy it.  adsb_multi_destroy never blocks on a device. */
 typedef struct adsb_multi adsb_multi;
 typedef struct {
     uint64_t n_samples;
@@ -353,6 +368,26 @@ int adsb_multi_get_stats(const adsb_multi *m, adsb_multi_stats *out);
  * in flight. */
 int adsb_multi_filter_table(const adsb_multi *m, uint32_t *out4096);
 const char *adsb_multi_last_error(const adsb_multi *m);
+/* How the handle's threads wait for their devices.
+ *   ADSB_WAIT_SPIN   a device thread polls its shard's summary in mapped memory while anything is out on its device
+ *                    (a phase's end is seen within a microsecond; costs a CPU per device while captures are in flight),
+ *                    the collector spins for 2 ms before it sleeps, the replay pool's workers stay hot for 1.5 ms;
+ *   ADSB_WAIT_BLOCK  the device threads sleep between looks (a timed wait on their command queue: 25 us while a
+ *                    phase is young, up to 1 ms as it ages; a command wakes them at once), the collector and the pool's
+ *                    workers sleep on their condition variables right away: next to no CPU, for a host whose cgroup
+ *                    quota or affinity mask is smaller than devices + 3 -- there spinning threads take the CPU from
+ *                    the one that has work, or get the whole process throttled;
+ *   ADSB_WAIT_AUTO   (default) BLOCK when the CPUs the process may use (affinity mask, cgroup cpu.max) are fewer
+ *                    than devices + 3, else SPIN; decided at create and again by this call.
+ * ADSB_ERR_BUSY while captures are in flight.  adsb_multi_get_wait returns what is in effect (SPIN or BLOCK). */
+#define ADSB_WAIT_AUTO 0
+#define ADSB_WAIT_SPIN 1
+#define ADSB_WAIT_BLOCK 2
+int adsb_multi_set_wait(adsb_multi *m, int mode);
+int adsb_multi_get_wait(const adsb_multi *m);
+/* After this long without a shard phase finishing, the device it runs on is given up (see "When a capture fails").
+ * 0 = the default, 30 000 ms.  May be called at any time. */
+int adsb_multi_set_timeout_ms(adsb_multi *m, uint32_t ms);
 
 /* Host only, no device needed: the ordered replay every demod call ends with
  * (score_modes_message src/mode_s/mod.rs:34-139 + best-of-5 selection
@@ -407,10 +442,21 @@ int adsb_selftest_set_order_polls(adsb_ctx *ctx, uint32_t polls);
  *               2: scored, but the collector refuses the result and fetches the records instead (the path a filter
  *               table about to fill up takes). */
 int adsb_multi_selftest_tune(adsb_multi *m, uint32_t fresh_cap, uint32_t parallel_min, uint32_t score_mode);
+/* Fault injection for the tests of "When a capture fails": shard `shard` of the capture submitted `captures_from_now`
+ * submissions after this call (0 = the next one) fails in the given way; kind 0 disarms.
+ *   ADSB_FAULT_PHASE1   its first phase is refused as if the launch had failed (ADSB_ERR_HIP);
+ *   ADSB_FAULT_PHASE2   ... its second phase;
+ *   ADSB_FAULT_HANG     its first phase is treated as never finishing: the timeout path, the device is given up;
+ *   ADSB_FAULT_RECORDS  its records are refused when the second phase has landed, as if their checksum had failed. */
+#define ADSB_FAULT_PHASE1 1
+#define ADSB_FAULT_PHASE2 2
+#define ADSB_FAULT_HANG 3
+#define ADSB_FAULT_RECORDS 4
+int adsb_multi_selftest_fail(adsb_multi *m, uint32_t captures_from_now, int shard, int kind);
 /* ... and what the shards did so far: out8[0] shards whose records the host had to put in order, [1] shards that took
  * the fresh_cap fallback, [2] shards whose second phase ordered its records on the device (a dense stream's), [3] captures
  * whose records were scored by several host threads at once, [4] shards scored on their device, [5] such results the
- * collector used, [6] ... and refused; [7] 0. */
+ * collector used, [6] ... and refused; [7] 1 while the handle is poisoned. */
 int adsb_multi_selftest_counters(const adsb_multi *m, uint64_t *out8);
 
 /* Host only, no context: the ordered replay done by several threads at once, as adsb_multi_collect does it for captures

@@ -15,6 +15,7 @@ pub const ADSB_ERR_TOO_LONG: c_int = -4;
 pub const ADSB_ERR_CAPACITY: c_int = -5;
 pub const ADSB_ERR_NOMEM: c_int = -6;
 pub const ADSB_ERR_BUSY: c_int = -7;
+pub const ADSB_ERR_POISONED: c_int = -8;
 
 /// `adsb_msg`: `ModeSMessage` (src/demod_2400.rs:92-102) + provenance.  40 bytes.
 #[repr(C)]
@@ -133,6 +134,9 @@ unsafe extern "C" {
     pub fn adsb_multi_get_stats(m: *const AdsbMulti, out: *mut AdsbMultiStats) -> c_int;
     pub fn adsb_multi_filter_table(m: *const AdsbMulti, out4096: *mut u32) -> c_int;
     pub fn adsb_multi_last_error(m: *const AdsbMulti) -> *const c_char;
+    pub fn adsb_multi_set_wait(m: *mut AdsbMulti, mode: c_int) -> c_int;
+    pub fn adsb_multi_get_wait(m: *const AdsbMulti) -> c_int;
+    pub fn adsb_multi_set_timeout_ms(m: *mut AdsbMulti, ms: u32) -> c_int;
     pub fn adsb_replay_records(filter_table: *mut u32, records: *mut AdsbTrial, n: usize, out: *mut AdsbMsg, cap: usize, n_out: *mut usize) -> c_int;
     pub fn adsb_format_raw(msg: *const AdsbMsg, out: *mut c_char, out_size: usize) -> c_int;
     pub fn adsb_read_test_data(path: *const c_char, iq_re_im: *mut i16, max_samples: usize, n_out: *mut usize) -> c_int;
@@ -141,6 +145,7 @@ unsafe extern "C" {
     pub fn adsb_selftest_gate_stages(ctx: *mut AdsbCtx, device_iq_re_im: *const c_void, n_samples: usize, preamble: *mut u64, preamble_cap: usize, n_preamble: *mut usize, snr: *mut u64, snr_cap: usize, n_snr: *mut usize) -> c_int;
     pub fn adsb_selftest_set_order_polls(ctx: *mut AdsbCtx, polls: u32) -> c_int;
     pub fn adsb_multi_selftest_tune(m: *mut AdsbMulti, fresh_cap: u32, parallel_min: u32, score_mode: u32) -> c_int;
+    pub fn adsb_multi_selftest_fail(m: *mut AdsbMulti, captures_from_now: u32, shard: c_int, kind: c_int) -> c_int;
     pub fn adsb_multi_selftest_counters(m: *const AdsbMulti, out8: *mut u64) -> c_int;
     pub fn adsb_selftest_parallel_replay(filter_table: *mut u32, records: *const AdsbTrial, n: usize, runs: c_int, parts: c_int, threads: c_int, out: *mut AdsbMsg, cap: usize, n_out: *mut usize, went_parallel: *mut c_int) -> c_int;
     pub fn adsb_selftest_crc_table(out256: *mut u32) -> c_int;

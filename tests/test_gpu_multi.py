@@ -540,17 +540,15 @@ def test_compiled_c_host_drives_the_multi_entry_points(hip_lib, golden):
     assert subprocess.run([str(exe), "--multi", "3", str(GOLDEN / fx["file"]), *fx["frames"][:-1]], capture_output=True).returncode == 1
 
 
-def test_two_gib_capture_through_one_device_and_through_eight_contexts(hip_lib, oracle_mod):
-    """BASELINE config 4's capture size once through the entry points (2 GiB = 4096 buffers would take the oracle
-    a minute: 512 buffers = 256 MiB here, the bench runs the 2 GiB one): one device holding everything, then eight
-    contexts of 64 buffers -- both equal to the oracle."""
+def capture_through_one_device_and_through_eight_contexts(oracle_mod, n_buffers, n_bursts, seed, threads):
     import torch
     from dump1090_rs_amd.multi import MultiContext
-    n = 512 * CHUNK
-    dev = synth.make_iq_torch(n, n_bursts=400, seed=77001, device=torch.device("cuda", 0))
+    n = n_buffers * CHUNK
+    dev = synth.make_iq_torch(n, n_bursts=n_bursts, seed=seed, device=torch.device("cuda", 0))
     torch.cuda.synchronize()
-    want, _ = oracle_mod.Oracle().demod_iq(dev.cpu().numpy(), cap=1 << 18, threads=8)
-    for devices, per in (([0], 512), ([0] * 8, 64)):
+    want, _ = oracle_mod.Oracle().demod_iq(dev.cpu().numpy(), cap=1 << 18, threads=threads)
+    assert len(want) >= n_bursts * 9 // 10
+    for devices, per in (([0], n_buffers), ([0] * 8, n_buffers // 8)):
         with MultiContext(devices, per) as multi:
             ranges = multi.shard_ranges(n)
             ptrs = [dev.data_ptr() + 4 * a for a, _ in ranges]
@@ -565,3 +563,154 @@ def test_two_gib_capture_through_one_device_and_through_eight_contexts(hip_lib, 
                 multi.submit_iq_device(ptrs, ns)
             while multi.pending():
                 assert [key(m) for m in multi.collect(cap=1 << 18)] == [want_key(w) for w in want]
+
+
+def test_256_mib_capture_through_one_device_and_through_eight_contexts(hip_lib, oracle_mod):
+    """512 buffers = 256 MiB: one device holding everything, then eight contexts of 64 buffers -- both equal to the
+    oracle, blocking and four captures in flight."""
+    capture_through_one_device_and_through_eight_contexts(oracle_mod, 512, 400, 77001, 8)
+
+
+def test_two_gib_capture_through_one_device_and_through_eight_contexts(hip_lib, oracle_mod):
+    """BASELINE config 4's capture, the real size: 4096 buffers = 2 GiB through one context of 4096 buffers and through
+    eight of 512, against the threaded oracle over the whole capture (sixteen threads: a second or two)."""
+    capture_through_one_device_and_through_eight_contexts(oracle_mod, 4096, 3200, 77002, 16)
+
+
+# ------------------------------------------------------------------------------------------------ when a capture fails
+def fault_kinds():
+    from dump1090_rs_amd import _lib
+    return [_lib.ADSB_FAULT_PHASE1, _lib.ADSB_FAULT_PHASE2, _lib.ADSB_FAULT_RECORDS]
+
+
+@pytest.mark.parametrize("per,kind_idx,wait", [(5, 0, 0), (5, 1, 2), (5, 2, 1), (24, 0, 2), (24, 1, 0), (24, 2, 0)])
+def test_a_failed_shard_poisons_the_handle_and_a_flush_starts_the_stream_over(hip_lib, oracle_mod, per, kind_idx, wait):
+    """include/adsb_hip.h, "When a capture fails": one of eight shards of the third capture of a pipeline fails (phase 1,
+    phase 2, or its records refused).  The captures in front of it are the oracle's; ITS collect returns the shard's
+    error and names the device; the captures in flight behind it and a further submission return ADSB_ERR_POISONED --
+    never a silently different list; adsb_multi_icao_flush with captures still in flight is refused; with nothing in
+    flight it resets every context, and what follows equals ONE fresh oracle stream, learned addresses and
+    address/parity hits included; destroy returns.  Contexts of 5 buffers (folded supersets, one-launch phases) and of 24
+    (full bitmaps, exact bitmaps, device-scored dense shards); spinning and blocking device threads."""
+    import torch
+    from dump1090_rs_amd import _lib
+    from dump1090_rs_amd._lib import AdsbError
+    from dump1090_rs_amd.multi import MultiContext
+    kind = fault_kinds()[kind_idx]
+    n_buf = 8 * per - 3
+    caps = [np.ascontiguousarray(coupled_capture8(4300 + i)[: n_buf * CHUNK]) if per == 5 else dense_capture(6300 + i, n_buf, 6, n_icao=12)
+            for i in range(7)]
+    orc = oracle_mod.Oracle()
+    wants_before = [orc.demod_iq(caps[i])[0] for i in (0, 1)]
+    with MultiContext([0] * 8, per) as multi:
+        multi.set_wait(wait)
+        resident = [to_devices(iq, multi, torch) for iq in caps]
+        multi.icao_flush()
+        multi.submit_iq_device(*resident[0][1:])
+        multi.submit_iq_device(*resident[1][1:])
+        multi.selftest_fail(0, 5, kind)                       # shard 5 of the NEXT capture
+        multi.submit_iq_device(*resident[2][1:])
+        multi.submit_iq_device(*resident[3][1:])
+        for i in (0, 1):
+            assert [key(m) for m in multi.collect()] == [want_key(w) for w in wants_before[i]], f"capture {i}"
+        with pytest.raises(AdsbError) as e:
+            multi.collect()
+        assert e.value.status == _lib.ADSB_ERR_HIP and "shard 5" in str(e.value) and "injected" in str(e.value)
+        assert multi.stats()["n_messages"] == 0
+        with pytest.raises(AdsbError) as e:                    # behind it: submitted before the failure was known
+            multi.submit_iq_device(*resident[4][1:])
+        assert e.value.status == _lib.ADSB_ERR_POISONED and multi.pending() == 1
+        with pytest.raises(AdsbError) as e:                    # the restart wants nothing in flight
+            multi.icao_flush()
+        assert e.value.status == _lib.ADSB_ERR_BUSY
+        with pytest.raises(AdsbError) as e:
+            multi.collect()
+        assert e.value.status == _lib.ADSB_ERR_POISONED and multi.pending() == 0
+        with pytest.raises(AdsbError) as e:
+            multi.demod_iq(caps[4])
+        assert e.value.status == _lib.ADSB_ERR_POISONED and multi.selftest_counters()["poisoned"] == 1
+        multi.icao_flush()                                     # the restart
+        assert multi.selftest_counters()["poisoned"] == 0
+        fresh = oracle_mod.Oracle()
+        fresh.icao_flush()
+        for i in (4, 5, 6, 2):
+            multi.submit_iq_device(*resident[i][1:])
+        for i in (4, 5, 6, 2):
+            assert [key(m) for m in multi.collect(cap=1 << 16)] == [want_key(w) for w in fresh.demod_iq(caps[i])[0]], f"capture {i} after the restart"
+        assert np.array_equal(multi.filter_table(), np.ctypeslib.as_array(fresh.filter.a))
+
+
+def test_a_device_that_stops_answering_is_given_up_and_destroy_returns(hip_lib, oracle_mod):
+    """The timeout path: a shard phase that "never finishes" (the hook makes the device thread blind to it) fails its
+    capture after the handle's timeout, the device is given up, everything behind it is refused, the restart is refused
+    too (a dead device cannot be reset), and adsb_multi_destroy returns instead of waiting for it."""
+    import time
+    import torch
+    from dump1090_rs_amd import _lib
+    from dump1090_rs_amd._lib import AdsbError
+    from dump1090_rs_amd.multi import MultiContext
+    iq = np.ascontiguousarray(coupled_capture8(4400)[: 16 * CHUNK])
+    want = oracle_mod.Oracle().demod_iq(iq)[0]
+    multi = MultiContext([0] * 4, 4)
+    multi.set_timeout_ms(250)
+    res = to_devices(iq, multi, torch)
+    multi.icao_flush()
+    assert [key(m) for m in multi.demod_iq_device(*res[1:])] == [want_key(w) for w in want]
+    multi.selftest_fail(1, 2, _lib.ADSB_FAULT_HANG)           # shard 2 of the capture AFTER the next
+    multi.submit_iq_device(*res[1:])
+    multi.submit_iq_device(*res[1:])
+    multi.submit_iq_device(*res[1:])
+    t0 = time.perf_counter()
+    assert len(multi.collect()) > 0                           # (no flush in between: more address/parity hits than the first time)
+    with pytest.raises(AdsbError) as e:
+        multi.collect()
+    waited = time.perf_counter() - t0
+    assert e.value.status == _lib.ADSB_ERR_HIP and "timeout" in str(e.value) and 0.2 < waited < 5.0
+    with pytest.raises(AdsbError) as e:
+        multi.collect()
+    assert e.value.status == _lib.ADSB_ERR_POISONED
+    with pytest.raises(AdsbError) as e:
+        multi.icao_flush()
+    assert e.value.status == _lib.ADSB_ERR_HIP and "destroy" in str(e.value)
+    t0 = time.perf_counter()
+    multi.close()
+    assert time.perf_counter() - t0 < 5.0
+    # ... and the process goes on: a new handle on the same device works
+    with MultiContext([0] * 4, 4) as again:
+        again.icao_flush()
+        assert [key(m) for m in again.demod_iq_device(*res[1:])] == [want_key(w) for w in want]
+
+
+def test_blocking_wait_mode_gives_the_same_results_and_auto_follows_the_cpus(hip_lib, oracle_mod):
+    """adsb_multi_set_wait: the device threads asleep between looks (ADSB_WAIT_BLOCK) instead of polling mapped memory;
+    AUTO resolves to BLOCK when the process may use fewer CPUs than devices + 3 (affinity mask) and to SPIN otherwise."""
+    import os
+    import torch
+    from dump1090_rs_amd import _lib
+    from dump1090_rs_amd.multi import MultiContext
+    iq = dense_capture(6400, 8 * 20 - 2, 6, n_icao=12)
+    want = oracle_mod.Oracle().demod_iq(iq)[0]
+    before = os.sched_getaffinity(0)
+    try:
+        with MultiContext([0] * 8, 20) as multi:
+            res = to_devices(iq, multi, torch)
+            for mode in (_lib.ADSB_WAIT_BLOCK, _lib.ADSB_WAIT_SPIN, _lib.ADSB_WAIT_BLOCK):
+                multi.set_wait(mode)
+                assert multi.get_wait() == mode
+                for _ in range(6):
+                    if multi.pending() == multi.max_in_flight():
+                        assert [key(m) for m in multi.collect(cap=1 << 16)] == [want_key(w) for w in want]
+                    multi.icao_flush()
+                    multi.submit_iq_device(*res[1:])
+                while multi.pending():
+                    assert [key(m) for m in multi.collect(cap=1 << 16)] == [want_key(w) for w in want]
+            if len(before) >= 11:
+                multi.set_wait(_lib.ADSB_WAIT_AUTO)
+                cpu_max = open("/sys/fs/cgroup/cpu.max").read().split() if os.path.exists("/sys/fs/cgroup/cpu.max") else ["max"]
+                quota = None if cpu_max[0] == "max" else int(cpu_max[0]) // int(cpu_max[1])
+                assert multi.get_wait() == (_lib.ADSB_WAIT_SPIN if quota is None or quota >= 11 else _lib.ADSB_WAIT_BLOCK)
+            os.sched_setaffinity(0, sorted(before)[:4])
+            multi.set_wait(_lib.ADSB_WAIT_AUTO)
+            assert multi.get_wait() == _lib.ADSB_WAIT_BLOCK
+    finally:
+        os.sched_setaffinity(0, before)

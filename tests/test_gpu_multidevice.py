@@ -40,11 +40,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench_as_one_nccl_rank(*extra, timeout=600):
+def _bench_as_one_nccl_rank(*extra, timeout=600, also=False):
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), ADSB_BENCH_FORCE_DIST="1", ADSB_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--blocks", "1",
-                        "--ramp-ms", "20", "--no-also", *extra], capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
+                        "--ramp-ms", "20", *([] if also else ["--no-also"]), *extra], capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -69,6 +69,24 @@ def test_bench_shard_workload_as_one_rank_over_rccl(hip_lib, oracle_mod):
     single stream) with RCCL as the default backend."""
     line = _bench_as_one_nccl_rank("--workload", "shard", "--capture-chunks", "48")
     assert line["backend"] == "nccl" and line["shard_merge_equals_single_stream"] is True and line["scaling"] == "strong"
+
+
+def test_bench_one_process_over_all_devices_behind_the_ranks_timed_region(hip_lib, oracle_mod):
+    """What `bench.py --gpus N` does after its timed independent-stream region: every rank closes
+    its context and waits at a host-side (gloo) barrier while rank 0 drives ONE adsb_multi over all the devices it sees
+    -- the reference's shape, one process and one filter (dump1090_rs/src/main.rs:154-167) -- sparse and busy sky, each
+    checked against the threaded oracle over the whole capture.  Here: one rank, RCCL as the default backend, a
+    capture of 96 buffers."""
+    line = _bench_as_one_nccl_rank("--chunks", "32", "--capture-chunks", "96", also=True)
+    assert line["backend"] == "nccl" and line["parity_checked"] is True
+    leg = line["also"]["config4_one_process_n_devices"]
+    assert leg["parity_checked"] is True and "error" not in leg
+    assert [r["sky"] for r in leg["runs"]] == ["sparse", "busy_sky"]
+    for r in leg["runs"]:
+        assert r["parity_checked"] is True and r["parity_frames"] > 0 and r["value"] > 0 and r["devices"] == [0]
+        assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
+        assert set(r["blocking_steps_host_clock"]) >= {"ms_wall", "ms_phase1_span", "ms_phase2_span", "ms_exchange", "ms_replay", "ms_overhead"}
+    assert set(line["also"]) == {"config4_one_process_n_devices"}     # (the N = 1 legs are not run under a process group)
 
 
 # ------------------------------------------------------------------------------------------------ device > 0

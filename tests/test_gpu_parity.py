@@ -1578,13 +1578,15 @@ def test_bench_line_keeps_the_driver_contract(hip_lib, oracle_mod):
     """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver reads:
     the metric / value / unit block, `roofline` (bound, achieved, peak, unit, frac, traffic) for the
     dominant kernel, `cpu_baseline` (value, unit, cores, kind, sample) and the parity flag -- checked on a
-    small workload (32 buffers, no ramp, no extra legs)."""
+    small workload (32 buffers, no ramp; of the extra legs only config 4's, on a capture of 96 buffers:
+    `also.config4_sharded_capture` = the capture through adsb_multi_* on one context and on eight, sparse and busy sky,
+    each against the threaded oracle over the whole capture)."""
     import json
     import subprocess
     import sys
     from tests.conftest import ROOT
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--chunks", "32",
-                        "--ramp-ms", "0", "--no-also"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+                        "--ramp-ms", "0", "--also-only", "config4", "--capture-chunks", "96"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -1601,3 +1603,10 @@ def test_bench_line_keeps_the_driver_contract(hip_lib, oracle_mod):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["sample"]
     assert d["parity_checked"] is True and d["parity_frames"] > 0 and d["per_rank_ms_per_step"] and d["world_size_seen"] == 1
+    c4 = d["also"]["config4_sharded_capture"]
+    assert set(d["also"]) == {"config4_sharded_capture"} and c4["parity_checked"] is True
+    assert [(r["sky"], r["shards"]) for r in c4["runs"] if r["shards"] in (1, 8)] == [("sparse", 1), ("sparse", 8), ("busy_sky", 1), ("busy_sky", 8)]
+    for r in c4["runs"]:
+        assert r["parity_checked"] is True and r["parity_frames"] > 0 and r["value"] > 0 and r["steps"] == 4
+        assert r["roofline"]["bound"] == "hbm" and r["roofline"]["unit"] == "GB/s" and 0 < r["roofline"]["frac"] < 1
+        assert abs(r["roofline"]["achieved"] - 4 * 96 * 131072 / (r["ms_per_step"] * 1e-3) / 1e9) / r["roofline"]["achieved"] < 0.01

@@ -162,7 +162,7 @@ def test_the_comparison_does_notice_a_changed_prototype(tmp_path, monkeypatch):
 def test_status_constants_match_the_header():
     hdr = dict(re.findall(r"^\s*(ADSB_(?:OK|ERR_\w+))\s*=\s*(-?\d+)", strip_comments(HEADER.read_text()), flags=re.M))
     ffi = dict(re.findall(r"pub const (ADSB_\w+): c_int = (-?\d+);", FFI.read_text()))
-    assert hdr == ffi and len(hdr) == 8
+    assert hdr == ffi and len(hdr) == 9
     from dump1090_rs_amd import _lib
     assert {k: int(v) for k, v in hdr.items()} == {k: getattr(_lib, k) for k in hdr}
 
