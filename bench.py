@@ -621,7 +621,7 @@ def resident_result(env: Env, args, r, workload: str):
                       "library build, tools/sq_counters.py; not measured in this run)"}
     # ... and the two floors of the kernel beside it: the memory floor of its access pattern (the kernel cut after P1: the
     # whole HBM read, none of the later stages) and where its vector instructions go, stage by stage -- committed
-    # measurements of this library build (tools/session_ablate.sh, tools/stage_split.py), not taken in this run.
+    # measurements of this library build (tools/experiments/sessions/session_ablate.sh, tools/stage_split.py), not taken in this run.
     split = _profile_json("scan_stage_split.json", library, args.chunks)
     if split:
         result["roofline"]["memory_floor_ms"] = split["memory_floor_ms"]
@@ -1076,8 +1076,18 @@ def run_shard_single_process(env: Env, args):
         want = solo.demod_iq_device(whole.data_ptr(), total_chunks * CHUNK, cap=cap)
     key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
     same = [key(m) for m in merged] == [key(m) for m in want]
+    # ... and the CPU oracle over the whole capture (threads over buffers, one ordered replay)
+    from oracle import binding
+    orc = binding.Oracle()
+    orc.icao_flush()
+    with env.all_cores():
+        oracle_want, _ = orc.demod_iq(whole.cpu().numpy(), cap=cap, threads=_oracle_threads())
+    parity = _same(merged, oracle_want)
     del whole
     n = total_chunks * CHUNK
+    ms_step = elapsed / args.steps * 1e3
+    n_real = len(set(devices))
+    gbs = n * BYTES_PER_SAMPLE / (ms_step * 1e-3) / 1e9
     result = {
         "metric": "IQ Msamples/s demodulated", "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
         "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
@@ -1098,7 +1108,11 @@ def run_shard_single_process(env: Env, args):
                                "replay through one filter on the caller's thread; no process group, no collective",
                    "host_api": f"adsb_multi_submit_iq_device / adsb_multi_collect, {depth} captures in flight",
                    "library": _lib.lib().adsb_version().decode(), "host_affinity": env.affinity_summary(), "clock_ramp": ramp},
-        "shard_merge_equals_single_stream": bool(same), "parity_frames": len(want),
+        "shard_merge_equals_single_stream": bool(same), "parity_checked": bool(parity), "parity_frames": len(oracle_want),
+        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * n_real, "unit": "GB/s",
+                     "frac": round(gbs / (HBM_PEAK_GBS * n_real), 4), "traffic": None,
+                     "is": f"{BYTES_PER_SAMPLE} B per sample x the capture's samples / the whole step, against {n_real} x 8 TB/s "
+                           "(step-level: every kernel of both shard phases, the exchange and the replay are inside)"},
     }
     multi.close()
     del parts

@@ -564,6 +564,6 @@ int adsb_get_stats(const adsb_ctx *c, adsb_stats *out)
 
 const char *adsb_last_error(const adsb_ctx *c) { return c ? c->last_error.c_str() : ""; }
 
-const char *adsb_version(void) { return "adsb_hip 0.20 gfx950 scan=v9-tile-buckets tail=v7-folded-supersets multi=v2-device-scored-shards"; }
+const char *adsb_version(void) { return "adsb_hip 0.21 gfx950 scan=v9-tile-buckets tail=v7-folded-supersets multi=v3-bounded-waits streams=v2-own-queues"; }
 
 }  // extern "C"

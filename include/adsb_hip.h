@@ -25,6 +25,8 @@
  * (process-global statics in the reference, src/icao_filter.rs:8-9) lives in the
  * context, so contexts are independent streams.  There is no CPU fallback:
  * adsb_create fails with ADSB_ERR_NO_DEVICE when no gfx950 device is usable.
+ * The host side of the library is built for x86-64 Linux hosts (its spin loops are
+ * the `pause` instruction; thread placement reads sysfs): the hosts MI355X boards sit in.
  */
 #ifndef ADSB_HIP_H
 #define ADSB_HIP_H

@@ -9,4 +9,4 @@ for n in 1 8; do
   tail -1 gpurun_out/bench_multi${n}_$T.json | cut -c1-240
 done
 python tools/hosttime.py resident --chunks 1 --depth 8 2>&1 | grep -v amdgpu.ids > gpurun_out/hosttime_resident_$T.txt; cat gpurun_out/hosttime_resident_$T.txt
-tools/session_ablate.sh 2>&1 | grep -v amdgpu.ids > gpurun_out/ablate_$T.txt; rm -rf gpurun_out/abl_r5; tail -9 gpurun_out/ablate_$T.txt
+tools/experiments/sessions/session_ablate.sh 2>&1 | grep -v amdgpu.ids > gpurun_out/ablate_$T.txt; rm -rf gpurun_out/abl_r5; tail -9 gpurun_out/ablate_$T.txt

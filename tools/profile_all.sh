@@ -14,7 +14,7 @@ python tools/hosttime.py ring --chunks 1 --depth 8 > gpurun_out/hosttime_ring_$T
 for ch in 2 4 8 16; do python tools/hosttime.py ring --chunks $ch --depth 8 --passes 6000 >> gpurun_out/hosttime_ring_$T.txt 2>&1; done
 python tools/hosttime.py ring --chunks 1 --depth 1 >> gpurun_out/hosttime_ring_$T.txt 2>&1
 python tools/hosttime.py resident --chunks 1 --depth 8 >> gpurun_out/hosttime_ring_$T.txt 2>&1
-python tools/config1.py > gpurun_out/config1_$T.txt 2>&1
+python tools/experiments/config1.py > gpurun_out/config1_$T.txt 2>&1
 ADSB_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --no-also > gpurun_out/bench_gloo2_$T.json 2> gpurun_out/bench_gloo2_$T.err
 ADSB_BENCH_BACKEND=gloo timeout 1200 python bench.py --gpus 8 --no-also > gpurun_out/bench_gloo8_$T.json 2> gpurun_out/bench_gloo8_$T.err
 ADSB_BENCH_BACKEND=gloo timeout 1200 python bench.py --gpus 8 --workload shard --capture-chunks 512 --no-also > gpurun_out/bench_gloo8_shard_$T.json 2> gpurun_out/bench_gloo8_shard_$T.err

@@ -1,4 +1,4 @@
-"""tools/session_ablate.sh's output -> profiles/scan_stage_split.json: the vector wave-instructions k_scan_fast issues per launch in
+"""tools/experiments/sessions/session_ablate.sh's output -> profiles/scan_stage_split.json: the vector wave-instructions k_scan_fast issues per launch in
 each stage (SQ_INSTS_VALU with the kernel cut short after the stage, ADSB_DEBUG_STOP, differences), per wave-tile, and the blocking
 launch durations of the cuts -- the P1-only one is the memory floor of this access pattern (the whole HBM read, no later stage).
 usage: python tools/stage_split.py gpurun_out/r5_ablate.txt "<library version string>" > profiles/scan_stage_split.json"""
@@ -24,6 +24,6 @@ out = {"library": sys.argv[2], "chunks": 512, "wave_tiles_per_launch": wave_tile
        "memory_floor_is": "k_scan_fast cut after P1 (ADSB_DEBUG_STOP=1, tuning build, blocking launches, tools/ablate.py --sync): the whole "
                           "HBM read of a launch with none of the later stages -- what this access pattern (8080 magnitudes per 7712 positions, "
                           "eight 16-byte loads per thread in flight, four workgroups per CU) takes at best",
-       "source": "tools/session_ablate.sh: rocprofv3 --pmc SQ_INSTS_VALU ... over bench.py with ADSB_DEBUG_STOP = 1, 2, 3, 6, 4, 5, 0 (differences between "
+       "source": "tools/experiments/sessions/session_ablate.sh: rocprofv3 --pmc SQ_INSTS_VALU ... over bench.py with ADSB_DEBUG_STOP = 1, 2, 3, 6, 4, 5, 0 (differences between "
                  "consecutive cuts), and tools/ablate.py --sync for the durations"}
 print(json.dumps(out, indent=1))
