@@ -1309,13 +1309,17 @@ def one_process_n_devices_leg(env: Env, args):
     group: an RCCL barrier would keep a spinning kernel on the very devices being measured).  Returns the leg on rank 0,
     None elsewhere."""
     torch = env.torch
-    group = env.dist.new_group(backend="gloo") if env.dist is not None else None
+    import datetime
+    group = env.dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=15)) if env.dist is not None else None
     leg = None
     if env.rank == 0:
         try:
             n_vis = torch.cuda.device_count()
             devices = list(range(env.world)) if n_vis >= env.world else [k % n_vis for k in range(env.world)]
-            leg = config4_leg(env, args, [devices], args.steps)
+            # (the rank is pinned to the cores of ITS GPU's NUMA node; the library places a thread per device on that
+            # device's node, within what the process may use: give it the whole mask back for this leg)
+            with env.all_cores():
+                leg = config4_leg(env, args, [devices], args.steps)
             leg["devices_visible_to_rank0"] = n_vis
             leg["is"] = (f"rank 0 alone, the other {env.world - 1} rank(s) idle at a host-side barrier: adsb_multi over devices {devices}")
         except Exception as e:   # the headline line must still come out; the failure is in it

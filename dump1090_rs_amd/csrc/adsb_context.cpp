@@ -78,13 +78,20 @@ int device_streams(adsb_ctx *c, int device, bool small, DeviceStreams **out)
     // They must have the SAME priority: with different ones, whenever two scans are pending at once the higher one
     // starts first, its successor on that stream is then free earlier too, and the stream settles into finishing
     // passes in the order 2, 1, 4, 3, ... for thousands of passes, 8-10 % slower (measured over 22 000 passes).
+    // (measurement aid, tuning builds: ADSB_POOL_LARGE=1 the two scan streams of large contexts with a hardware queue each
+    // instead of the highest priority, =2 the tail and score streams as well)
+    const int large_variant = tuning_env("ADSB_POOL_LARGE") ? std::atoi(tuning_env("ADSB_POOL_LARGE")) : 0;
     if (!d->high[0])
-        for (auto &q : d->high) HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, d->greatest));
+        for (auto &q : d->high) {
+            if (large_variant >= 1) HIP_TRY(c, dedicated_stream(device, &q));
+            else HIP_TRY(c, hipStreamCreateWithPriority(&q, hipStreamNonBlocking, d->greatest));
+        }
     if (!d->n_low) {
         const int n = 2;
         for (int k = 0; k < 4; k++) {
-            if (k < n) HIP_TRY(c, hipStreamCreateWithPriority(&d->low[k], hipStreamNonBlocking, d->least));
-            else d->low[k] = d->low[k % n];
+            if (k >= n) d->low[k] = d->low[k % n];
+            else if (large_variant >= 2) HIP_TRY(c, dedicated_stream(device, &d->low[k]));
+            else HIP_TRY(c, hipStreamCreateWithPriority(&d->low[k], hipStreamNonBlocking, d->least));
         }
         d->n_low = n;
     }

@@ -950,11 +950,14 @@ int deliver_multi(adsb_multi *m, std::vector<adsb_msg> &msgs, adsb_msg *out, siz
 
 void resolve_wait(adsb_multi *m)
 {
-    // AUTO: the device threads spin while anything is out on their device -- worth a CPU each where the process has them
-    // (a phase's end is seen within a fraction of a microsecond), ruinous where it has not: threads beyond a cgroup's
-    // quota get the whole process throttled, threads beyond the affinity mask take turns with the one that has work
+    // AUTO: the device threads spin while anything is out on their device -- a phase's end is seen within a fraction of a
+    // microsecond, which is worth 4-7 % to a caller with ONE capture in flight and nothing to a pipelined one -- where that
+    // is cheap: at most half of the CPUs the process may use (affinity mask, cgroup quota) go to threads that spin or score
+    // (devices + caller + a few pool workers).  Where it is not, spinning is ruinous: threads beyond a cgroup's quota get the
+    // whole process throttled, threads beyond the affinity mask take turns with the one that has work (measured on eight
+    // contexts under four CPUs: +43-54 % per capture; profiles/r6_wait_policy.txt)
     bool block = m->wait_setting == ADSB_WAIT_BLOCK;
-    if (m->wait_setting == ADSB_WAIT_AUTO) block = usable_cpus() < m->n + 3;
+    if (m->wait_setting == ADSB_WAIT_AUTO) block = usable_cpus() < 2 * (m->n + 3);
     m->block.store(block, std::memory_order_relaxed);
 }
 

@@ -376,11 +376,13 @@ const char *adsb_multi_last_error(const adsb_multi *m);
  *                    the collector spins for 2 ms before it sleeps, the replay pool's workers stay hot for 1.5 ms;
  *   ADSB_WAIT_BLOCK  the device threads sleep between looks (a timed wait on their command queue: 25 us while a
  *                    phase is young, up to 1 ms as it ages; a command wakes them at once), the collector and the pool's
- *                    workers sleep on their condition variables right away: next to no CPU, for a host whose cgroup
- *                    quota or affinity mask is smaller than devices + 3 -- there spinning threads take the CPU from
- *                    the one that has work, or get the whole process throttled;
+ *                    workers sleep on their condition variables right away: a quarter of the CPU time, the same
+ *                    throughput for a caller with several captures in flight, 4-7 % more latency for one that has a
+ *                    single capture in flight (profiles/r6_wait_policy.txt).  Where the process is short of CPUs
+ *                    (a cgroup quota, an affinity mask) it is the only sane form: spinning threads take the CPU from
+ *                    the one that has work, or get the whole process throttled (+43-54 % per capture under 4 CPUs);
  *   ADSB_WAIT_AUTO   (default) BLOCK when the CPUs the process may use (affinity mask, cgroup cpu.max) are fewer
- *                    than devices + 3, else SPIN; decided at create and again by this call.
+ *                    than 2 x (devices + 3), else SPIN; decided at create and again by this call.
  * ADSB_ERR_BUSY while captures are in flight.  adsb_multi_get_wait returns what is in effect (SPIN or BLOCK). */
 #define ADSB_WAIT_AUTO 0
 #define ADSB_WAIT_SPIN 1

@@ -683,7 +683,8 @@ def test_a_device_that_stops_answering_is_given_up_and_destroy_returns(hip_lib, 
 
 def test_blocking_wait_mode_gives_the_same_results_and_auto_follows_the_cpus(hip_lib, oracle_mod):
     """adsb_multi_set_wait: the device threads asleep between looks (ADSB_WAIT_BLOCK) instead of polling mapped memory;
-    AUTO resolves to BLOCK when the process may use fewer CPUs than devices + 3 (affinity mask) and to SPIN otherwise."""
+    AUTO resolves to BLOCK when the process may use fewer CPUs than 2 x (devices + 3) (affinity mask, cgroup quota) and to
+    SPIN otherwise."""
     import os
     import torch
     from dump1090_rs_amd import _lib
@@ -704,11 +705,10 @@ def test_blocking_wait_mode_gives_the_same_results_and_auto_follows_the_cpus(hip
                     multi.submit_iq_device(*res[1:])
                 while multi.pending():
                     assert [key(m) for m in multi.collect(cap=1 << 16)] == [want_key(w) for w in want]
-            if len(before) >= 11:
-                multi.set_wait(_lib.ADSB_WAIT_AUTO)
-                cpu_max = open("/sys/fs/cgroup/cpu.max").read().split() if os.path.exists("/sys/fs/cgroup/cpu.max") else ["max"]
-                quota = None if cpu_max[0] == "max" else int(cpu_max[0]) // int(cpu_max[1])
-                assert multi.get_wait() == (_lib.ADSB_WAIT_SPIN if quota is None or quota >= 11 else _lib.ADSB_WAIT_BLOCK)
+            multi.set_wait(_lib.ADSB_WAIT_AUTO)
+            cpu_max = open("/sys/fs/cgroup/cpu.max").read().split() if os.path.exists("/sys/fs/cgroup/cpu.max") else ["max"]
+            usable = len(before) if cpu_max[0] == "max" else min(len(before), max(1, int(cpu_max[0]) // int(cpu_max[1])))
+            assert multi.get_wait() == (_lib.ADSB_WAIT_SPIN if usable >= 22 else _lib.ADSB_WAIT_BLOCK)
             os.sched_setaffinity(0, sorted(before)[:4])
             multi.set_wait(_lib.ADSB_WAIT_AUTO)
             assert multi.get_wait() == _lib.ADSB_WAIT_BLOCK

@@ -77,9 +77,21 @@ def main():
                 if frames_ref is None:
                     frames_ref = frames
                 assert frames == frames_ref, (frames, frames_ref)
+                # one capture at a time: submit -> the caller has its messages (what a blocking caller waits for)
+                for _ in range(3):
+                    multi.icao_flush()
+                    multi.submit_raw(ptrs, ns)
+                    multi.collect_raw(out, cap)
+                torch.cuda.synchronize()
+                b0 = time.perf_counter()
+                for _ in range(20):
+                    multi.icao_flush()
+                    multi.submit_raw(ptrs, ns)
+                    multi.collect_raw(out, cap)
+                one_at_a_time = (time.perf_counter() - b0) / 20
                 print(f"{sky:9s} {name:5s} (in effect: {got:5s})  {1e3 * (t1 - t0) / args.steps:8.4f} ms per capture   "
                       f"{1e3 * (c1 - c0) / args.steps:8.3f} CPU-ms per capture   {(c1 - c0) / (t1 - t0):5.2f} CPUs busy   "
-                      f"{frames // args.steps} frames per capture", flush=True)
+                      f"{frames // args.steps} frames per capture   one at a time {1e3 * one_at_a_time:7.4f} ms", flush=True)
         del parts, whole
         torch.cuda.empty_cache()
 
