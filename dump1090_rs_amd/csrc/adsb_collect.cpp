@@ -336,7 +336,7 @@ int deliver(adsb_ctx *c, std::vector<adsb_msg> &msgs, adsb_msg *out, size_t cap,
 extern "C" {
 
 int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
-{
+try {
     if (!c || (!out && cap)) return ADSB_ERR_INVALID;
     if (c->submitted == c->delivered) return ADSB_ERR_INVALID;
     ADSB_ON_DEVICE(c);
@@ -344,17 +344,17 @@ int adsb_collect(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
     int rc = collect_next(c, msgs);
     if (rc) return rc;
     return deliver(c, msgs, out, cap, n_out);
-}
+} ADSB_ABI_CATCH
 
 int adsb_pending(const adsb_ctx *c) { return c ? (int)(c->submitted - c->delivered) : 0; }
 
 int adsb_fetch_messages(adsb_ctx *c, adsb_msg *out, size_t cap, size_t *n_out)
-{
+try {
     if (!c || (!out && cap) || !c->has_undelivered) return ADSB_ERR_INVALID;
     const size_t n = std::min(cap, c->undelivered.size());
     if (n) std::memcpy(out, c->undelivered.data(), n * sizeof(adsb_msg));
     if (n_out) *n_out = c->undelivered.size();
     return c->undelivered.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 }  // extern "C"

@@ -114,7 +114,7 @@ int device_streams(adsb_ctx *c, int device, bool small, DeviceStreams **out)
 }
 
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
-{
+try {
     if (!out) return ADSB_ERR_INVALID;
     *out = nullptr;
     if (device < 0) return ADSB_ERR_NO_DEVICE;  // no CPU backend by design
@@ -323,7 +323,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     }
     *out = c;
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 void adsb_destroy(adsb_ctx *c)
 {
@@ -515,26 +515,26 @@ void adsb_destroy(adsb_ctx *c)
 }
 
 int adsb_set_stream(adsb_ctx *c, void *hip_stream)
-{
+try {
     if (!c) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_set_profiling(adsb_ctx *c, int enabled)
-{
+try {
     if (!c) return ADSB_ERR_INVALID;
     // (the level decides whether a pass of a few buffers is one launch or three, and the cross-stream edges of a
     // pass are worked out from what the passes in flight are: like the other settings, only between passes)
     if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_set_carry_over(adsb_ctx *c, int enabled)
-{
+try {
     if (!c) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered || c->shard_active) return ADSB_ERR_BUSY;
     ADSB_ON_DEVICE(c);
@@ -545,7 +545,7 @@ int adsb_set_carry_over(adsb_ctx *c, int enabled)
     HIP_TRY(c, hipMemsetAsync(c->d_carry_next, 0, kCarrySamples * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_icao_flush(adsb_ctx *c)
 {

@@ -551,7 +551,7 @@ int ensure_stage(adsb_ctx *c, size_t bytes)
 extern "C" {
 
 int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, size_t *length_out)
-{
+try {
     if (!c || (!iq && n) || !data_out) return ADSB_ERR_INVALID;
     if (n > kChunkSamples) return ADSB_ERR_TOO_LONG;  // reference: index panic, lib.rs:48
     ADSB_ON_DEVICE(c);
@@ -571,11 +571,11 @@ int adsb_to_mag(adsb_ctx *c, const int16_t *iq, size_t n, uint16_t *data_out, si
     std::memcpy(data_out, h_mag, out_bytes);
     if (length_out) *length_out = n;
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_msg *out, size_t cap,
                         size_t *n_out)
-{
+try {
     if (!c || !data || (!out && cap)) return ADSB_ERR_INVALID;
     if (length > kChunkSamples) return ADSB_ERR_TOO_LONG;
     ADSB_ON_DEVICE(c);
@@ -593,11 +593,11 @@ int adsb_demodulate2400(adsb_ctx *c, const uint16_t *data, size_t length, adsb_m
         if (rc) return rc;
     }
     return deliver(c, msgs, out, cap, n_out);
-}
+} ADSB_ABI_CATCH
 
 int adsb_demod_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples, adsb_msg *out, size_t cap,
                          size_t *n_out)
-{
+try {
     if (!c || (!d_iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
     if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
     ADSB_ON_DEVICE(c);
@@ -605,21 +605,21 @@ int adsb_demod_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples, adsb_m
     int rc = demod_device(c, d_iq, n_samples, msgs);
     if (rc) return rc;
     return deliver(c, msgs, out, cap, n_out);
-}
+} ADSB_ABI_CATCH
 
 int adsb_submit_iq_device(adsb_ctx *c, const void *d_iq, size_t n_samples)
-{
+try {
     if (!c || !d_iq || n_samples == 0) return ADSB_ERR_INVALID;
     if (((uintptr_t)d_iq & 15u) != 0) return ADSB_ERR_INVALID;
     if ((n_samples + kChunkSamples - 1) / kChunkSamples > std::min<uint64_t>(kMaxChunks, c->max_chunks))
         return ADSB_ERR_INVALID;  // more buffers than the context was created for
     ADSB_ON_DEVICE(c);
     return submit(c, d_iq, false, n_samples);
-}
+} ADSB_ABI_CATCH
 
 int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *out, size_t cap,
                   size_t *n_out)
-{
+try {
     if (!c || (!iq && n_samples) || (!out && cap)) return ADSB_ERR_INVALID;
     ADSB_ON_DEVICE(c);
     // stage through the device in pieces of at most max_chunks chunks
@@ -722,6 +722,6 @@ int adsb_demod_iq(adsb_ctx *c, const int16_t *iq, size_t n_samples, adsb_msg *ou
     total.n_samples = n_samples;
     c->stats = total;
     return deliver(c, msgs, out, cap, n_out);
-}
+} ADSB_ABI_CATCH
 
 }  // extern "C"

@@ -467,7 +467,7 @@ static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "adsb_trial mirrors Tri
 
 int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, adsb_msg *out,
                         size_t cap, size_t *n_out)
-{
+try {
     if (!filter_table || (!records && n) || (!out && cap)) return ADSB_ERR_INVALID;
     static const Crc24 crc;
     IcaoFilter filter;
@@ -479,10 +479,10 @@ int adsb_replay_records(uint32_t *filter_table, adsb_trial *records, size_t n, a
     if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
     if (n_out) *n_out = msgs.size();
     return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_read_test_data(const char *path, int16_t *iq, size_t max_samples, size_t *n_out)
-{
+try {
     if (!path || !iq) return ADSB_ERR_INVALID;
     FILE *fp = std::fopen(path, "rb");
     if (!fp) return ADSB_ERR_INVALID;
@@ -497,7 +497,7 @@ int adsb_read_test_data(const char *path, int16_t *iq, size_t max_samples, size_
     std::fclose(fp);
     if (n_out) *n_out = k;
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
 {
@@ -520,7 +520,7 @@ int adsb_format_raw(const adsb_msg *m, char *out, size_t out_size)
 
 int adsb_selftest_learned_union(const adsb_trial *records, size_t n, const uint32_t *known, size_t n_known, uint32_t *out,
                                  size_t cap, size_t *n_out)
-{
+try {
     if ((!records && n) || (!known && n_known) || (!out && cap)) return ADSB_ERR_INVALID;
     static const Crc24 crc;
     std::vector<uint32_t> learned, kn(known, known + n_known), fresh;
@@ -534,11 +534,11 @@ int adsb_selftest_learned_union(const adsb_trial *records, size_t n, const uint3
     const size_t k = std::min(cap, fresh.size());
     if (k) std::memcpy(out, fresh.data(), k * sizeof(uint32_t));
     return fresh.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *records, size_t n, int runs, int parts, int threads,
                                   adsb_msg *out, size_t cap, size_t *n_out, int *went_parallel)
-{
+try {
     if (!filter_table || (!records && n) || (!out && cap) || runs < 1 || parts < 1 || threads < 1) return ADSB_ERR_INVALID;
     static const Crc24 crc;
     IcaoFilter filter;
@@ -604,7 +604,7 @@ int adsb_selftest_parallel_replay(uint32_t *filter_table, const adsb_trial *reco
     if (k) std::memcpy(out, msgs.data(), k * sizeof(adsb_msg));
     if (n_out) *n_out = msgs.size();
     return msgs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_selftest_crc_table(uint32_t *out256)
 {

@@ -9,12 +9,19 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
 #include "../../include/adsb_hip.h"
 #include "adsb_record.h"
 #include "mode_s_host.hpp"
+
+// The tail of every extern "C" function whose body can allocate (`int f(...) try { ... } ADSB_ABI_CATCH`): nothing is
+// thrown across the ABI (include/adsb_hip.h) -- a Rust host would abort on an unwinding foreign frame.
+#define ADSB_ABI_CATCH                                        \
+    catch (const std::bad_alloc &) { return ADSB_ERR_NOMEM; } \
+    catch (...) { return ADSB_ERR_HIP; }
 
 namespace adsb {
 namespace host {

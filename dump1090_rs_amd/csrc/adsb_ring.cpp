@@ -11,7 +11,7 @@ constexpr uint32_t kRingInPlaceChunks = 2;
 extern "C" {
 
 int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
-{
+try {
     if (!c || samples_per_slot == 0 || c->ring_samples) return ADSB_ERR_INVALID;
     if ((samples_per_slot + kChunkSamples - 1) / kChunkSamples > c->max_chunks) return ADSB_ERR_INVALID;
     ADSB_ON_DEVICE(c);
@@ -51,19 +51,19 @@ int adsb_ring_create(adsb_ctx *c, size_t samples_per_slot)
     }
     c->ring_samples = samples_per_slot;
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_ring_acquire(adsb_ctx *c, int16_t **host_iq, size_t *capacity_samples)
-{
+try {
     if (!c || !host_iq || !c->ring_samples) return ADSB_ERR_INVALID;
     if (c->slot[c->submitted % (uint64_t)c->n_slots].busy || c->slot[c->submitted % (uint64_t)c->n_slots].parked) return ADSB_ERR_BUSY;  // collect the oldest pass first
     *host_iq = c->ring[c->submitted % (uint64_t)c->n_slots].h_iq;
     if (capacity_samples) *capacity_samples = c->ring_samples;
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
-{
+try {
     if (!c || !c->ring_samples || n_samples == 0 || n_samples > c->ring_samples) return ADSB_ERR_INVALID;
     if (c->slot[c->submitted % (uint64_t)c->n_slots].busy || c->slot[c->submitted % (uint64_t)c->n_slots].parked) return ADSB_ERR_BUSY;
     ADSB_ON_DEVICE(c);
@@ -104,10 +104,10 @@ int adsb_ring_submit(adsb_ctx *c, size_t n_samples)
     const int rc = submit(c, r.d_iq, false, n_samples, false, input_ready_now());
     c->input_on_stream = nullptr;
     return rc;
-}
+} ADSB_ABI_CATCH
 
 int adsb_host_register(adsb_ctx *c, void *host_ptr, size_t bytes)
-{
+try {
     if (!c || !host_ptr || bytes == 0) return ADSB_ERR_INVALID;
     char *b = static_cast<char *>(host_ptr);
     for (const auto &r : c->host_ranges)
@@ -125,10 +125,10 @@ int adsb_host_register(adsb_ctx *c, void *host_ptr, size_t bytes)
     r.dev = static_cast<char *>(dev);
     c->host_ranges.push_back(r);
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_host_unregister(adsb_ctx *c, void *host_ptr)
-{
+try {
     if (!c || !host_ptr) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     for (size_t k = 0; k < c->host_ranges.size(); k++)
@@ -139,6 +139,6 @@ int adsb_host_unregister(adsb_ctx *c, void *host_ptr)
             return ADSB_OK;
         }
     return ADSB_ERR_INVALID;
-}
+} ADSB_ABI_CATCH
 
 }  // extern "C"

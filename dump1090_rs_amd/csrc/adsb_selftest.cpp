@@ -130,7 +130,7 @@ extern "C" {
 
 int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, uint64_t *sum_out,
                              uint64_t *xor_out)
-{
+try {
     if (!c || !sum_out || !xor_out) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered) return ADSB_ERR_BUSY;
     ADSB_ON_DEVICE(c);
@@ -149,25 +149,25 @@ int adsb_selftest_mag_digest(adsb_ctx *c, uint32_t first_bits, uint32_t count, u
     *sum_out = res[0];
     *xor_out = res[1];
     return ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_selftest_stage_lists(adsb_ctx *c, const void *d_iq, size_t n_samples, uint64_t *cand, size_t cand_cap,
                               size_t *n_cand, uint64_t *ap, size_t ap_cap, size_t *n_ap)
-{
+try {
     if ((!cand && cand_cap) || (!ap && ap_cap)) return ADSB_ERR_INVALID;
     std::vector<uint64_t> cands, aps;
     if (int rc = selftest_pass(c, d_iq, n_samples, nullptr, nullptr, &cands, &aps)) return rc;
     return hand_out(cands, cand, cand_cap, n_cand, aps, ap, ap_cap, n_ap);
-}
+} ADSB_ABI_CATCH
 
 int adsb_selftest_gate_stages(adsb_ctx *c, const void *d_iq, size_t n_samples, uint64_t *preamble, size_t preamble_cap,
                               size_t *n_preamble, uint64_t *snr, size_t snr_cap, size_t *n_snr)
-{
+try {
     if ((!preamble && preamble_cap) || (!snr && snr_cap)) return ADSB_ERR_INVALID;
     std::vector<uint64_t> pre, sn;
     if (int rc = selftest_pass(c, d_iq, n_samples, &pre, &sn, nullptr, nullptr)) return rc;
     return hand_out(pre, preamble, preamble_cap, n_preamble, sn, snr, snr_cap, n_snr);
-}
+} ADSB_ABI_CATCH
 
 int adsb_selftest_set_order_polls(adsb_ctx *c, uint32_t polls)
 {

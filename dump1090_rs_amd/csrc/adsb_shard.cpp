@@ -619,7 +619,7 @@ extern "C" {
 
 int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32_t *addrs_out, size_t cap,
                     size_t *n_addrs)
-{
+try {
     if (!c || (!device_iq && n_samples) || (!addrs_out && cap)) return ADSB_ERR_INVALID;
     if (c->submitted != c->delivered || c->shard_active || c->shard[0].active) return ADSB_ERR_BUSY;
     if (n_addrs) *n_addrs = 0;
@@ -639,11 +639,11 @@ int adsb_shard_scan(adsb_ctx *c, const void *device_iq, size_t n_samples, uint32
     const size_t k = std::min(cap, addrs.size());
     if (k) std::memcpy(addrs_out, addrs.data(), k * sizeof(uint32_t));
     return addrs.size() > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, adsb_trial *records_out,
                       size_t cap, size_t *n_records)
-{
+try {
     if (!c || (!extra_addrs && n_extra) || (!records_out && cap)) return ADSB_ERR_INVALID;
     if (!c->shard_active) return ADSB_ERR_INVALID;
     if (n_records) *n_records = 0;
@@ -663,6 +663,6 @@ int adsb_shard_finish(adsb_ctx *c, const uint32_t *extra_addrs, size_t n_extra, 
     static_assert(sizeof(adsb_trial) == sizeof(TrialRecord), "record layout is the ABI's");
     if (k) std::memcpy(records_out, rec, k * sizeof(adsb_trial));
     return n > cap ? ADSB_ERR_CAPACITY : ADSB_OK;
-}
+} ADSB_ABI_CATCH
 
 }  // extern "C"

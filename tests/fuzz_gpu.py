@@ -241,7 +241,7 @@ def mixed_pipeline_case(rng, synth, Context, Oracle, torch, modes, case, seed):
     ctx.close()
 
 
-def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
+def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed, faults=True):
     """adsb_multi_*: a sequence of captures of random length over a random number of contexts on the one GPU (the
     devices wherever there are several), random icao_flush, the host form and resident shards, blocking and up to four
     captures in flight -- every capture against ONE oracle stream fed the same sequence."""
@@ -290,6 +290,11 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
     # ... and who scores a dense stream's shards: their devices (half), the host, or the devices with the result refused
     multi.selftest_tune(fresh_cap=2 if rng.random() < 0.25 else 0, parallel_min=1 if rng.random() < 0.5 else 0,
                         score_mode=int(rng.choice([0, 0, 1, 2])))
+    from dump1090_rs_amd import _lib
+    from dump1090_rs_amd._lib import AdsbError
+    # (round 6's draws come from a stream of their own: the sequences older seeds stand for -- 27182 / 45 is a test -- stay what they were)
+    frng = np.random.default_rng([int(seed) & 0x7FFFFFFF, int(case), 606])
+    multi.set_wait(int(frng.choice([_lib.ADSB_WAIT_AUTO, _lib.ADSB_WAIT_SPIN, _lib.ADSB_WAIT_BLOCK])))
     orc = Oracle()
     steps = int(rng.integers(4, 12))
     plan = []
@@ -300,9 +305,13 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
         form = "host" if (not fits or rng.random() < 0.3) else ("device" if rng.random() < 0.3 else "submit")
         if form == "submit" and len(caps[c]) and rng.random() < 0.4:   # the asynchronous HOST form, pinned or ordinary memory
             form = "submit_pinned" if rng.random() < 0.5 else "submit_host"
-        if flush:
-            orc.icao_flush()
-        plan.append((flush, c, form, [okey(w) for w in orc.demod_iq(caps[c], cap=1 << 18)[0]]))
+        plan.append((flush, c, form))
+    # a third of the sequences: one shard of one capture fails (include/adsb_hip.h, "When a capture fails") -- that capture
+    # returns the error, what is in flight behind it and what is submitted later ADSB_ERR_POISONED, the restart (icao_flush
+    # with nothing in flight) starts a fresh oracle stream
+    fault_step = int(frng.integers(0, steps)) if frng.random() < 0.33 and faults else -1
+    fault_kind = int(frng.choice([_lib.ADSB_FAULT_PHASE1, _lib.ADSB_FAULT_PHASE2, _lib.ADSB_FAULT_RECORDS]))
+    fault_shard = int(frng.integers(0, k))
     resident = {}
     for c, iq in enumerate(caps):
         if len(iq) > k * per * CHUNK:
@@ -316,51 +325,102 @@ def multi_case(rng, synth, MultiContext, Oracle, torch, modes, case, seed):
         resident[c] = (ts, ptrs, ns)
     for d in set(devices):
         torch.cuda.synchronize(d)
-    pending = []
+    pending = []   # per capture in flight: ("ok", the oracle's list) | ("fail",) | ("poisoned",)
+    state = {"broken": False, "fail_collected": False, "faults": 0, "restarts": 0, "poisoned_returns": 0}
+
+    def fail(what):
+        print(f"MISMATCH multi case {case} (fuzz seed {seed}) at {what}: devices {devices}, {per} buffers each, "
+              f"captures {[len(x) for x in caps]}, fault at step {fault_step} kind {fault_kind} shard {fault_shard}")
+        sys.exit(1)
 
     def check(got, want, what):
         if [key(m) for m in got] != want:
-            print(f"MISMATCH multi case {case} (fuzz seed {seed}) at {what}: devices {devices}, {per} buffers each, "
-                  f"captures {[len(x) for x in caps]}, {len(got)} frames, {len(want)} expected")
+            print(f"{len(got)} frames, {len(want)} expected")
             for x, y in zip(want, [key(m) for m in got]):
                 if x != y:
                     print(" first difference:", x, y)
                     break
-            sys.exit(1)
+            fail(what)
+
+    def expect_error(call, poisoned, what):
+        try:
+            call()
+        except AdsbError as e:
+            if (e.status == _lib.ADSB_ERR_POISONED) != poisoned or e.status == 0:
+                fail(f"{what}: status {e.status}, poisoned expected: {poisoned}")
+            return
+        fail(f"{what}: no error")
+
+    def collect_one(what):
+        entry = pending.pop(0)
+        if entry[0] == "ok":
+            check(multi.collect(cap=1 << 18), entry[1], what)
+        elif entry[0] == "fail":
+            expect_error(lambda: multi.collect(cap=1 << 18), False, what + " (the failing capture)")
+            state["fail_collected"] = True
+        else:
+            expect_error(lambda: multi.collect(cap=1 << 18), True, what + " (behind the failing capture)")
+            state["poisoned_returns"] += 1
 
     depth = int(rng.integers(1, 5))
     pinned = {}
-    for step, (flush, c, form, want) in enumerate(plan):
-        if not form.startswith("submit") or len(pending) == depth:
-            while pending and (not form.startswith("submit") or len(pending) == depth):   # the blocking forms want nothing in flight
-                check(multi.collect(cap=1 << 18), pending.pop(0), f"step {step} (collect)")
-        if flush:
+    for step, (flush, c, form) in enumerate(plan):
+        blocking = not form.startswith("submit")
+        while pending and (blocking or len(pending) == depth):   # the blocking forms want nothing in flight
+            collect_one(f"step {step} (collect)")
+        if state["broken"] and not pending:
+            multi.icao_flush()                                   # the restart
+            orc.icao_flush()
+            state["broken"] = state["fail_collected"] = False
+            state["restarts"] += 1
+        elif flush and not state["broken"]:
             multi.icao_flush()
+            orc.icao_flush()
+        # (a host capture longer than the contexts hold is cut into pieces = several captures: the fault is aimed at one)
+        inject = step == fault_step and not state["broken"] and len(caps[c]) <= k * per * CHUNK
+        if inject:
+            multi.selftest_fail(0, fault_shard, fault_kind)
+            state["faults"] += 1
+        expect = "poisoned" if state["broken"] else ("fail" if inject else "ok")
+        want = [okey(w) for w in orc.demod_iq(caps[c], cap=1 << 18)[0]] if expect == "ok" else None
         if form == "host":
-            check(multi.demod_iq(caps[c], cap=1 << 18), want, f"step {step} (host)")
+            call = lambda: multi.demod_iq(caps[c], cap=1 << 18)
         elif form == "device":
-            check(multi.demod_iq_device(resident[c][1], resident[c][2], cap=1 << 18), want, f"step {step} (device)")
+            call = lambda: multi.demod_iq_device(resident[c][1], resident[c][2], cap=1 << 18)
         elif form == "submit_host":
-            multi.submit_iq(caps[c])
-            pending.append(want)
+            call = lambda: multi.submit_iq(caps[c])
         elif form == "submit_pinned":
             if c not in pinned:
                 pinned[c] = multi.host_alloc(len(caps[c]))
                 pinned[c][:] = caps[c]
-            multi.submit_iq(pinned[c])
-            pending.append(want)
+            call = lambda: multi.submit_iq(pinned[c])
         else:
-            multi.submit_iq_device(resident[c][1], resident[c][2])
-            pending.append(want)
+            call = lambda: multi.submit_iq_device(resident[c][1], resident[c][2])
+        if blocking:   # (nothing in flight, and a broken handle was restarted above: "ok" or "fail")
+            if expect == "ok":
+                check(call(), want, f"step {step} ({form})")
+            else:
+                expect_error(call, False, f"step {step} ({form}, the failing capture)")
+                state["broken"] = state["fail_collected"] = True
+        elif expect == "poisoned" and state["fail_collected"]:
+            expect_error(call, True, f"step {step} ({form}, a submission to a poisoned handle)")
+            state["poisoned_returns"] += 1
+        else:
+            call()
+            pending.append(("ok", want) if expect == "ok" else (expect,))
+            if expect == "fail":
+                state["broken"] = True
     while pending:
-        check(multi.collect(cap=1 << 18), pending.pop(0), "drain")
+        collect_one("drain")
+    for name in ("faults", "restarts", "poisoned_returns"):
+        modes[("multi:" + name, False)] = modes.get(("multi:" + name, False), 0) + state[name]
     modes[("multi", False)] = modes.get(("multi", False), 0) + 1
     modes[("multi:captures", False)] = modes.get(("multi:captures", False), 0) + steps
     ctr = multi.selftest_counters()
     for name in ("device_ordered_shards", "fresh_list_fallbacks", "device_scored_shards", "scored_results_used", "scored_results_refused"):
         modes[("multi:" + name, False)] = modes.get(("multi:" + name, False), 0) + int(ctr[name])
     modes[("multi:parallel_replays", False)] = modes.get(("multi:parallel_replays", False), 0) + int(multi.selftest_counters()["parallel_scored_captures"])
-    modes[("multi:host_submits", False)] = modes.get(("multi:host_submits", False), 0) + sum(f in ("submit_host", "submit_pinned") for _, _, f, _ in plan)
+    modes[("multi:host_submits", False)] = modes.get(("multi:host_submits", False), 0) + sum(f in ("submit_host", "submit_pinned") for _, _, f in plan)
     multi.close()
 
 
@@ -381,6 +441,8 @@ def main():
     ap.add_argument("--multi", type=int, default=8,
                     help="also run this many adsb_multi_* sequences: captures over 1-8 contexts, flushes, host / resident, "
                          "blocking and pipelined, against one oracle stream")
+    ap.add_argument("--no-multi-faults", action="store_true",
+                    help="--multi sequences without injected shard failures (a third of them have one by default)")
     args = ap.parse_args()
     import torch
     from dump1090_rs_amd import Context, sharding, synth
@@ -513,7 +575,7 @@ def main():
         for k in range(args.mixed):
             mixed_pipeline_case(np.random.default_rng([args.seed, 1000003, k]), synth, Context, binding.Oracle, torch, modes, k, args.seed)
         for k in range(args.multi):
-            multi_case(np.random.default_rng([args.seed, 2000003, k]), synth, MultiContext, binding.Oracle, torch, modes, k, args.seed)
+            multi_case(np.random.default_rng([args.seed, 2000003, k]), synth, MultiContext, binding.Oracle, torch, modes, k, args.seed, faults=not args.no_multi_faults)
     print(f"{args.cases} cases identical in {time.time() - t0:.1f} s; modes: "
           + ", ".join(f"{k[0]}{'+carry' if k[1] else ''}={v}" for k, v in sorted(modes.items())))
 

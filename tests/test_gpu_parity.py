@@ -1393,7 +1393,8 @@ def test_soak_seed_that_found_the_overlapping_scans_hole(hip_lib, oracle_mod):
     import subprocess
     import sys
     from tests.conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "4", "--seed", "27182", "--dense", "0", "--mixed", "0", "--multi", "60"],
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_gpu.py"), "--cases", "4", "--seed", "27182", "--dense", "0", "--mixed", "0", "--multi", "60",
+                        "--no-multi-faults"],
                        capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "4 cases identical" in r.stdout and "multi=60" in r.stdout and "multi:device_ordered_shards=" in r.stdout
