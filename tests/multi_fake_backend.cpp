@@ -10,8 +10,10 @@
 //     with the ORACLE (orc_to_mag + orc_all_trials: every trial of every position the gates let through), keeps an address
 //     superset per flush epoch exactly as the real context does (own learned addresses at phase 1, the exchange's at
 //     phase 2), hands back the self-validating trials plus the address/parity trials whose value the superset holds --
-//     so an address the exchange fails to deliver costs a record and shows up as a wrong frame list -- and whose phases
-//     "land" from ANOTHER thread after random delays (0 us ... 6 ms), like a kernel's write to mapped memory;
+//     so an address the exchange fails to deliver costs a record and shows up as a wrong frame list --, that scores about
+//     half of its shards itself as k_score / k_emit do (the oracle's score_modes_message against "exact bitmap" + what the
+//     shards before it add), and whose phases "land" from ANOTHER thread after random delays (0 us ... 6 ms), like a
+//     kernel's write to mapped memory;
 //
 // and main() drives random sequences of captures (1-8 devices, 1-4 captures in flight, flushes, the host and the device
 // forms, spin and block waits, injected failures of every kind with the recovery that follows) and compares every
@@ -155,6 +157,10 @@ typedef std::set<uint32_t> AddrSet;
 
 struct FakeShard {
     std::shared_ptr<AddrSet> bitmap;      // the superset this shard matches against (its flush epoch's)
+    bool exact_flush = false;             // an icao_flush precedes the shard: its scoring starts from an empty "exact bitmap"
+    bool scored = false;                  // the "device" scored the shard itself (a dense stream's: csrc/adsb_shard.cpp)
+    std::vector<adsb_msg> scored_msgs;    // ... its messages (chunk = buffer within the shard) and the values its replay adds
+    std::vector<uint32_t> scored_adds;
     std::vector<TrialRecord> all;         // every trial of the shard, chunk = buffer within the shard
     std::vector<TrialRecord> out;         // what the second phase hands over
     std::vector<uint32_t> learned;
@@ -165,6 +171,7 @@ struct FakeShard {
 
 struct FakeCtx {
     std::shared_ptr<AddrSet> cur;
+    AddrSet exact;                        // the filter as the device believes it stood before the capture (the exact bitmap)
     FakeShard shard[kSlots];
     std::mt19937_64 rng;
     uint32_t next_seq = 1;
@@ -239,11 +246,13 @@ int shard_begin(adsb_ctx *c, int k, const void *d_iq, uint64_t n_samples, bool)
     adsb_ctx::ShardJob &job = c->shard[k];
     if (job.active) return ADSB_ERR_BUSY;
     if (fake_fails(c, 0)) return ADSB_ERR_HIP;
+    sh.exact_flush = c->flush_pending;
     if (c->flush_pending) {
         f->cur = std::make_shared<AddrSet>();
         f->cur->insert(0);   // (address 0 always tests true: src/icao_filter.rs:71-80)
         c->flush_pending = false;
     }
+    sh.scored = false;
     sh.bitmap = f->cur;
     sh.n_samples = n_samples;
     sh.all.clear();
@@ -301,7 +310,54 @@ int shard_learned(adsb_ctx *c, int k, std::vector<uint32_t> &addrs)
     return ADSB_OK;
 }
 
-int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra, const uint32_t *, size_t)
+// A shard scored where it is, as k_score / k_emit do it -- here by the ORACLE: the shard's records in replay order through
+// score_modes_message (src/mode_s/mod.rs:34-139) and the best-of-5 selection (src/demod_2400.rs:184-207) against a filter
+// that holds what the exact bitmap holds plus what the shards before this one add.
+void score_shard(FakeCtx *f, FakeShard &sh, const uint32_t *earlier, size_t n_earlier)
+{
+    auto filt = std::make_unique<orc_filter>();
+    orc_icao_flush(filt.get());
+    for (uint32_t a : f->exact) orc_icao_filter_add(filt.get(), a);
+    for (size_t i = 0; i < n_earlier; i++) orc_icao_filter_add(filt.get(), earlier[i]);
+    std::vector<const TrialRecord *> order;
+    for (const TrialRecord &r : sh.out) order.push_back(&r);
+    std::sort(order.begin(), order.end(), [](const TrialRecord *a, const TrialRecord *b) {
+        if (a->chunk != b->chunk) return a->chunk < b->chunk;
+        if ((a->j_tp & 0xFFFFFFu) != (b->j_tp & 0xFFFFFFu)) return (a->j_tp & 0xFFFFFFu) < (b->j_tp & 0xFFFFFFu);
+        return (a->j_tp >> 24) < (b->j_tp >> 24);
+    });
+    sh.scored_msgs.clear();
+    sh.scored_adds.clear();
+    for (size_t i = 0; i < order.size();) {
+        const uint32_t chunk = order[i]->chunk, j = order[i]->j_tp & 0xFFFFFFu;
+        const TrialRecord *best = nullptr;
+        int32_t best_score = -2;
+        int best_len = 7;
+        for (; i < order.size() && order[i]->chunk == chunk && (order[i]->j_tp & 0xFFFFFFu) == j; i++) {
+            const TrialRecord &r = *order[i];
+            const unsigned df = r.msg[0] >> 3;
+            const bool adder = ((df == 17 || df == 18) && orc_modes_checksum(r.msg, 112) == 0) || (df == 11 && orc_modes_checksum(r.msg, 56) == 0);
+            if (adder && !orc_icao_filter_test(filt.get(), addr_of(r.msg)))   // (what score_modes_message is about to hand icao_filter_add)
+                sh.scored_adds.push_back(df == 18 ? (addr_of(r.msg) | ORC_ICAO_FILTER_ADSB_NT) : addr_of(r.msg));
+            int len = 0;
+            int32_t score = 0;
+            if (!orc_score_modes_message(filt.get(), r.msg, 14, &len, &score)) continue;
+            if (score > best_score) best = &r, best_score = score, best_len = len;
+        }
+        if (!best || best_score < 0) continue;
+        adsb_msg m{};
+        std::memcpy(m.msg, best->msg, 14);
+        m.len = (uint8_t)best_len;
+        m.try_phase = (uint8_t)(best->j_tp >> 24);
+        m.score = best_score;
+        m.j = j;
+        m.chunk = chunk;
+        m.signal_level = (double)(best->power & ((1ull << 40) - 1)) / 65535.0 / 65535.0 / 33.0;
+        sh.scored_msgs.push_back(m);
+    }
+}
+
+int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra, const uint32_t *earlier, size_t n_earlier)
 {
     FakeCtx *f = fake_of(c);
     FakeShard &sh = f->shard[k];
@@ -323,6 +379,14 @@ int shard_match(adsb_ctx *c, int k, const uint32_t *extra, size_t n_extra, const
     }
     // (now and then out of replay order, as records of a sparse shard come: the device thread sorts them)
     if (sh.out.size() > 2 && f->rng() % 3 == 0) std::swap(sh.out[0], sh.out[sh.out.size() - 1]);
+    // the exact bitmap's life (csrc/adsb_shard.cpp: exact_side): cleared in front of a flushed capture's scoring, this
+    // shard scored against it, then the capture's additions -- every shard's, the exchange has them -- committed to it
+    if (sh.exact_flush) f->exact.clear();
+    if (c->shard_scoring && sh.n_samples && f->rng() % 2 == 0) {
+        score_shard(f, sh, earlier, n_earlier);
+        sh.scored = true;
+    }
+    for (size_t i = 0; i < n_extra; i++) f->exact.insert(extra[i]);
     if (sh.n_samples) {
         job.waiting = true;
         schedule_landing(f, sh);
@@ -344,12 +408,22 @@ int shard_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
     st.n_chunks = (sh.n_samples + kChunkSamples - 1) / kChunkSamples;
     st.n_records = sh.out.size();
     c->stats = st;
-    *rec = sh.out.data();
-    *n_out = sh.out.size();
+    job.result_scored = sh.scored;   // (a scored shard's records stay on the "device": shard_fetch_records brings them over)
+    *rec = sh.scored ? nullptr : sh.out.data();
+    *n_out = sh.scored ? 0 : sh.out.size();
     return ADSB_OK;
 }
 
-bool shard_scored_result(adsb_ctx *, int, adsb_msg **, size_t *, const uint32_t **, size_t *) { return false; }
+bool shard_scored_result(adsb_ctx *c, int k, adsb_msg **msgs, size_t *n_msgs, const uint32_t **adds, size_t *n_adds)
+{
+    FakeShard &sh = fake_of(c)->shard[k];
+    if (!c->shard[k].result_scored) return false;
+    *msgs = sh.scored_msgs.data();
+    *n_msgs = sh.scored_msgs.size();
+    *adds = sh.scored_adds.data();
+    *n_adds = sh.scored_adds.size();
+    return true;
+}
 
 int shard_fetch_records(adsb_ctx *c, int k, const TrialRecord **rec, size_t *n_out)
 {
@@ -365,6 +439,7 @@ int shard_reset(adsb_ctx *c)
     FakeCtx *f = fake_of(c);
     f->cur = std::make_shared<AddrSet>();
     f->cur->insert(0);
+    f->exact.clear();
     for (int k = 0; k < kSlots; k++) {
         c->shard[k].active = c->shard[k].waiting = false;
         f->shard[k].bitmap.reset();
@@ -425,6 +500,7 @@ int main(int argc, char **argv)
     std::vector<orc_msg> scratch(cap);
     auto filt = std::make_unique<orc_filter>();
     size_t total_captures = 0, total_msgs = 0, failures_injected = 0, recoveries = 0, dead_handles = 0, blocked = 0, parallel = 0, poisoned_returns = 0;
+    size_t scored_used = 0, scored_refused = 0;
 
     for (int seq_no = 0; seq_no < sequences; seq_no++) {
         const int n_dev = 1 + (int)(rng() % 8);
@@ -437,7 +513,10 @@ int main(int argc, char **argv)
         if (adsb_multi_set_wait(m, wait_mode) != ADSB_OK) return 1;
         blocked += adsb_multi_get_wait(m) == ADSB_WAIT_BLOCK;
         // (half of the sequences: every capture's records scored by the pool's threads, whatever their number)
-        if (adsb_multi_selftest_tune(m, 0, rng() % 2 ? 1 : 0, 0) != ADSB_OK) return 1;
+        // ... and who scores a shard: its "device" for about half of them (score mode 0), never (1), or the device with the
+        // collector refusing every result and asking the shard's thread for the records instead (2)
+        static const uint32_t score_modes[] = {0, 0, 1, 2};
+        if (adsb_multi_selftest_tune(m, 0, rng() % 2 ? 1 : 0, score_modes[rng() % 4]) != ADSB_OK) return 1;
         const bool with_fault = rng() % 3 == 0;
         const bool hang = with_fault && rng() % 6 == 0;
         if (hang) (void)adsb_multi_set_timeout_ms(m, 500);   // (well above what a phase of the fake takes on a loaded box)
@@ -613,7 +692,7 @@ int main(int argc, char **argv)
         }
         while (!pending.empty() && !bad) collect_one(steps);
         uint64_t ctr[8] = {};
-        if (!dead && adsb_multi_selftest_counters(m, ctr) == ADSB_OK) parallel += ctr[3];
+        if (!dead && adsb_multi_selftest_counters(m, ctr) == ADSB_OK) parallel += ctr[3], scored_used += ctr[5], scored_refused += ctr[6];
         if (!dead)
             for (void *p : pinned)
                 if (adsb_multi_host_free(m, p) != ADSB_OK) bad = true;
@@ -626,7 +705,8 @@ int main(int argc, char **argv)
         }
     }
     std::printf("multi orchestration ok: %d sequences, %zu captures, %zu messages, %zu failures injected, %zu restarts, %zu dead handles, "
-                "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool\n",
-                sequences, total_captures, total_msgs, failures_injected, recoveries, dead_handles, poisoned_returns, blocked, parallel);
+                "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool, %zu shards scored by their device used, %zu refused\n",
+                sequences, total_captures, total_msgs, failures_injected, recoveries, dead_handles, poisoned_returns, blocked, parallel, scored_used,
+                scored_refused);
     return 0;
 }
