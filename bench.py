@@ -1323,7 +1323,9 @@ def one_process_n_devices_leg(env: Env, args):
             leg["devices_visible_to_rank0"] = n_vis
             leg["is"] = (f"rank 0 alone, the other {env.world - 1} rank(s) idle at a host-side barrier: adsb_multi over devices {devices}")
         except Exception as e:   # the headline line must still come out; the failure is in it
-            leg = {"error": f"{type(e).__name__}: {e}", "parity_checked": False}
+            # (parity_checked stays None: nothing was compared -- a mismatch says False and fails the run, a leg that could
+            # not run must not take the headline's exit status with it)
+            leg = {"error": f"{type(e).__name__}: {e}", "parity_checked": None}
     if group is not None:
         env.dist.barrier(group=group)
     return leg
@@ -1564,52 +1566,67 @@ def main():
         want_leg = lambda name: not only or name in only   # noqa: E731
         if env.dist is not None and not args.no_also and not args.sync and args.workload == "sparse":
             # the reference's shape -- one process, one filter -- over all N devices, by rank 0 (every rank takes part in the barrier)
-            leg = one_process_n_devices_leg(env, args)
+            one = one_process_n_devices_leg(env, args)
             if env.rank == 0:
-                result.setdefault("also", {})["config4_one_process_n_devices"] = leg
+                result.setdefault("also", {})["config4_one_process_n_devices"] = one
         if env.rank == 0 and env.dist is None and not args.no_also and not args.sync and args.workload == "sparse":
             also = result.setdefault("also", {})
+
+            def leg(key, fn):
+                """one short leg; if it cannot run (out of memory, a missing tool ...) the line still comes out, with the
+                reason in the leg's place and parity_checked None -- only a MISMATCH (False) fails the run"""
+                try:
+                    also[key] = fn()
+                except Exception as e:
+                    also[key] = {"error": f"{type(e).__name__}: {e}", "parity_checked": None}
+                    env.torch.cuda.empty_cache()
+
             if want_leg("config1"):
-                also["config1_cargo_bench_case"] = run_config1(env)
+                leg("config1_cargo_bench_case", lambda: run_config1(env))
             if want_leg("config3"):
-                also["config3_streaming_ring"] = config3_leg(env, args)
+                leg("config3_streaming_ring", lambda: config3_leg(env, args))
             if want_leg("live"):
-                also["live_receiver"] = live_leg(env, args)
+                leg("live_receiver", lambda: live_leg(env, args))
             # (a dense pass is a longer chain -- scan, match, order, records, score, emit, replay -- so the fill and the
             # drain of the pipeline between the two fences weigh ~0.3 ms: 14 us per step in a block of 20, 1.4 in one
             # of 200.  This leg reports the steady state, over at least 200 steps, and the short block beside it.)
-            if want_leg("config5"):
+            def dense_leg():
                 dargs = argparse.Namespace(**vars(args))
                 dargs.steps = max(args.steps, 200)
                 d = run_resident(env, dargs, "dense", dargs.steps, dargs.warmup, level2=False, short_block=args.steps)
-                dr = resident_result(env, dargs, d, "dense")
-                _, dsame, dframes = parity_leg(env, d, args.chunks, baseline=False) if not args.no_cpu_baseline else (None, None, None)
-                also["config5_dense"] = {
-                    "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
-                    "steps": dargs.steps, "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
-                    "ms_per_step_blocks": (dr["ms_per_step_blocks"] or {}).get("all"),
-                    "ms_per_step_in_a_block_of": {"steps": args.steps, "ms_per_step": round(d["short_block_ms"], 4),
-                                                  "is": "the same loop over only this many steps between the fences: the "
-                                                        "pipeline's fill and drain (one pass's whole chain, ~0.3 ms) included once"},
-                    "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
-                    "device_ms_per_launch": dr["roofline"]["sustained"]["device_ms_per_launch"],
-                    "n_records_last_step": dr["device_stats_last_step"]["n_records"],
-                    "parity_checked": dsame, "parity_frames": dframes}
-                d["ctx"].close()
-                del d
-                env.torch.cuda.empty_cache()
+                try:
+                    dr = resident_result(env, dargs, d, "dense")
+                    _, dsame, dframes = parity_leg(env, d, args.chunks, baseline=False) if not args.no_cpu_baseline else (None, None, None)
+                    return {
+                        "workload": dr["config"]["workload"], "value": dr["value"], "unit": "Msamples/s",
+                        "steps": dargs.steps, "ms_per_step": dr["ms_per_step"], "ms_per_step_median": dr["ms_per_step_median"],
+                        "ms_per_step_blocks": (dr["ms_per_step_blocks"] or {}).get("all"),
+                        "ms_per_step_in_a_block_of": {"steps": args.steps, "ms_per_step": round(d["short_block_ms"], 4),
+                                                      "is": "the same loop over only this many steps between the fences: the "
+                                                            "pipeline's fill and drain (one pass's whole chain, ~0.3 ms) included once"},
+                        "frames_per_step": dr["frames_per_step"], "kernel_avg_ms": dr["roofline"]["kernel_avg_ms"],
+                        "device_ms_per_launch": dr["roofline"]["sustained"]["device_ms_per_launch"],
+                        "n_records_last_step": dr["device_stats_last_step"]["n_records"],
+                        "parity_checked": dsame, "parity_frames": dframes}
+                finally:
+                    d["ctx"].close()
+                    del d
+                    env.torch.cuda.empty_cache()
+
+            if want_leg("config5"):
+                leg("config5_dense", dense_leg)
             if want_leg("config4"):
                 n_dev = env.torch.cuda.device_count()
                 sets = [[env.local_rank], [env.local_rank] * 8] + ([list(range(n_dev))] if n_dev > 1 else [])
-                also["config4_sharded_capture"] = config4_leg(env, args, sets, args.steps)
+                leg("config4_sharded_capture", lambda: config4_leg(env, args, sets, args.steps))
 
     if env.rank == 0:
         print(json.dumps(result), flush=True)
     env.finish()
     if env.rank == 0:
         bad = result.get("parity_checked") is False or result.get("shard_merge_equals_single_stream") is False
-        for leg in (result.get("also") or {}).values():
-            bad = bad or leg.get("parity_checked") is False or (leg.get("compiled_host") or {}).get("parity_checked") is False
+        for entry in (result.get("also") or {}).values():
+            bad = bad or entry.get("parity_checked") is False or (entry.get("compiled_host") or {}).get("parity_checked") is False
         if bad:
             sys.exit(3)
 

@@ -305,7 +305,9 @@ int adsb_shard_finish(adsb_ctx *ctx, const uint32_t *extra_addrs, size_t n_extra
  *                            device) the copies are DMAs, one per device over its own link, and overlap the
  *                            scans of the captures in flight; out of ordinary memory they go through the
  *                            runtime's staging buffers (a third of the rate).  The samples stay the caller's
- *                            and must not change before the capture is collected.
+ *                            and must not change before the capture is collected.  (Device side: a staging buffer of
+ *                            max_chunks_per_device buffers per capture in flight and device, allocated the first
+ *                            time the host form uses that slot and kept: up to 4 x 256 MiB per device at 512.)
  * adsb_msg.chunk is the buffer's index in the whole capture.  Errors and ADSB_ERR_CAPACITY behave as for
  * the one-device calls (adsb_multi_fetch_messages hands out the whole list of a capture whose `out` was too
  * small).  One adsb_multi is driven by one host thread at a time.  Like every entry point of this header, these leave

@@ -126,6 +126,30 @@ static int run_multi(int n_dev, int argc, char **argv)
             if (rc == 0 && adsb_multi_host_free(m, pinned) != ADSB_OK) rc = 1;
             if (rc == 0) printf("multi: three pinned host captures in flight, each equal to the blocking call\n");
         }
+        /* "When a capture fails" (include/adsb_hip.h) as a compiled host meets it: the last shard of the second of three
+         * captures in flight fails -> the first is fine, the second returns the shard's error, the third and a further
+         * submission ADSB_ERR_POISONED, the restart with nothing in flight succeeds and the stream gives the blocking
+         * call's list again; all under the blocking wait policy */
+        if (rc == 0 && again) {
+            size_t n2 = 0;
+            if (adsb_multi_set_wait(m, ADSB_WAIT_BLOCK) != ADSB_OK || adsb_multi_get_wait(m) != ADSB_WAIT_BLOCK) rc = 1;
+            if (adsb_multi_selftest_fail(m, 1, n_dev - 1, ADSB_FAULT_PHASE2) != ADSB_OK) rc = 1;
+            for (int k = 0; k < 3 && rc == 0; k++)
+                if (adsb_multi_icao_flush(m) != ADSB_OK || adsb_multi_submit_iq(m, iq, per * (size_t)n_dev) != ADSB_OK) rc = 1;
+            if (rc == 0 && (adsb_multi_collect(m, again, 256 * (size_t)n_dev, &n2) != ADSB_OK || n2 != n ||
+                            memcmp(again, msgs, n * sizeof(adsb_msg)) != 0))
+                rc = 1;
+            if (rc == 0 && adsb_multi_collect(m, again, 256 * (size_t)n_dev, &n2) != ADSB_ERR_HIP) rc = 1;
+            if (rc == 0 && !strstr(adsb_multi_last_error(m), "injected")) rc = 1;
+            if (rc == 0 && adsb_multi_submit_iq(m, iq, per * (size_t)n_dev) != ADSB_ERR_POISONED) rc = 1;
+            if (rc == 0 && adsb_multi_icao_flush(m) != ADSB_ERR_BUSY) rc = 1;
+            if (rc == 0 && adsb_multi_collect(m, again, 256 * (size_t)n_dev, &n2) != ADSB_ERR_POISONED) rc = 1;
+            if (rc == 0 && (adsb_multi_pending(m) != 0 || adsb_multi_icao_flush(m) != ADSB_OK)) rc = 1;
+            if (rc == 0 && (adsb_multi_demod_iq(m, iq, per * (size_t)n_dev, again, 256 * (size_t)n_dev, &n2) != ADSB_OK || n2 != n ||
+                            memcmp(again, msgs, n * sizeof(adsb_msg)) != 0))
+                rc = 1;
+            if (rc == 0) printf("multi: a failed shard poisoned the handle, the restart gave the blocking call's list again\n");
+        }
         free(again);
     }
 out:
