@@ -941,7 +941,7 @@ def run_shard(env: Env, args):
     merged = pipe.drain()[-1]       # (checked below: the overlapped form's result, whichever form was timed)
     pipe.close()
     # the single-stream answer: rank 0 demodulates the whole capture alone (untimed)
-    same, n_frames = None, None
+    same, n_frames, parity = None, None, None
     if env.rank == 0:
         whole = torch.cat([mine] + [shard_iq(r, env.dev) for r in range(1, env.world)]) if env.world > 1 else mine
         with Context(device=env.local_rank, max_chunks=min(512, total_chunks)) as solo:
@@ -950,6 +950,13 @@ def run_shard(env: Env, args):
         key = lambda m: (m.chunk, m.j, m.try_phase, m.score, m.msg, m.signal_level)
         same = [key(m) for m in merged] == [key(m) for m in want] and results == args.steps
         n_frames = len(want)
+        # ... and the CPU oracle over the whole capture
+        from oracle import binding
+        orc = binding.Oracle()
+        orc.icao_flush()
+        with env.all_cores():
+            oracle_want, _ = orc.demod_iq(whole.cpu().numpy(), cap=1 << 20, threads=_oracle_threads())
+        parity = _same(merged, oracle_want)
         del whole
     elapsed, frames = env.reduce(elapsed, frames)
     result = {
@@ -977,8 +984,14 @@ def run_shard(env: Env, args):
                    "library": _lib.lib().adsb_version().decode(),
                    "host_affinity": env.affinity_summary(),
                    "clock_ramp": ramp},
-        "shard_merge_equals_single_stream": same, "parity_frames": n_frames,
+        "shard_merge_equals_single_stream": same, "parity_checked": parity, "parity_frames": n_frames,
     }
+    ms_step = elapsed / args.steps * 1e3
+    gbs = total_chunks * CHUNK * BYTES_PER_SAMPLE / (ms_step * 1e-3) / 1e9
+    result["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * env.world, "unit": "GB/s",
+                          "frac": round(gbs / (HBM_PEAK_GBS * env.world), 4), "traffic": None,
+                          "is": f"{BYTES_PER_SAMPLE} B per sample x the capture's samples / the whole step (both shard phases, the exchange over "
+                                f"gloo, the gathered replay), against {env.world} x 8 TB/s"}
     for c in ctxs:
         c.close()
     return result

@@ -69,6 +69,7 @@ def test_bench_shard_workload_as_one_rank_over_rccl(hip_lib, oracle_mod):
     single stream) with RCCL as the default backend."""
     line = _bench_as_one_nccl_rank("--workload", "shard", "--capture-chunks", "48")
     assert line["backend"] == "nccl" and line["shard_merge_equals_single_stream"] is True and line["scaling"] == "strong"
+    assert line["parity_checked"] is True and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1     # (against the oracle too)
 
 
 def test_bench_one_process_over_all_devices_behind_the_ranks_timed_region(hip_lib, oracle_mod):
