@@ -464,10 +464,6 @@ void device_thread(adsb_multi *m, adsb_multi::Dev *d) noexcept
             return true;
         }
         if ((t - issued_at) * 1e3 > (double)m->timeout_ms.load(std::memory_order_relaxed)) {
-#ifdef ADSB_MULTI_DEBUG
-            std::fprintf(stderr, "TIMEOUT dev %d id %llu issued_at %.6f now %.6f p1 %.6f p2 %.6f hang %d fault_capture %llu w1 %d w2 %d\n", d->index, (unsigned long long)id,
-                         issued_at, t, sd.t_p1_issue, sd.t_p2_issue, (int)hang, (unsigned long long)m->fault_capture.load(), w1.n, w2.n);
-#endif
             d->dead.store(true, std::memory_order_relaxed);
             shard_failed(d, sd, ADSB_ERR_HIP, "a shard phase did not finish within the adsb_multi's timeout: the device is given up");
             return true;
