@@ -105,7 +105,14 @@ int device_streams(adsb_ctx *c, int device, bool small, DeviceStreams **out)
             const bool share = (variant == 0 || variant == 1) && k < 2;
             const int prio = variant == 0 || variant == 3 ? d->greatest : (variant == 4 ? d->least : mid);
             if (share) d->small[k] = d->high[k];
-            else if (variant == 5) HIP_TRY(c, dedicated_stream(device, &d->small[k]));
+            else if (variant == 5) {
+                // (a runtime that refuses the mask: the pool stream this used to be -- slower when the host's own streams
+                // crowd the pool, never wrong)
+                if (dedicated_stream(device, &d->small[k]) != hipSuccess) {
+                    (void)hipGetLastError();
+                    HIP_TRY(c, hipStreamCreateWithPriority(&d->small[k], hipStreamNonBlocking, mid));
+                }
+            }
             else HIP_TRY(c, hipStreamCreateWithPriority(&d->small[k], hipStreamNonBlocking, prio));
         }
     }
