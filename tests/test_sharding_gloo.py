@@ -325,3 +325,62 @@ def test_rank_affinity_plan_follows_the_gpus_numa_nodes(tmp_path):
     p = sharding.plan_affinity(2, 4, [], {}, range(8))
     assert p["cpus"] == [4, 5] and p["numa_node"] == -1
     assert sharding.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and sharding.parse_cpulist("") == []
+
+
+def _one_process_leg_worker(rank, world, port, q):
+    """bench.py's `one_process_n_devices_leg` with the GPU work stubbed out: what is under test is the choreography --
+    every rank creates the host-side (gloo) group, rank 0 alone works (here: sleeps, or raises), the others wait at the
+    group's barrier and nobody is left behind."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import contextlib
+    import time
+    import types
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        env = types.SimpleNamespace(torch=torch, dist=dist, rank=rank, world=world, local_rank=0,
+                                    all_cores=lambda: contextlib.nullcontext())
+        args = types.SimpleNamespace(steps=3, capture_chunks=8)
+        torch.cuda.device_count = lambda: 1     # (rank 0 sees one device: shards wrap around onto it)
+        seen = {}
+
+        def fake_leg(e, a, device_sets, steps):
+            seen["device_sets"] = device_sets
+            time.sleep(1.5)                     # the other rank must still be waiting when this returns
+            return {"runs": [], "parity_checked": True}
+
+        bench.config4_leg = fake_leg
+        t0 = time.perf_counter()
+        leg = bench.one_process_n_devices_leg(env, args)
+        waited = time.perf_counter() - t0
+        # ... and when the leg cannot run, the line still comes out and the waiting ranks are released
+        def broken_leg(e, a, device_sets, steps):
+            raise MemoryError("no room for the capture")
+        bench.config4_leg = broken_leg
+        leg2 = bench.one_process_n_devices_leg(env, args)
+        q.put((rank, leg, waited, seen.get("device_sets"), leg2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_process_leg_behind_the_timed_region_releases_every_rank():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_process_leg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, leg0, waited0, sets0, leg0b), (r1, leg1, waited1, sets1, leg1b) = got
+    assert (r0, r1) == (0, 1)
+    assert leg0["parity_checked"] is True and leg0["devices_visible_to_rank0"] == 1 and sets0 == [[0, 0]] and leg1 is None and sets1 is None
+    assert waited0 >= 1.4 and waited1 >= 1.2          # rank 1 sat at the host-side barrier while rank 0 worked
+    assert leg0b["parity_checked"] is None and "MemoryError" in leg0b["error"] and leg1b is None
