@@ -500,7 +500,7 @@ int main(int argc, char **argv)
     std::vector<orc_msg> scratch(cap);
     auto filt = std::make_unique<orc_filter>();
     size_t total_captures = 0, total_msgs = 0, failures_injected = 0, recoveries = 0, dead_handles = 0, blocked = 0, parallel = 0, poisoned_returns = 0;
-    size_t scored_used = 0, scored_refused = 0;
+    size_t scored_used = 0, scored_refused = 0, failed_resets = 0;
 
     for (int seq_no = 0; seq_no < sequences; seq_no++) {
         const int n_dev = 1 + (int)(rng() % 8);
@@ -584,6 +584,20 @@ int main(int argc, char **argv)
             while ((int)pending.size() >= depth && !bad) collect_one(step);
             if (bad) break;
             if (broken && pending.empty()) {
+                // now and then the reset of one context fails first: the flush says so, the handle stays poisoned, and the
+                // next flush -- nothing wrong any more -- restarts it
+                if (!hang && rng() % 4 == 0) {
+                    g_fail_countdown.store(1 + (int)(rng() % n_dev), std::memory_order_relaxed);
+                    g_fail_call.store(4, std::memory_order_relaxed);
+                    uint64_t c8[8] = {};
+                    if (adsb_multi_icao_flush(m) == ADSB_OK || adsb_multi_selftest_counters(m, c8) != ADSB_OK || c8[7] != 1 ||
+                        adsb_multi_submit_iq(m, arena.data(), kChunkSamples) != ADSB_ERR_POISONED) {
+                        std::fprintf(stderr, "sequence %d step %d: a restart whose reset failed did not leave the handle poisoned\n", seq_no, step);
+                        bad = true;
+                        break;
+                    }
+                    failed_resets++;
+                }
                 // the restart: flush, and the oracle's filter with it
                 const int rc = adsb_multi_icao_flush(m);
                 if (hang) {
@@ -705,8 +719,8 @@ int main(int argc, char **argv)
         }
     }
     std::printf("multi orchestration ok: %d sequences, %zu captures, %zu messages, %zu failures injected, %zu restarts, %zu dead handles, "
-                "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool, %zu shards scored by their device used, %zu refused\n",
+                "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool, %zu shards scored by their device used, %zu refused, %zu failed resets\n",
                 sequences, total_captures, total_msgs, failures_injected, recoveries, dead_handles, poisoned_returns, blocked, parallel, scored_used,
-                scored_refused);
+                scored_refused, failed_resets);
     return 0;
 }

@@ -100,7 +100,8 @@ def test_orchestration_under_thread_sanitizer(arena):
     assert count("failures") >= 40 and count("restarts,") >= 20 and count("dead") >= 3 and count("poisoned") >= 5
     assert count("blocking") >= 50 and int(words[words.index("captures,") - 1]) >= 1200
     # ... shards scored by their "device" were taken as they are, and refused (their records fetched by the shard's own thread)
-    assert int(words[words.index("used,") - 6]) >= 300 and int(words[words.index("refused") - 1]) >= 100
+    assert int(words[words.index("used,") - 6]) >= 300 and int(words[words.index("refused,") - 1]) >= 100
+    assert int(words[words.index("failed") - 1]) >= 5      # restarts whose reset failed first: the handle stayed poisoned
 
 
 def test_orchestration_under_address_and_ub_sanitizers(arena):
