@@ -179,7 +179,8 @@ struct FakeCtx {
 FakeCtx *fake_of(adsb_ctx *c) { return reinterpret_cast<FakeCtx *>(c->h_block); }
 
 // a failure the fake itself injects: the n-th call (counted over all contexts) of one of its entry points fails
-std::atomic<int> g_fail_call{-1};      // 0 shard_begin, 1 shard_learned, 2 shard_match, 3 shard_records, 4 shard_reset
+std::atomic<int> g_live_contexts{0};    // adsb_create - adsb_destroy
+std::atomic<int> g_fail_call{-1};      // 0 shard_begin, 1 shard_learned, 2 shard_match, 3 shard_records, 4 shard_reset, 5 adsb_create
 std::atomic<int> g_fail_countdown{0};
 bool fake_fails(adsb_ctx *c, int call)
 {
@@ -212,6 +213,11 @@ extern "C" {
 
 int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
 {
+    *out = nullptr;
+    if (g_fail_call.load(std::memory_order_relaxed) == 5 && g_fail_countdown.fetch_sub(1, std::memory_order_relaxed) == 1) {
+        g_fail_call.store(-1, std::memory_order_relaxed);
+        return ADSB_ERR_NOMEM;   // (the k-th context of an adsb_multi cannot be made: the ones before it must be undone)
+    }
     adsb_ctx *c = new adsb_ctx;
     c->device = device;
     c->max_chunks = max_chunks;
@@ -221,6 +227,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
     f->rng.seed(0x5EED0000u + (uint64_t)device * 977 + max_chunks);
     c->h_block = reinterpret_cast<char *>(f);
     c->flush_pending = true;
+    g_live_contexts.fetch_add(1, std::memory_order_relaxed);
     *out = c;
     return ADSB_OK;
 }
@@ -228,6 +235,7 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
 void adsb_destroy(adsb_ctx *c)
 {
     if (!c) return;
+    g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
     delete fake_of(c);
     delete c;
 }
@@ -500,7 +508,7 @@ int main(int argc, char **argv)
     std::vector<orc_msg> scratch(cap);
     auto filt = std::make_unique<orc_filter>();
     size_t total_captures = 0, total_msgs = 0, failures_injected = 0, recoveries = 0, dead_handles = 0, blocked = 0, parallel = 0, poisoned_returns = 0;
-    size_t scored_used = 0, scored_refused = 0, failed_resets = 0;
+    size_t scored_used = 0, scored_refused = 0, failed_resets = 0, failed_creates = 0;
 
     for (int seq_no = 0; seq_no < sequences; seq_no++) {
         const int n_dev = 1 + (int)(rng() % 8);
@@ -508,6 +516,16 @@ int main(int argc, char **argv)
         int devices[8];
         for (int k = 0; k < n_dev; k++) devices[k] = (int)(rng() % 8);
         adsb_multi *m = nullptr;
+        if (rng() % 16 == 0) {   // a context that cannot be made: create says so and leaves nothing behind
+            g_fail_countdown.store(1 + (int)(rng() % n_dev), std::memory_order_relaxed);
+            g_fail_call.store(5, std::memory_order_relaxed);
+            const int live_before = g_live_contexts.load();   // (handles whose device was given up keep that device's context: by design)
+            if (adsb_multi_create(&m, devices, n_dev, per) != ADSB_ERR_NOMEM || m != nullptr || g_live_contexts.load() != live_before) {
+                std::fprintf(stderr, "sequence %d: a failed adsb_multi_create returned success or left contexts behind\n", seq_no);
+                return 1;
+            }
+            failed_creates++;
+        }
         if (adsb_multi_create(&m, devices, n_dev, per) != ADSB_OK) return 1;
         const int wait_mode = (int)(rng() % 3);
         if (adsb_multi_set_wait(m, wait_mode) != ADSB_OK) return 1;
@@ -719,8 +737,8 @@ int main(int argc, char **argv)
         }
     }
     std::printf("multi orchestration ok: %d sequences, %zu captures, %zu messages, %zu failures injected, %zu restarts, %zu dead handles, "
-                "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool, %zu shards scored by their device used, %zu refused, %zu failed resets\n",
+                "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool, %zu shards scored by their device used, %zu refused, %zu failed resets, %zu failed creates\n",
                 sequences, total_captures, total_msgs, failures_injected, recoveries, dead_handles, poisoned_returns, blocked, parallel, scored_used,
-                scored_refused, failed_resets);
+                scored_refused, failed_resets, failed_creates);
     return 0;
 }

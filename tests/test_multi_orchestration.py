@@ -101,7 +101,8 @@ def test_orchestration_under_thread_sanitizer(arena):
     assert count("blocking") >= 50 and int(words[words.index("captures,") - 1]) >= 1200
     # ... shards scored by their "device" were taken as they are, and refused (their records fetched by the shard's own thread)
     assert int(words[words.index("used,") - 6]) >= 300 and int(words[words.index("refused,") - 1]) >= 100
-    assert int(words[words.index("failed") - 1]) >= 5      # restarts whose reset failed first: the handle stayed poisoned
+    assert int(words[words.index("resets,") - 2]) >= 5     # restarts whose reset failed first: the handle stayed poisoned
+    assert int(words[words.index("creates") - 2]) >= 5     # adsb_multi_create with a context that cannot be made: undone, nothing left
 
 
 def test_orchestration_under_address_and_ub_sanitizers(arena):
