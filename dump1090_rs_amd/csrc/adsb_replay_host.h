@@ -135,9 +135,16 @@ class ReplayPool {
     // a worker keeps spinning for the next job before it goes to sleep -- 0 for a host that is short of CPUs)
     explicit ReplayPool(int workers, std::function<void(int)> on_start = {}, int hot_us = 1500) : hot_us_(hot_us)
     {
-        for (int k = 0; k < workers; k++) th_.emplace_back([this, k, on_start] { work(k, on_start); });
+        try {
+            th_.reserve((size_t)workers);
+            for (int k = 0; k < workers; k++) th_.emplace_back([this, k, on_start] { work(k, on_start); });
+        } catch (...) {
+            shutdown();   // (a thread that could not be started: the ones that were must be joined before the vector goes)
+            throw;
+        }
     }
-    ~ReplayPool()
+    ~ReplayPool() { shutdown(); }
+    void shutdown() noexcept
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -145,7 +152,8 @@ class ReplayPool {
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        for (auto &t : th_) t.join();
+        for (auto &t : th_)
+            if (t.joinable()) t.join();
     }
     int threads() const { return (int)th_.size() + 1; }
     void run(ParallelReplay &pr, void (ParallelReplay::*stage)(int))
@@ -164,6 +172,9 @@ class ReplayPool {
         cv_.notify_all();
         take(*job, (int)th_.size());
         while (job->done.load(std::memory_order_acquire) < job->parts) __builtin_ia32_pause();
+        // (a stage that ran out of memory on a worker: an exception must not leave a thread function -- it is caught where
+        // it happens and raised again here, on the caller's thread, whose callers turn it into a status)
+        if (job->failed.load(std::memory_order_acquire)) throw std::bad_alloc();
     }
 
   private:
@@ -173,6 +184,7 @@ class ReplayPool {
         int parts = 0;
         std::unique_ptr<std::atomic<uint8_t>[]> claimed;
         std::atomic<int> done{0};
+        std::atomic<bool> failed{false};
     };
     // Thread `me` of T takes parts me, me + T, ... first -- the same ones in both stages of a capture, so the second
     // stage finds its records in the cache the first left them in -- and then whatever nobody has claimed (a thread
@@ -182,7 +194,11 @@ class ReplayPool {
         const int T = threads();
         auto claim = [&](int i) {
             if (job.claimed[(size_t)i].exchange(1, std::memory_order_acq_rel)) return;
-            (job.pr->*job.stage)(i);
+            try {
+                (job.pr->*job.stage)(i);
+            } catch (...) {
+                job.failed.store(true, std::memory_order_release);
+            }
             job.done.fetch_add(1, std::memory_order_release);
         };
         for (int i = me; i < job.parts; i += T) claim(i);

@@ -39,6 +39,31 @@
 using namespace adsb::host;
 
 // ------------------------------------------------------------------------------------------------------------------
+// operator new that can be told to fail: "the n-th allocation from now, on whichever thread, throws std::bad_alloc"
+// (include/adsb_hip.h: nothing is thrown across the ABI, nothing aborts -- main() arms it around single library calls)
+// ------------------------------------------------------------------------------------------------------------------
+// (GCC sees malloc / free inside the replaced operators inlined next to new-expressions and calls that a mismatch: it is the
+// pair the replacement defines)
+#pragma GCC diagnostic ignored "-Wmismatched-new-delete"
+static std::atomic<long> g_new_countdown{0};   // <= 0: off
+static std::atomic<long> g_new_failures{0};
+void *operator new(std::size_t n)
+{
+    if (g_new_countdown.load(std::memory_order_relaxed) > 0 && g_new_countdown.fetch_sub(1, std::memory_order_relaxed) == 1) {
+        g_new_failures.fetch_add(1, std::memory_order_relaxed);
+        throw std::bad_alloc();
+    }
+    void *p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void *operator new[](std::size_t n) { return operator new(n); }
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+
+// ------------------------------------------------------------------------------------------------------------------
 // HIP, as far as adsb_multi.cpp and the inline helpers of adsb_ctx.h use it
 // ------------------------------------------------------------------------------------------------------------------
 static thread_local int t_device = 0;
@@ -218,12 +243,20 @@ int adsb_create(adsb_ctx **out, int device, size_t max_chunks)
         g_fail_call.store(-1, std::memory_order_relaxed);
         return ADSB_ERR_NOMEM;   // (the k-th context of an adsb_multi cannot be made: the ones before it must be undone)
     }
-    adsb_ctx *c = new adsb_ctx;
+    adsb_ctx *c = nullptr;
+    FakeCtx *f = nullptr;
+    try {   // (the real adsb_create returns ADSB_ERR_NOMEM where this would throw: csrc/adsb_context.cpp)
+        c = new adsb_ctx;
+        f = new FakeCtx;
+        f->cur = std::make_shared<AddrSet>();
+        f->cur->insert(0);
+    } catch (...) {
+        delete c;
+        delete f;
+        return ADSB_ERR_NOMEM;
+    }
     c->device = device;
     c->max_chunks = max_chunks;
-    FakeCtx *f = new FakeCtx;
-    f->cur = std::make_shared<AddrSet>();
-    f->cur->insert(0);
     f->rng.seed(0x5EED0000u + (uint64_t)device * 977 + max_chunks);
     c->h_block = reinterpret_cast<char *>(f);
     c->flush_pending = true;
@@ -736,6 +769,96 @@ int main(int argc, char **argv)
             return 1;
         }
     }
+    // ---- allocation failures: around ONE library call at a time the n-th operator new from now throws, on whichever thread
+    // it falls (the caller's, a device thread's, a pool worker's, the fake's own code below the library).  Whatever the call
+    // and the captures in flight then return, nothing may throw across the ABI, terminate or hang; and once what is in flight
+    // has been collected and the stream restarted (adsb_multi_icao_flush, as often as it takes), the handle gives the
+    // oracle's list again.
+    size_t alloc_rounds = 0, alloc_calls_failed = 0;
+    for (int seq_no = 0; seq_no < std::max(8, sequences / 4); seq_no++) {
+        const int n_dev = 1 + (int)(rng() % 8);
+        const size_t per = 1 + rng() % 3;
+        int devices[8];
+        for (int k = 0; k < n_dev; k++) devices[k] = (int)(rng() % 8);
+        adsb_multi *m = nullptr;
+        g_new_countdown.store(rng() % 3 == 0 ? 1 + (long)(rng() % 40) : 0);   // (a third of the creates meet one too)
+        int rc = adsb_multi_create(&m, devices, n_dev, per);
+        g_new_countdown.store(0);
+        if (rc != ADSB_OK) {
+            if (m != nullptr || rc != ADSB_ERR_NOMEM) {
+                std::fprintf(stderr, "alloc sequence %d: adsb_multi_create returned %d with a handle %p\n", seq_no, rc, (void *)m);
+                return 1;
+            }
+            alloc_calls_failed++;
+            if (adsb_multi_create(&m, devices, n_dev, per) != ADSB_OK) return 1;
+        }
+        (void)adsb_multi_set_wait(m, (int)(rng() % 3));
+        (void)adsb_multi_selftest_tune(m, 0, rng() % 2 ? 1 : 0, (uint32_t)(rng() % 3));
+        const size_t room = (size_t)n_dev * per;
+        bool bad = false;
+        for (int round = 0; round < 6 && !bad; round++) {
+            const size_t chunks = std::min<size_t>(1 + rng() % room, arena_chunks);
+            const size_t first = rng() % (arena_chunks - chunks + 1);
+            const size_t n_samples = chunks * kChunkSamples;
+            const int16_t *iq = arena.data() + 2 * first * kChunkSamples;
+            const void *ptrs[8];
+            size_t ns[8];
+            for (int k = 0; k < n_dev; k++) {
+                size_t a = 0;
+                (void)adsb_multi_shard_range(n_samples, n_dev, k, &a, &ns[k]);
+                ptrs[k] = ns[k] ? iq + 2 * a : nullptr;
+            }
+            // a few captures in flight, then ONE call with the countdown armed
+            const int in_flight = (int)(rng() % 4);
+            for (int k = 0; k < in_flight; k++) (void)adsb_multi_submit_iq_device(m, ptrs, ns);
+            size_t n = 0;
+            const int which = (int)(rng() % 6);
+            g_new_countdown.store(1 + (long)(rng() % 60));
+            if (which == 0) rc = adsb_multi_submit_iq_device(m, ptrs, ns);
+            else if (which == 1) rc = adsb_multi_pending(m) ? adsb_multi_collect(m, got.data(), cap, &n) : adsb_multi_demod_iq(m, iq, n_samples, got.data(), cap, &n);
+            else if (which == 2) rc = adsb_multi_pending(m) ? adsb_multi_collect(m, got.data(), cap, &n) : adsb_multi_demod_iq_device(m, ptrs, ns, got.data(), cap, &n);
+            else if (which == 3) rc = adsb_multi_submit_iq(m, iq, n_samples);
+            else if (which == 4) rc = adsb_multi_icao_flush(m);
+            else {
+                void *p = nullptr;
+                rc = adsb_multi_host_alloc(m, 4096, &p);
+                if (rc == ADSB_OK && adsb_multi_pending(m) == 0) (void)adsb_multi_host_free(m, p);
+            }
+            // (let the captures in flight meet the rest of the countdown on their device threads, then switch it off)
+            std::this_thread::sleep_for(std::chrono::microseconds(rng() % 1500));
+            g_new_countdown.store(0);
+            alloc_rounds++;
+            alloc_calls_failed += rc != ADSB_OK;
+            // drain, restart, and the stream must be the oracle's again
+            for (int guard = 0; adsb_multi_pending(m) > 0; guard++) {
+                (void)adsb_multi_collect(m, got.data(), cap, &n);
+                if (guard > 16) {
+                    std::fprintf(stderr, "alloc sequence %d round %d: captures stay in flight for ever\n", seq_no, round);
+                    bad = true;
+                    break;
+                }
+            }
+            int tries = 0;
+            while (!bad && (rc = adsb_multi_icao_flush(m)) != ADSB_OK)
+                if (++tries > 3) {
+                    std::fprintf(stderr, "alloc sequence %d round %d: the restart keeps returning %d (%s)\n", seq_no, round, rc, adsb_multi_last_error(m));
+                    bad = true;
+                }
+            if (bad) break;
+            orc_icao_flush(filt.get());
+            const size_t k = orc_demod_iq(filt.get(), iq, n_samples, scratch.data(), cap, nullptr);
+            std::vector<orc_msg> want(scratch.begin(), scratch.begin() + (long)k);
+            rc = adsb_multi_demod_iq_device(m, ptrs, ns, got.data(), cap, &n);
+            if (rc != ADSB_OK || !same(got.data(), n, want, "after an allocation failure and the restart", seq_no, round)) {
+                std::fprintf(stderr, "alloc sequence %d round %d: after the restart the capture returned %d (%s)\n", seq_no, round, rc, adsb_multi_last_error(m));
+                bad = true;
+            }
+        }
+        adsb_multi_destroy(m);
+        if (bad) return 1;
+    }
+    std::printf("allocation failures ok: %zu armed calls, %ld allocations failed, %zu calls returned an error\n", alloc_rounds,
+                g_new_failures.load(), alloc_calls_failed);
     std::printf("multi orchestration ok: %d sequences, %zu captures, %zu messages, %zu failures injected, %zu restarts, %zu dead handles, "
                 "%zu poisoned returns, %zu blocking handles, %zu captures scored by the pool, %zu shards scored by their device used, %zu refused, %zu failed resets, %zu failed creates\n",
                 sequences, total_captures, total_msgs, failures_injected, recoveries, dead_handles, poisoned_returns, blocked, parallel, scored_used,

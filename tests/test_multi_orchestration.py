@@ -7,7 +7,9 @@ it: the handful of HIP calls it makes itself and the shard_* entry points of csr
 its shard with the oracle, keeps the address superset the real context keeps, scores about half of its shards itself (as
 k_score / k_emit do, here by the oracle's score_modes_message), and lands its phases from another thread after random delays.  The driver in that file runs random sequences -- 1-8 devices, up to four captures in flight, flushes,
 host and device forms, spin and block waits, injected failures of every kind (the product's own hook and the fake's)
-followed by the restart -- and compares every capture with ONE oracle stream.  CPU only; the same scenarios run on the
+followed by the restart -- and compares every capture with ONE oracle stream; then it makes the n-th `operator new` from now
+throw std::bad_alloc, on whichever thread it falls, around single library calls: nothing may cross the ABI, terminate or hang,
+and after the restart the handle must give the oracle's list again.  CPU only; the same scenarios run on the
 GPU through the real backend in tests/test_gpu_multi.py."""
 import shutil
 import subprocess
@@ -95,7 +97,7 @@ def test_orchestration_under_thread_sanitizer(arena):
     assert r.returncode == 0 and "multi orchestration ok: 300 sequences" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     # the run did what it is for: failures of both kinds were injected, handles restarted, some devices given up, both wait modes
-    words = r.stdout.split()
+    words = [ln for ln in r.stdout.splitlines() if ln.startswith("multi orchestration ok")][0].split()
     count = lambda what: int(words[words.index(what) - 1])   # noqa: E731
     assert count("failures") >= 40 and count("restarts,") >= 20 and count("dead") >= 3 and count("poisoned") >= 5
     assert count("blocking") >= 50 and int(words[words.index("captures,") - 1]) >= 1200
@@ -103,6 +105,12 @@ def test_orchestration_under_thread_sanitizer(arena):
     assert int(words[words.index("used,") - 6]) >= 300 and int(words[words.index("refused,") - 1]) >= 100
     assert int(words[words.index("resets,") - 2]) >= 5     # restarts whose reset failed first: the handle stayed poisoned
     assert int(words[words.index("creates") - 2]) >= 5     # adsb_multi_create with a context that cannot be made: undone, nothing left
+    # ... and the allocation failures: std::bad_alloc from the n-th operator new on whichever thread, around single library
+    # calls -- nothing thrown across the ABI, nothing terminated, every handle restarted and equal to the oracle again
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("allocation failures ok")]
+    assert line, r.stdout[-1500:]
+    w = line[0].split()
+    assert int(w[w.index("armed") - 1]) >= 400 and int(w[w.index("allocations") - 1]) >= 100 and int(w[w.index("calls", 5) - 1]) >= 50
 
 
 def test_orchestration_under_address_and_ub_sanitizers(arena):
