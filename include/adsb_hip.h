@@ -19,9 +19,14 @@
  *     benches/demod_benchmark.rs:10-11                      adsb_demod_iq / _device
  *
  * Conventions: every function returns ADSB_OK (0) or a negative adsb_status and
- * never throws, aborts or panics across the ABI; the caller owns every host
+ * never throws, aborts or panics across the ABI (an allocation that fails inside
+ * comes back as ADSB_ERR_NOMEM); the caller owns every host
  * buffer; all pointers are plain host pointers except where the name says
- * `device`.  One adsb_ctx per host thread / per GPU: the ICAO address filter
+ * `device`.  After ADSB_ERR_HIP or ADSB_ERR_NOMEM from a demodulating call the
+ * pass it was working on is lost and the filter may have seen part of it: an
+ * adsb_ctx is then best destroyed and made anew (or adsb_icao_flush'ed, if starting
+ * from an empty filter is acceptable); an adsb_multi says so itself
+ * (ADSB_ERR_POISONED) and restarts on adsb_multi_icao_flush.  One adsb_ctx per host thread / per GPU: the ICAO address filter
  * (process-global statics in the reference, src/icao_filter.rs:8-9) lives in the
  * context, so contexts are independent streams.  There is no CPU fallback:
  * adsb_create fails with ADSB_ERR_NO_DEVICE when no gfx950 device is usable.
